@@ -1,0 +1,145 @@
+"""The CPU oracle (oracle/drin_oracle.py) against the fixtures produced by the unmodified
+reference forward (oracle/gen_golden.py).  CPU only; no reference import at test time."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import drin_oracle as O
+from oracle.cases import CASES, TINY, build_case
+from drin_amd import synth
+from drin_amd.config import DrinConfig
+
+ATOL = 2e-6  # fp32 re-association only: same ops, vectorised
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"{name}.npz"))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference(golden_dir, name):
+    cfg, sd, batch = build_case(name)
+    g = _load(golden_dir, name)
+    trace = {}
+    scores = O.forward(sd, batch, num_layers=cfg.num_gcn_layers, edge_enabled=cfg.gcn_edge_enabled,
+                       dynamic=cfg.gcn_edge_type == "dynamic", trace=trace)
+    assert scores.shape == (batch[0].shape[0], cfg.num_candidates_model)
+    np.testing.assert_allclose(scores.numpy(), g["scores"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(trace["edge0"][0].numpy(), g["mtet"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(trace["edge0"][3].numpy(), g["miei"], atol=ATOL, rtol=0)
+    full = CASES[name][4]
+    for l in range(cfg.num_gcn_layers + 1):
+        v = trace[f"vertex{l}"]
+        np.testing.assert_allclose(v[0].numpy(), g[f"mt{l}"], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(v[1].numpy(), g[f"mi{l}"], atol=1e-5, rtol=1e-5)
+        for nm, t in (("et", v[2]), ("ei", v[3])):
+            ref = g[f"{nm}{l}"]
+            np.testing.assert_allclose((t if full else t[0]).numpy(), ref, atol=1e-5, rtol=1e-5)
+            assert abs(t.double().norm().item() - float(g[f"{nm}{l}_l2"])) <= 1e-5 * float(g[f"{nm}{l}_l2"])
+        if l > 0:
+            np.testing.assert_allclose(torch.stack(trace[f"edge{l}"]).numpy(), g[f"edges{l}"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n][5]])
+def test_backward_matches_reference(golden_dir, name):
+    """autograd through the restatement == autograd through the reference (linear functional of
+    the scores, then the triplet loss), including which parameters receive no gradient."""
+    cfg, sd, batch = build_case(name)
+    g = _load(golden_dir, name)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = dict(num_layers=cfg.num_gcn_layers, edge_enabled=cfg.gcn_edge_enabled, dynamic=cfg.gcn_edge_type == "dynamic")
+    scores = O.forward(p, batch, **kw)
+    rng = np.random.Generator(np.random.Philox(key=[int(g["functional_weights_seed"]), 99]))
+    w = torch.from_numpy(rng.standard_normal(size=tuple(scores.shape), dtype=np.float32))
+    grads = torch.autograd.grad((scores * w).sum(), list(p.values()), allow_unused=True)
+    none = sorted(k for k, gr in zip(p, grads) if gr is None)
+    assert none == sorted(g["grad_none"].tolist())
+    full = CASES[name][4]
+    for k, gr in zip(p, grads):
+        if gr is None:
+            continue
+        l2 = float(g[f"lin_grad_l2/{k}"])
+        assert abs(gr.double().norm().item() - l2) <= 2e-4 * l2 + 1e-7, k
+        ref = g[f"lin_grad/{k}"]
+        got = gr.numpy() if full else gr.flatten()[:16].numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-4 * l2 / np.sqrt(gr.numel()) + 1e-7, rtol=1e-3, err_msg=k)
+    # triplet loss value and gradient norms
+    p2 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = O.triplet_loss(batch[-1], O.forward(p2, batch, **kw), cfg.triplet_margin)
+    assert abs(loss.item() - float(g["triplet_loss"])) <= 2e-6
+    grads = torch.autograd.grad(loss, list(p2.values()), allow_unused=True)
+    for k, gr in zip(p2, grads):
+        if gr is not None:
+            l2 = float(g[f"loss_grad_l2/{k}"])
+            assert abs(gr.double().norm().item() - l2) <= 5e-4 * l2 + 1e-9, k
+
+
+def test_empty_span_is_nan_row_only(golden_dir):
+    cfg = DrinConfig(**TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    batch = synth.make_batch(cfg, 3, 11)
+    batch[3][1] = batch[2][1]
+    s = O.forward(sd, batch).numpy()
+    g = _load(golden_dir, "tiny_wd_nan")["scores"]
+    assert np.isnan(g[1]).all() and np.isfinite(g[[0, 2]]).all()
+    assert np.isnan(s[1]).all()
+    np.testing.assert_allclose(s[[0, 2]], g[[0, 2]], atol=ATOL, rtol=0)
+
+
+def test_triplet_loss_matches_reference_source(golden_dir):
+    g = _load(golden_dir, "triplet")
+    for i in range(3):
+        got = O.triplet_loss(torch.from_numpy(g[f"y{i}"]), torch.from_numpy(g[f"yhat{i}"]), 0.25)
+        assert abs(got.item() - float(g[f"loss{i}"])) <= 1e-6
+
+
+def test_triplet_loss_known_answer():
+    # B=2, N-1=2 (+1 answer slot dropped).  p = -yhat[:, :2] = [[-.5,.2],[.1,-.3]]
+    y = torch.tensor([[1, 0], [0, 1]], dtype=torch.uint8)
+    yhat = torch.tensor([[0.5, -0.2, 9.0], [-0.1, 0.3, 9.0]])
+    # pos = [-.5, -.3]; i=0: mean(relu(-.5 - p + .25)) over all 4 = mean(relu([.25,-.45,-.35,.05])) = .075
+    # i=1: relu(-.3 - p + .25) = relu([.45,-.25,-.15,.25]) -> mean .175 ; loss = (.075+.175)/2
+    assert abs(O.triplet_loss(y, yhat, 0.25).item() - 0.125) < 1e-7
+
+
+def test_topk_known_answer():
+    yhat = torch.tensor([[0.9, 0.1, 0.5, 7.0], [0.2, 0.2, 0.1, 7.0], [0.3, 0.6, 0.1, 7.0]])
+    y = torch.tensor([[0, 0, 1], [0, 1, 0], [0, 0, 0]], dtype=torch.uint8)
+    # top-1: row0 gold .5 < .9 miss; row1 gold ties the max (.2 >= .2) hit; row2 has no gold
+    assert O.topk_counts(yhat, y, 1) == (1, 3)
+    assert O.topk_counts(yhat, y, 2) == (2, 3)
+
+
+def test_cosine_semantics_pinned():
+    """torch>=2 clamps each norm separately."""
+    x = torch.tensor([[1e-9, 0.0]])
+    assert abs(O.cosine(x, x).item() - 0.01) < 1e-9
+    a, b = torch.randn(5, 7, 33), torch.randn(5, 7, 33)
+    np.testing.assert_allclose(O.cosine(a, b).numpy(), torch.nn.functional.cosine_similarity(a, b, dim=-1).numpy(), atol=1e-7)
+    assert O.cosine(torch.zeros(1, 4), torch.ones(1, 4)).item() == 0.0
+
+
+def test_entity_token_mean_slice_semantics():
+    feat = torch.arange(2 * 3 * 6 * 2, dtype=torch.float32).reshape(2, 3, 6, 2)
+    mask = torch.zeros(2, 3, 6, dtype=torch.int64)
+    ntoks = [[3, 6, 0], [1, 2, 4]]
+    for b in range(2):
+        for n in range(3):
+            mask[b, n, : ntoks[b][n]] = 1
+    got = O.entity_token_mean(feat, mask)
+    for b in range(2):
+        for n in range(3):
+            ref = feat[b, n, 1: ntoks[b][n] - 1].mean(0)   # baselines/ghmfc.py:249 verbatim slice
+            assert torch.allclose(got[b, n], ref, equal_nan=True), (b, n)
+
+
+def test_mention_independence():
+    """No cross-mention term in Model.forward: a sub-batch scores identically."""
+    cfg = DrinConfig(**TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    batch = synth.make_batch(cfg, 6, 21)
+    full = O.forward(sd, batch)
+    sub = O.forward(sd, [t[2:5] for t in batch])
+    np.testing.assert_allclose(full[2:5].numpy(), sub.numpy(), atol=1e-6)

@@ -1,0 +1,199 @@
+"""bench.py - mention x candidate pairs scored per second on WikiMEL-shaped synthetic batches.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload wikimel|wikidiverse] [--batch B]
+
+One "step" = one pass of the DRIN scoring path (Model.forward, drin/model.py:164-209) over one
+batch of B mentions x N candidates of seeded synthetic features that are already resident in HBM.
+N>1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; every rank scores
+its own shard of mentions (weak scaling, no data-path collective - mentions are independent,
+SURVEY.md 8e); the timed region is bracketed by barrier + synchronize and the max over ranks is used.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : dominant kernel class, HIP-event timed inside this process
+  cpu_baseline : the CPU oracle (oracle/drin_oracle.py) timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from drin_amd import _lib, synth  # noqa: E402
+from drin_amd.config import DrinConfig, wikimel_config  # noqa: E402
+from drin_amd.model import Model  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def path_flops_per_pair(D, R, layers, dynamic):
+    """FLOPs per pair the HIP path executes (dead work of the last layer removed, SURVEY.md 8a tail)."""
+    f = 2.0 * D * D + 2.0 * R * D                       # W_et, W_ei
+    for l in range(layers):
+        last = l == layers - 1
+        f += 2.0 * D * D * (1 if last else 2)           # W_h on et (+ ei unless last)
+        if dynamic and not last:
+            f += 2.0 * D * D * 2                        # W_v on et, ei
+    return f
+
+
+def algorithmic_bytes_per_pair(cfg, batch):
+    """Compulsory input bytes per pair: entity-side rows that are actually needed
+    + the mention-side bytes amortised over the N candidates + the 4-byte score."""
+    B, N = batch[0].shape[0], cfg.num_candidates_model
+    D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
+    if cfg.token_level_entities:
+        ntok = batch[8].sum(-1).float()
+        rows = (ntok - 2).clamp(min=0) + 1              # pooled tokens 1..ntok-2 plus the CLS row
+        ent_text = float(rows.mean()) * D * 4 + batch[8].shape[-1] * 8
+    else:
+        ent_text = D * 4
+    ent = ent_text + R * 4 + cfg.object_topk_entity * R * 4 + (cfg.object_topk_entity + 2) * 4
+    span = float((batch[3] - batch[2]).float().mean())
+    men = span * D * 4 + cfg.resnet_num_region * R * 4 + cfg.object_topk_mention * (R + 1) * 4 + 16
+    return ent + men / N + 4
+
+
+def cpu_baseline(cfg, sd, seconds=12.0):
+    from oracle import drin_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 8 if cfg.token_level_entities else 64
+    batch = synth.make_batch(cfg, B, 3)
+    with torch.no_grad():
+        O.forward(sd, batch)  # warm-up
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            O.forward(sd, batch)
+            it += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or it >= 50:
+                break
+    pairs = it * B * cfg.num_candidates_model
+    return {"value": pairs / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={cfg.num_candidates_model} fp32, "
+                      f"torch {torch.get_num_threads()} threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="wikimel", choices=["wikimel", "wikidiverse"])
+    ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 256 wikimel / 4096 wikidiverse)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
+    B = args.batch or (256 if args.workload == "wikimel" else 4096)
+    sd = synth.make_state_dict(cfg, 7)
+    model = Model(cfg).to(dev).eval()
+    model.load_state_dict(sd)
+    batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
+    N = cfg.num_candidates_model
+    pairs_per_step = B * N
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(batch)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(batch)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(out).all()
+
+        # instrumented pass: per-kernel-class GPU time from HIP events on the launch stream
+        _lib.profile_begin(1 << 16)
+        for _ in range(args.steps):
+            model(batch)
+        prof = _lib.profile_end()
+
+    if rank == 0:
+        D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
+        total_ms = sum(v[0] for v in prof.values())
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, launches = prof[dom]
+        per_launch_ms = ms / max(launches, 1)
+        flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic")
+        bytes_pair = algorithmic_bytes_per_pair(cfg, batch)
+        if dom == "gemm":
+            # mention-side Linears ride in the same kernel: 2 vertex Linears + per layer W_h (2 rows sets) + W_u
+            men_flops = B * (2.0 * D * D + 2.0 * R * D + sum(
+                2.0 * D * D * ((1 if l == cfg.num_gcn_layers - 1 else 2) + (0 if l == cfg.num_gcn_layers - 1 else 2))
+                for l in range(cfg.num_gcn_layers)))
+            work = (flops_pair * pairs_per_step + men_flops) * args.steps / max(launches, 1)   # flops per launch
+            achieved = work / (per_launch_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_gemm_f32", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                    "launches": int(launches), "avg_launch_ms": per_launch_ms}
+        else:
+            work = bytes_pair * pairs_per_step * args.steps / max(launches, 1)
+            achieved = work / (per_launch_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": None, "launches": int(launches),
+                    "avg_launch_ms": per_launch_ms}
+        value = pairs_per_step * world * args.steps / elapsed
+        line = {
+            "metric": "mention x candidate pairs scored/sec",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.dataset_name}-shaped scoring forward: {N - 1}-cand (+1 answer slot), D={D}, R={R}, "
+                                   f"L={cfg.max_mention_sentence_len}, P={cfg.resnet_num_region}"
+                                   + (f", T={cfg.max_entity_attr_token_len} token-level entity text" if cfg.token_level_entities else ""),
+                       "mentions_per_step_per_gpu": B, "pairs_per_step": pairs_per_step * world,
+                       "parallelism": f"dp{world} (mentions sharded, no collective)"},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "hbm_fraction_whole_path": bytes_pair * value / world / (PEAK_HBM_GBS * 1e9),
+            "mfma_f32_fraction_whole_path": flops_pair * value / world / (PEAK_F32_MATRIX_TFLOPS * 1e12),
+            "algorithmic": {"bytes_per_pair": bytes_pair, "flops_per_pair_executed": flops_pair,
+                            "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Builds libdrin_hip.so (gfx950) in-tree with hipcc.  No GPU is needed: hipcc cross-compiles.
+
+    python -m drin_amd.build [--force] [--debug]
+
+The shared library is written next to this file so that it travels with the source tree
+(it is git-ignored, not gpurun-ignored).  Objects are rebuilt only when a source or header
+is newer than them.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libdrin_hip.so")
+ARCH = "gfx950"
+SOURCES = ["api.hip", "stream_kernels.hip", "gemm_f32.hip", "gcn_kernels.hip"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newest_header() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str:
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    hipcc = _hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden",
+             f"-I{INCLUDE}", f"-I{CSRC}"]
+    if debug:
+        flags += ["-g", "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    hdr_t = _newest_header()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            jobs.append([hipcc, "-c", s, "-o", o] + flags)
+
+    def run(cmd):
+        if verbose:
+            print("[drin_amd.build]", " ".join(cmd[:5]), "...", flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, debug="--debug" in sys.argv))

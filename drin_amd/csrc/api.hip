@@ -1,0 +1,510 @@
+// C ABI of libdrin_hip.so (include/drin_hip.h): argument validation, workspace layout and the launch
+// sequence of Model.forward (drin/model.py:164-209).  Host code only; kernels live in the sibling files.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "internal.h"
+#include "layout.h"
+
+namespace drin {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return DRIN_E_HIP;
+}
+
+// ---- thread-local kernel profile ---------------------------------------------------------------
+struct Profile {
+  bool open = false;
+  int capacity = 0, used = 0;
+  hipEvent_t* start = nullptr;
+  hipEvent_t* stop = nullptr;
+  int* cls = nullptr;
+};
+static thread_local Profile g_prof;
+
+KernelTimer::KernelTimer(int kernel_class, hipStream_t st) : slot(-1), stream(st) {
+  Profile& p = g_prof;
+  if (!p.open || p.used >= p.capacity) return;
+  slot = p.used++;
+  p.cls[slot] = kernel_class;
+  (void)hipEventRecord(p.start[slot], st);
+}
+
+KernelTimer::~KernelTimer() {
+  if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], stream);
+}
+
+static void profile_free(Profile& p) {
+  for (int i = 0; i < p.capacity; ++i) {
+    if (p.start) (void)hipEventDestroy(p.start[i]);
+    if (p.stop) (void)hipEventDestroy(p.stop[i]);
+  }
+  delete[] p.start;
+  delete[] p.stop;
+  delete[] p.cls;
+  p = Profile();
+}
+
+int validate_config(const drin_config* c) {
+  if (!c) {
+    set_error("config is NULL");
+    return DRIN_E_NULL;
+  }
+  if (c->batch < 0 || c->num_candidates <= 0 || c->embed_dim <= 0 || c->image_dim <= 0 || c->mention_tokens <= 0 ||
+      c->image_regions <= 0 || c->mention_objects < 0 || c->entity_objects < 0 || c->entity_tokens < 0 ||
+      c->mention_object_inner < 0 || c->entity_image_inner < 0 || c->entity_object_inner < 0) {
+    set_error("config: negative or zero dimension");
+    return DRIN_E_SHAPE;
+  }
+  if (c->embed_dim % 4 || c->image_dim % 4) {
+    set_error("config: embed_dim=%d and image_dim=%d must be multiples of 4 (16-byte lane accesses)", c->embed_dim,
+              c->image_dim);
+    return DRIN_E_SHAPE;
+  }
+  if (c->embed_dim > 1024) {
+    set_error("config: embed_dim=%d > 1024 is not built (LayerNorm row kept in registers)", c->embed_dim);
+    return DRIN_E_UNSUPPORTED;
+  }
+  if (c->num_layers < 0 || c->num_layers > DRIN_MAX_LAYERS) {
+    set_error("config: num_layers=%d outside [0, %d]", c->num_layers, DRIN_MAX_LAYERS);
+    return DRIN_E_SHAPE;
+  }
+  if ((int64_t)c->batch * c->num_candidates > (int64_t)1 << 30) {
+    set_error("config: batch * num_candidates too large for one call; split the batch");
+    return DRIN_E_SHAPE;
+  }
+  if (c->precision != DRIN_PREC_F32) {
+    set_error("config: precision %d is not built yet (fp32 MFMA only)", c->precision);
+    return DRIN_E_UNSUPPORTED;
+  }
+  return DRIN_OK;
+}
+
+static int validate_batch(const drin_config* c, const drin_batch* b) {
+  if (!b) {
+    set_error("batch is NULL");
+    return DRIN_E_NULL;
+  }
+  const void* req[] = {b->mention_text,  b->mention_start,        b->mention_end,     b->mention_image,
+                       b->mention_object, b->mention_object_score, b->entity_text,     b->entity_image,
+                       b->entity_object,  b->entity_object_score,  b->miet_similarity, b->mtei_similarity};
+  const char* names[] = {"mention_text",   "mention_start",        "mention_end",     "mention_image",
+                         "mention_object", "mention_object_score", "entity_text",     "entity_image",
+                         "entity_object",  "entity_object_score",  "miet_similarity", "mtei_similarity"};
+  for (int i = 0; i < 12; ++i) {
+    if (!req[i]) {
+      set_error("batch.%s is NULL", names[i]);
+      return DRIN_E_NULL;
+    }
+  }
+  if (c->entity_tokens > 0 && !b->entity_text_mask) {
+    set_error("batch.entity_text_mask is NULL but entity_tokens=%d", c->entity_tokens);
+    return DRIN_E_NULL;
+  }
+  const void* al[] = {b->mention_text, b->mention_image, b->mention_object, b->entity_text, b->entity_image,
+                      b->entity_object};
+  for (const void* p : al)
+    if (!aligned16(p)) {
+      set_error("batch: feature tensors must be 16-byte aligned");
+      return DRIN_E_ALIGN;
+    }
+  return DRIN_OK;
+}
+
+static int validate_params(const drin_config* c, const drin_params* p) {
+  if (!p) {
+    set_error("params is NULL");
+    return DRIN_E_NULL;
+  }
+  const void* req[] = {p->w_mention_text,  p->b_mention_text,  p->w_entity_text,  p->b_entity_text,
+                       p->w_mention_image, p->b_mention_image, p->w_entity_image, p->b_entity_image};
+  for (const void* q : req)
+    if (!q || !aligned16(q)) {
+      set_error("params: vertex encoder tensor NULL or not 16-byte aligned");
+      return q ? DRIN_E_ALIGN : DRIN_E_NULL;
+    }
+  for (int l = 0; l < c->num_layers; ++l) {
+    const drin_layer_params& L = p->layer[l];
+    const void* lr[] = {L.w_h, L.b_h, L.w_u, L.b_u, L.w_v, L.b_v, L.ln_weight, L.ln_bias};
+    for (const void* q : lr)
+      if (!q || !aligned16(q)) {
+        set_error("params: layer %d tensor NULL or not 16-byte aligned", l);
+        return q ? DRIN_E_ALIGN : DRIN_E_NULL;
+      }
+  }
+  return DRIN_OK;
+}
+
+// Resolves the pooled / raw operand pointers of the vertex and edge encoders and runs the pooling.
+int run_pooling(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out, hipStream_t st) {
+  const int B = c->batch, N = c->num_candidates, D = c->embed_dim, R = c->image_dim;
+  const int64_t M = (int64_t)B * N;
+  out->span_mean = ws + L.span_mean;
+  DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B, c->mention_tokens,
+                            D, st));
+  out->mention_image = ws + L.mimg_pool;
+  DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg_pool, B, c->image_regions, R, st));
+  if (c->mention_object_inner > 1) {
+    DRIN_TRY(launch_axis_mean(b->mention_object, ws + L.mobj_pool, (int64_t)B * c->mention_objects,
+                              c->mention_object_inner, R, st));
+    out->mention_object = ws + L.mobj_pool;
+  } else {
+    out->mention_object = b->mention_object;
+  }
+  if (c->entity_object_inner > 1) {
+    DRIN_TRY(launch_axis_mean(b->entity_object, ws + L.eobj_pool, M * c->entity_objects, c->entity_object_inner, R, st));
+    out->entity_object = ws + L.eobj_pool;
+  } else {
+    out->entity_object = b->entity_object;
+  }
+  if (c->entity_image_inner > 1) {
+    DRIN_TRY(launch_axis_mean(b->entity_image, ws + L.eimg_pool, M, c->entity_image_inner, R, st));
+    out->entity_image = ws + L.eimg_pool;
+  } else {
+    out->entity_image = b->entity_image;
+  }
+  if (c->entity_tokens > 0) {
+    DRIN_TRY(launch_entity_token_mean(b->entity_text, b->entity_text_mask, ws + L.xet_pool, M, c->entity_tokens, D, st));
+    out->entity_text = ws + L.xet_pool;
+    out->entity_text_raw_stride = (int64_t)c->entity_tokens * D;  // token 0 = CLS (model.py:73-75)
+  } else {
+    out->entity_text = b->entity_text;
+    out->entity_text_raw_stride = D;
+  }
+  return DRIN_OK;
+}
+
+int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P, float* edges, hipStream_t st) {
+  const int B = c->batch, N = c->num_candidates;
+  const int64_t M = (int64_t)B * N;
+  // tt (model.py:71-76), ti = mtei / 100, it = miet / 100 (model.py:203), ii (model.py:78-92)
+  DRIN_TRY(launch_cosine_rows(P.span_mean, b->entity_text, P.entity_text_raw_stride, edges + 0 * M, B, N, c->embed_dim,
+                              c->cosine_eps, 1.0f, st));
+  DRIN_TRY(launch_scale_div(b->mtei_similarity, edges + 1 * M, M, 1.0f, c->clip_scale, st));
+  DRIN_TRY(launch_scale_div(b->miet_similarity, edges + 2 * M, M, 1.0f, c->clip_scale, st));
+  DRIN_TRY(launch_miei(P.mention_object, b->mention_object_score, P.entity_object, b->entity_object_score,
+                       edges + 3 * M, B, N, c->mention_objects, c->entity_objects, c->image_dim, c->cosine_eps,
+                       c->miei_eps, 1.0f, st));
+  return DRIN_OK;
+}
+
+static int copy_out(float* dst, const float* src, size_t n, hipStream_t st) {
+  if (!dst) return DRIN_OK;
+  hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(trace)");
+  return DRIN_OK;
+}
+
+static int tap(const drin_trace* t, int l, const Layout& L, const float* ws, int B, int64_t M, int D, hipStream_t st) {
+  if (!t) return DRIN_OK;
+  DRIN_TRY(copy_out(t->mention_text_vertex[l], ws + L.vm[l], (size_t)B * D, st));
+  DRIN_TRY(copy_out(t->mention_image_vertex[l], ws + L.vm[l] + (size_t)B * D, (size_t)B * D, st));
+  DRIN_TRY(copy_out(t->entity_text_vertex[l], ws + L.ve[l], (size_t)M * D, st));
+  DRIN_TRY(copy_out(t->entity_image_vertex[l], ws + L.ve[l] + (size_t)M * D, (size_t)M * D, st));
+  DRIN_TRY(copy_out(t->edges[l], ws + L.edges[l], (size_t)4 * M, st));
+  return DRIN_OK;
+}
+
+}  // namespace drin
+
+using namespace drin;
+
+extern "C" {
+
+int drin_version(void) { return DRIN_ABI_VERSION; }
+
+const char* drin_last_error(void) { return g_err; }
+
+const char* drin_build_info(void) { return "gfx950 hipcc " __VERSION__ " " __DATE__; }
+
+int drin_default_config(drin_config* cfg) {
+  if (!cfg) {
+    set_error("config is NULL");
+    return DRIN_E_NULL;
+  }
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->batch = 0;
+  cfg->num_candidates = 11;
+  cfg->embed_dim = 768;
+  cfg->image_dim = 2048;
+  cfg->mention_tokens = 128;
+  cfg->image_regions = 49;
+  cfg->mention_objects = 3;
+  cfg->entity_objects = 1;
+  cfg->entity_tokens = 0;
+  cfg->mention_object_inner = 1;
+  cfg->entity_image_inner = 0;
+  cfg->entity_object_inner = 0;
+  cfg->num_layers = 2;
+  cfg->dynamic_edges = 1;
+  for (int k = 0; k < 4; ++k) cfg->edge_enabled[k] = 1.0f;
+  cfg->layer_norm_eps = 1e-5f;
+  cfg->cosine_eps = 1e-8f;
+  cfg->miei_eps = 1e-9f;
+  cfg->clip_scale = 100.0f;
+  cfg->precision = DRIN_PREC_F32;
+  return DRIN_OK;
+}
+
+size_t drin_workspace_bytes(const drin_config* cfg, int for_training) {
+  if (validate_config(cfg) != DRIN_OK) return 0;
+  Layout L;
+  L.build(*cfg, for_training != 0);
+  return L.total_floats * sizeof(float);
+}
+
+int drin_edges_fwd(const drin_config* cfg, const drin_batch* batch, float* edges, float* span_mean, void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(validate_batch(cfg, batch));
+  if (!edges) {
+    set_error("edges is NULL");
+    return DRIN_E_NULL;
+  }
+  if (cfg->mention_object_inner > 1 || cfg->entity_object_inner > 1) {
+    set_error("drin_edges_fwd: inner object dims > 1 need the pooled path of drin_forward");
+    return DRIN_E_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int B = cfg->batch, D = cfg->embed_dim;
+  if (!span_mean) {
+    set_error("drin_edges_fwd: span_mean scratch [B, D] is required");
+    return DRIN_E_NULL;
+  }
+  DRIN_TRY(launch_span_mean(batch->mention_text, batch->mention_start, batch->mention_end, span_mean, B,
+                            cfg->mention_tokens, D, st));
+  Pooled P;
+  P.span_mean = span_mean;
+  P.mention_object = batch->mention_object;
+  P.entity_object = batch->entity_object;
+  P.entity_text_raw_stride = cfg->entity_tokens > 0 ? (int64_t)cfg->entity_tokens * D : D;
+  return run_static_edges(cfg, batch, P, edges, st);
+}
+
+int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled_entity_text,
+                  float* pooled_mention_image, float* pooled_entity_image, void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(validate_batch(cfg, batch));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t M = (int64_t)cfg->batch * cfg->num_candidates;
+  if (pooled_entity_text) {
+    if (cfg->entity_tokens <= 0) {
+      set_error("drin_pool_fwd: entity text is already pooled when entity_tokens == 0");
+      return DRIN_E_SHAPE;
+    }
+    DRIN_TRY(launch_entity_token_mean(batch->entity_text, batch->entity_text_mask, pooled_entity_text, M,
+                                      cfg->entity_tokens, cfg->embed_dim, st));
+  }
+  if (pooled_mention_image)
+    DRIN_TRY(launch_axis_mean(batch->mention_image, pooled_mention_image, cfg->batch, cfg->image_regions,
+                              cfg->image_dim, st));
+  if (pooled_entity_image) {
+    const int inner = cfg->entity_image_inner > 0 ? cfg->entity_image_inner : 1;
+    DRIN_TRY(launch_axis_mean(batch->entity_image, pooled_entity_image, M, inner, cfg->image_dim, st));
+  }
+  return DRIN_OK;
+}
+
+int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t rows, int32_t n_out, int32_t k,
+                    int32_t precision, void* stream) {
+  if (!x || !w || !y) {
+    set_error("drin_linear_fwd: NULL operand");
+    return DRIN_E_NULL;
+  }
+  if (rows < 0 || n_out <= 0 || k <= 0) {
+    set_error("drin_linear_fwd: bad shape rows=%lld n_out=%d k=%d", (long long)rows, n_out, k);
+    return DRIN_E_SHAPE;
+  }
+  return launch_gemm_nt(x, k, w, k, bias, y, n_out, rows, n_out, k, false, precision, (hipStream_t)stream);
+}
+
+int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
+                 size_t workspace_bytes, float* scores, int keep_for_backward, const drin_trace* trace, void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(validate_batch(cfg, batch));
+  DRIN_TRY(validate_params(cfg, params));
+  if (!scores) {
+    set_error("scores is NULL");
+    return DRIN_E_NULL;
+  }
+  Layout L;
+  L.build(*cfg, keep_for_backward != 0);
+  if (!workspace || !aligned16(workspace)) {
+    set_error("workspace is NULL or not 16-byte aligned");
+    return workspace ? DRIN_E_ALIGN : DRIN_E_NULL;
+  }
+  if (workspace_bytes < L.total_floats * sizeof(float)) {
+    set_error("workspace has %zu bytes, needs %zu", workspace_bytes, L.total_floats * sizeof(float));
+    return DRIN_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
+  const int64_t M = (int64_t)B * N;
+  const int nl = cfg->num_layers;
+  const int prec = cfg->precision;
+  if (B == 0) return DRIN_OK;
+  // dead work of the last layer (its edge update and its image-vertex updates never reach the score,
+  // SURVEY.md 3.2) is only computed when a trace asks to see it
+  const bool full = trace != nullptr;
+
+  Pooled P;
+  DRIN_TRY(run_pooling(cfg, batch, L, ws, &P, st));
+  DRIN_TRY(run_static_edges(cfg, batch, P, ws + L.edges[0], st));
+
+  // VertexEncoder (model.py:26-46): four Linears
+  float* vm0 = ws + L.vm[0];
+  float* ve0 = ws + L.ve[0];
+  DRIN_TRY(launch_gemm_nt(P.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false,
+                          prec, st));
+  DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
+                          D, B, D, R, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
+                          prec, st));
+  DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
+                          M, D, R, false, prec, st));
+  DRIN_TRY(tap(trace, 0, L, ws, B, M, D, st));
+
+  bool all_enabled = true;
+  for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
+
+  for (int l = 0; l < nl; ++l) {
+    const drin_layer_params& W = params->layer[l];
+    const bool last = l == nl - 1;
+    const bool live_image = !last || full;                       // mi / ei updates
+    const bool live_edges = cfg->dynamic_edges && (!last || full);
+    const float* e = ws + L.edges[l];
+    if (!all_enabled) {  // edges = [e * m ...] (model.py:122)
+      float* me = ws + L.masked[l];
+      for (int k = 0; k < 4; ++k) DRIN_TRY(launch_scale_div(e + k * M, me + k * M, M, cfg->edge_enabled[k], 1.0f, st));
+      e = me;
+    }
+    const float *e_tt = e, *e_ti = e + M, *e_it = e + 2 * M, *e_ii = e + 3 * M;
+    const float* mt = ws + L.vm[l];
+    const float* mi = mt + (size_t)B * D;
+    const float* et = ws + L.ve[l];
+    const float* ei = et + (size_t)M * D;
+    float* agg_m = ws + L.agg_m[l];
+    float* agg_e = ws + L.agg_e[l];
+    // neighbour aggregation, vertex_graph of model.py:105
+    DRIN_TRY(launch_mention_aggregate(e_tt, et, e_ti, ei, mt, agg_m, B, N, D, st));
+    DRIN_TRY(launch_entity_aggregate(e_tt, mt, e_it, mi, et, agg_e, B, N, D, st));
+    if (live_image) {
+      DRIN_TRY(launch_mention_aggregate(e_it, et, e_ii, ei, mi, agg_m + (size_t)B * D, B, N, D, st));
+      DRIN_TRY(launch_entity_aggregate(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
+    }
+    const int types = live_image ? 2 : 1;
+    // shared W_h + LayerNorm + GELU for all vertex types of the layer (model.py:128)
+    float* h_m = ws + L.h_m[l];
+    float* h_e = ws + L.h_e[l];
+    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st));
+    DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st));
+    float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
+    float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
+    DRIN_TRY(launch_layernorm_gelu(h_m, W.ln_weight, W.ln_bias, ws + L.vm[l + 1], st_m, st_m ? st_m + 2 * (size_t)B : nullptr,
+                                   (int64_t)types * B, D, cfg->layer_norm_eps, st));
+    DRIN_TRY(launch_layernorm_gelu(h_e, W.ln_weight, W.ln_bias, ws + L.ve[l + 1], st_e, st_e ? st_e + 2 * (size_t)M : nullptr,
+                                   (int64_t)types * M, D, cfg->layer_norm_eps, st));
+    // dynamic edges, edge_graph of model.py:107: (mt,et) (mt,ei) (mi,et) (mi,ei)
+    float* e_next = ws + L.edges[l + 1];
+    if (live_edges) {
+      float* fu = ws + L.fu[l];
+      float* fv = ws + L.fv[l];
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st));
+      for (int k = 0; k < 4; ++k) {
+        const float* fuk = fu + (size_t)(k >> 1) * B * D;
+        const float* fvk = fv + (size_t)(k & 1) * M * D;
+        DRIN_TRY(launch_edge_update(fuk, fvk, e + k * M, e_next + k * M, B, N, D, st));
+      }
+    } else if (!cfg->dynamic_edges) {
+      hipError_t err = hipMemcpyAsync(e_next, e, 4 * M * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (err != hipSuccess) return hip_fail(err, "hipMemcpyAsync(static edges)");
+    }
+    if (full) DRIN_TRY(tap(trace, l + 1, L, ws, B, M, D, st));
+  }
+  // score (model.py:207-209)
+  return launch_cosine_rows(ws + L.vm[nl], ws + L.ve[nl], D, scores, B, N, D, cfg->cosine_eps, 1.0f, st);
+}
+
+int drin_profile_begin(int max_launches) {
+  Profile& p = g_prof;
+  if (p.open) profile_free(p);
+  if (max_launches <= 0 || max_launches > (1 << 20)) {
+    set_error("drin_profile_begin: max_launches=%d outside (0, 2^20]", max_launches);
+    return DRIN_E_SHAPE;
+  }
+  p.start = new hipEvent_t[max_launches];
+  p.stop = new hipEvent_t[max_launches];
+  p.cls = new int[max_launches];
+  for (int i = 0; i < max_launches; ++i) {
+    hipError_t e = hipEventCreate(&p.start[i]);
+    if (e == hipSuccess) e = hipEventCreate(&p.stop[i]);
+    if (e != hipSuccess) {
+      p.capacity = i;
+      profile_free(p);
+      return hip_fail(e, "hipEventCreate");
+    }
+  }
+  p.capacity = max_launches;
+  p.used = 0;
+  p.open = true;
+  return DRIN_OK;
+}
+
+int drin_profile_end(double* ms_by_class, int64_t* launches_by_class) {
+  Profile& p = g_prof;
+  if (!p.open) {
+    set_error("drin_profile_end: no profile open on this thread");
+    return DRIN_E_SHAPE;
+  }
+  for (int k = 0; k < DRIN_KC_COUNT; ++k) {
+    if (ms_by_class) ms_by_class[k] = 0.0;
+    if (launches_by_class) launches_by_class[k] = 0;
+  }
+  int status = DRIN_OK;
+  for (int i = 0; i < p.used; ++i) {
+    hipError_t e = hipEventSynchronize(p.stop[i]);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
+    if (e != hipSuccess) {
+      status = hip_fail(e, "hipEventElapsedTime");
+      break;
+    }
+    const int k = p.cls[i];
+    if (k >= 0 && k < DRIN_KC_COUNT) {
+      if (ms_by_class) ms_by_class[k] += ms;
+      if (launches_by_class) launches_by_class[k] += 1;
+    }
+  }
+  if (status == DRIN_OK && p.used >= p.capacity) {
+    set_error("drin_profile_end: profile overflowed its %d launch slots", p.capacity);
+    status = DRIN_E_SHAPE;
+  }
+  profile_free(p);
+  return status;
+}
+
+const char* drin_kernel_class_name(int kernel_class) {
+  static const char* names[DRIN_KC_COUNT] = {"gemm", "pool", "edge", "gcn"};
+  return (kernel_class >= 0 && kernel_class < DRIN_KC_COUNT) ? names[kernel_class] : "?";
+}
+
+int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
+                  size_t workspace_bytes, const float* grad_scores, const drin_param_grads* grads, void* stream) {
+  (void)cfg; (void)batch; (void)params; (void)workspace; (void)workspace_bytes; (void)grad_scores; (void)grads; (void)stream;
+  set_error("drin_backward: not built yet");
+  return DRIN_E_UNSUPPORTED;
+}
+
+}  // extern "C"

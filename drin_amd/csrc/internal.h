@@ -1,0 +1,81 @@
+// Host-side internals of libdrin_hip.so: launch wrappers, error plumbing, workspace layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/drin_hip.h"
+
+namespace drin {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DRIN_CHECK_LAUNCH(what)                                  \
+  do {                                                           \
+    hipError_t _e = hipGetLastError();                           \
+    if (_e != hipSuccess) return ::drin::hip_fail(_e, what);     \
+  } while (0)
+
+#define DRIN_TRY(expr)              \
+  do {                              \
+    int _s = (expr);                \
+    if (_s != DRIN_OK) return _s;   \
+  } while (0)
+
+// Brackets the launches issued during its lifetime with hipEvents when a profile is open on this
+// thread (drin_profile_begin); otherwise free.
+struct KernelTimer {
+  KernelTimer(int kernel_class, hipStream_t st);
+  ~KernelTimer();
+  int slot;
+  hipStream_t stream;
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- streaming / pooling kernels (stream_kernels.hip) -------------------------------------------
+// out[g, c] = mean_s in[g, s, c]
+int launch_axis_mean(const float* in, float* out, int64_t groups, int inner, int cols, hipStream_t st);
+// Avg.avg (ghmfc.py:54-60): out[b, :] = mean(seq[b, start[b]:end[b], :])
+int launch_span_mean(const float* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
+                     hipStream_t st);
+// ghmfc.py:245-249: out[p, :] = mean(feat[p, 1:ntok-1, :]), ntok = sum(mask[p, :])
+int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
+                             hipStream_t st);
+// out[b*N + n] = scale * cos(x[b, :], y[(b*N + n) * y_stride : +D])
+int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
+                       float scale, hipStream_t st);
+// model.py:84-92: weighted object-pair similarity
+int launch_miei(const float* mobj, const float* mscore, const float* eobj, const float* escore, float* out, int B,
+                int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st);
+// out[i] = in[i] * mul / div
+int launch_scale_div(const float* in, float* out, int64_t n, float mul, float div, hipStream_t st);
+
+// ---- GEMM (gemm_f32.hip) ------------------------------------------------------------------------
+// y[m, n] (+)= sum_k x[m, k] * w[n, k] + bias[n];  x row stride ldx, w row stride ldw, y row stride ldy
+int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
+                   int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st);
+// y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)
+int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
+                   int K, bool accumulate, int precision, hipStream_t st);
+// y[n, k] += sum_m a[m, n] * b[m, k]          (used by backward: dW = dY^T * X), split over m
+int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
+                   int K, int precision, hipStream_t st);
+
+// ---- GCN elementwise / reduction kernels (gcn_kernels.hip) --------------------------------------
+// model.py:143-144 + :128 input: out[b,:] = mean_n(e1[b,n] v1[b,n,:]) + mean_n(e2[b,n] v2[b,n,:]) + u[b,:]
+int launch_mention_aggregate(const float* e1, const float* v1, const float* e2, const float* v2, const float* u,
+                             float* out, int B, int N, int D, hipStream_t st);
+// model.py:146 + :128 input: out[b,n,:] = e1[b,n] m1[b,:] + e2[b,n] m2[b,:] + v[b,n,:]
+int launch_entity_aggregate(const float* e1, const float* m1, const float* e2, const float* m2, const float* v,
+                            float* out, int B, int N, int D, hipStream_t st);
+// model.py:128: y = gelu(layer_norm(h)) row-wise; optionally keeps mean / rstd for backward
+int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          int64_t rows, int D, float eps, hipStream_t st);
+// model.py:148-153 + :133: out[b,n] = sigmoid(mean_d(fu[b,:] fv[b,n,:]) + e[b,n])
+int launch_edge_update(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
+                       hipStream_t st);
+
+}  // namespace drin

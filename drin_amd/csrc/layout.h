@@ -1,0 +1,112 @@
+// Workspace layout of one forward (+ backward) pass.  All offsets are in floats from the 16-byte
+// aligned workspace base the caller owns; every region starts on a 256-byte boundary.
+//
+// Inference (training == false) re-uses the per-layer scratch regions across layers and ping-pongs
+// the vertex buffers; training keeps every layer's intermediates because backward reads them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/drin_hip.h"
+
+namespace drin {
+
+struct Pooled {
+  const float* span_mean = nullptr;      // [B, D]   mean of the mention span (ghmfc.py:54-60)
+  const float* mention_image = nullptr;  // [B, R]   mean over regions (model.py:41)
+  const float* mention_object = nullptr; // [B, Km, R]
+  const float* entity_object = nullptr;  // [B, N, Ke, R]
+  const float* entity_image = nullptr;   // [B, N, R]
+  const float* entity_text = nullptr;    // [B, N, D] pooled (ghmfc.py:245-249) or as delivered
+  int64_t entity_text_raw_stride = 0;    // row stride of the raw CLS / pooler vector (model.py:73-75)
+};
+
+struct Layout {
+  bool training = false;
+  size_t total_floats = 0;
+  size_t span_mean = 0, mimg_pool = 0, mobj_pool = 0, eobj_pool = 0, eimg_pool = 0, xet_pool = 0;
+  size_t edges[DRIN_MAX_LAYERS + 1] = {};   // [4][M]  tt, ti, it, ii
+  size_t masked[DRIN_MAX_LAYERS] = {};      // [4][M]  edges * gcn_edge_enabled (model.py:122)
+  size_t vm[DRIN_MAX_LAYERS + 1] = {};      // [2][B][D]  mention text, mention image vertex
+  size_t ve[DRIN_MAX_LAYERS + 1] = {};      // [2][M][D]  entity text, entity image vertex
+  size_t agg_m[DRIN_MAX_LAYERS] = {};       // [2][B][D]  W_h input of the mention vertices
+  size_t agg_e[DRIN_MAX_LAYERS] = {};       // [2][M][D]  W_h input of the entity vertices
+  size_t h_m[DRIN_MAX_LAYERS] = {};         // [2][B][D]  pre-LayerNorm
+  size_t h_e[DRIN_MAX_LAYERS] = {};         // [2][M][D]
+  size_t ln_stat_m[DRIN_MAX_LAYERS] = {};   // [2][2][B]  mean, rstd   (training only)
+  size_t ln_stat_e[DRIN_MAX_LAYERS] = {};   // [2][2][M]
+  size_t fu[DRIN_MAX_LAYERS] = {};          // [2][B][D]  W_u(mt), W_u(mi)
+  size_t fv[DRIN_MAX_LAYERS] = {};          // [2][M][D]  W_v(et), W_v(ei)
+  size_t bwd_scratch = 0;                   // backward temporaries (training only)
+  size_t bwd_scratch_floats = 0;
+
+  size_t take(size_t n) {
+    const size_t o = total_floats;
+    total_floats += (n + 63) & ~(size_t)63;
+    return o;
+  }
+
+  void build(const drin_config& c, bool train) {
+    training = train;
+    total_floats = 0;
+    const size_t B = (size_t)c.batch, N = (size_t)c.num_candidates, D = (size_t)c.embed_dim, R = (size_t)c.image_dim;
+    const size_t M = B * N;
+    const int nl = c.num_layers;
+    span_mean = take(B * D);
+    mimg_pool = take(B * R);
+    mobj_pool = take(c.mention_object_inner > 1 ? B * c.mention_objects * R : 0);
+    eobj_pool = take(c.entity_object_inner > 1 ? M * c.entity_objects * R : 0);
+    eimg_pool = take(c.entity_image_inner > 1 ? M * R : 0);
+    xet_pool = take(c.entity_tokens > 0 ? M * D : 0);
+    if (train) {
+      for (int l = 0; l <= nl; ++l) {
+        edges[l] = take(4 * M);
+        vm[l] = take(2 * B * D);
+        ve[l] = take(2 * M * D);
+      }
+      for (int l = 0; l < nl; ++l) {
+        masked[l] = take(4 * M);
+        agg_m[l] = take(2 * B * D);
+        agg_e[l] = take(2 * M * D);
+        h_m[l] = take(2 * B * D);
+        h_e[l] = take(2 * M * D);
+        ln_stat_m[l] = take(4 * B);
+        ln_stat_e[l] = take(4 * M);
+        fu[l] = take(2 * B * D);
+        fv[l] = take(2 * M * D);
+      }
+      // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
+      bwd_scratch_floats = 6 * (2 * M * D) + 8 * (2 * B * D) + 4 * (4 * M) + 4 * M + 4 * B + 1024;
+      bwd_scratch = take(bwd_scratch_floats);
+    } else {
+      size_t e2[2] = {take(4 * M), take(4 * M)};
+      size_t vm2[2] = {take(2 * B * D), take(2 * B * D)};
+      size_t ve2[2] = {take(2 * M * D), take(2 * M * D)};
+      for (int l = 0; l <= nl; ++l) {
+        edges[l] = e2[l & 1];
+        vm[l] = vm2[l & 1];
+        ve[l] = ve2[l & 1];
+      }
+      const size_t s_masked = take(4 * M), s_agg_m = take(2 * B * D), s_agg_e = take(2 * M * D);
+      const size_t s_fu = take(2 * B * D);
+      for (int l = 0; l < nl; ++l) {
+        masked[l] = s_masked;
+        agg_m[l] = s_agg_m;
+        agg_e[l] = s_agg_e;
+        // pre-LN values are written straight into the next vertex buffer and normalised in place
+        h_m[l] = vm[l + 1];
+        h_e[l] = ve[l + 1];
+        fu[l] = s_fu;
+        // W_v(et), W_v(ei) are consumed by the edge update before the next layer touches agg_e
+        fv[l] = s_agg_e;
+      }
+    }
+  }
+};
+
+int validate_config(const drin_config* c);
+int run_pooling(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out, hipStream_t st);
+int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P, float* edges, hipStream_t st);
+
+}  // namespace drin

@@ -1,0 +1,250 @@
+// HBM-bound, parameter-free kernels of the path: input pooling (VertexEncoder, drin/model.py:41-45,
+// baselines/ghmfc.py:54-60,245-249) and the static edges (EdgeEncoder, drin/model.py:60-94).
+// All are pure streaming: 16-byte loads per lane, one pass over the bytes they need, wave64 shuffle
+// reductions, no LDS.
+#include "device_utils.h"
+#include "internal.h"
+
+namespace drin {
+
+// ------------------------------------------------------------------------------------------------
+// out[g, c] = mean_s in[g, s, c]      (region mean over P, "inner" means of model.py:43-44,78-83)
+// grid: (ceil(cols/4 / 256), groups); each thread owns one float4 column and walks the inner axis.
+__global__ void __launch_bounds__(256) k_axis_mean(const float* __restrict__ in, float* __restrict__ out, int inner,
+                                                   int cols4) {
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 >= cols4) return;
+  const int64_t g = blockIdx.y;
+  const float* p = in + (g * inner) * (int64_t)cols4 * 4 + (int64_t)c4 * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 7 <= inner; s += 7) {  // 7 independent 16-B loads in flight (P = 49 = 7 * 7)
+    float4 v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = ld4(p + (int64_t)(s + j) * cols4 * 4);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc = acc + v[j];
+  }
+  for (; s < inner; ++s) acc = acc + ld4(p + (int64_t)s * cols4 * 4);
+  const float cnt = (float)inner;  // sum / count like torch.mean (a true division, not a reciprocal multiply)
+  st4(out + g * (int64_t)cols4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt));
+}
+
+int launch_axis_mean(const float* in, float* out, int64_t groups, int inner, int cols, hipStream_t st) {
+  if (groups <= 0) return DRIN_OK;
+  if (cols % 4 != 0 || inner <= 0) {
+    set_error("axis_mean: cols=%d must be a multiple of 4 and inner=%d positive", cols, inner);
+    return DRIN_E_SHAPE;
+  }
+  if (groups > 65535) {  // grid.y limit: fold in chunks
+    for (int64_t g0 = 0; g0 < groups; g0 += 65535) {
+      const int64_t n = groups - g0 < 65535 ? groups - g0 : 65535;
+      DRIN_TRY(launch_axis_mean(in + g0 * inner * cols, out + g0 * cols, n, inner, cols, st));
+    }
+    return DRIN_OK;
+  }
+  const int cols4 = cols / 4;
+  dim3 grid((unsigned)cdiv(cols4, 256), (unsigned)groups);
+  KernelTimer timer(DRIN_KC_POOL, st);
+  hipLaunchKernelGGL(k_axis_mean, grid, dim3(256), 0, st, in, out, inner, cols4);
+  DRIN_CHECK_LAUNCH("k_axis_mean");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Avg.avg (baselines/ghmfc.py:54-60).  Python slice semantics: the range is clipped to [0, L]; an
+// empty range gives 0/0 = NaN like torch.mean of an empty slice.  grid: (ceil(D/4/256), B).
+__global__ void __launch_bounds__(256) k_span_mean(const float* __restrict__ seq, const int64_t* __restrict__ start,
+                                                   const int64_t* __restrict__ end, float* __restrict__ out, int L,
+                                                   int D4) {
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 >= D4) return;
+  const int b = blockIdx.y;
+  int64_t s = start[b], e = end[b];
+  if (s < 0) s = s + L < 0 ? 0 : s + L;  // python negative index
+  if (e < 0) e = e + L < 0 ? 0 : e + L;
+  if (e > L) e = L;
+  if (s > L) s = L;
+  const float* p = seq + ((int64_t)b * L) * D4 * 4 + (int64_t)c4 * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t t = s; t < e; ++t) acc = acc + ld4(p + t * D4 * 4);
+  const float cnt = e > s ? (float)(e - s) : 0.0f;  // empty span: 0 / 0 = NaN, as the reference
+  st4(out + (int64_t)b * D4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt));
+}
+
+int launch_span_mean(const float* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
+                     hipStream_t st) {
+  if (B <= 0) return DRIN_OK;
+  if (D % 4 != 0) {
+    set_error("span_mean: D=%d must be a multiple of 4", D);
+    return DRIN_E_SHAPE;
+  }
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    dim3 grid((unsigned)cdiv(D / 4, 256), (unsigned)nb);
+    KernelTimer timer(DRIN_KC_POOL, st);
+    hipLaunchKernelGGL(k_span_mean, grid, dim3(256), 0, st, seq + (int64_t)b0 * L * D, start + b0, end + b0,
+                       out + (int64_t)b0 * D, L, D / 4);
+    DRIN_CHECK_LAUNCH("k_span_mean");
+  }
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// WikiMEL entity pooling (baselines/ghmfc.py:245-249): x[p] = mean(feat[p, 1:ntok-1]), ntok = sum(mask[p]).
+// Only the rows inside the slice are read (the compulsory bytes).  One block per pair;
+// each thread owns float4 columns and keeps 8 token rows in flight.
+__global__ void __launch_bounds__(256) k_entity_token_mean(const float* __restrict__ feat,
+                                                           const int64_t* __restrict__ mask, float* __restrict__ out,
+                                                           int T, int D4) {
+  const int64_t p = blockIdx.x;
+  // every wave recomputes ntok (T <= 512 int64 values, L2/L1 resident) - cheaper than a barrier
+  int cnt = 0;
+  for (int t = threadIdx.x & 63; t < T; t += 64) cnt += (int)mask[p * T + t];
+  cnt = (int)wave_sum((float)cnt);  // T <= 2^24: exact in fp32
+  int stop = cnt - 1;
+  if (stop < 0) stop += T;  // python negative stop index (ntok == 0 -> 1:-1)
+  if (stop < 0) stop = 0;
+  if (stop > T) stop = T;
+  const int n = stop - 1;  // rows 1 .. stop-1
+  const float* base = feat + p * (int64_t)T * D4 * 4;
+  for (int c4 = threadIdx.x; c4 < D4; c4 += blockDim.x) {
+    const float* col = base + (int64_t)c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int t = 1;
+    for (; t + 8 <= stop; t += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ld4(col + (int64_t)(t + j) * D4 * 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = acc + v[j];
+    }
+    for (; t < stop; ++t) acc = acc + ld4(col + (int64_t)t * D4 * 4);
+    const float den = n > 0 ? (float)n : 0.0f;  // empty slice: 0 / 0 = NaN, as the reference
+    st4(out + p * (int64_t)D4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den));
+  }
+}
+
+int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
+                             hipStream_t st) {
+  if (pairs <= 0) return DRIN_OK;
+  if (D % 4 != 0 || T <= 0) {
+    set_error("entity_token_mean: D=%d must be a multiple of 4, T=%d positive", D, T);
+    return DRIN_E_SHAPE;
+  }
+  const int D4 = D / 4;
+  int threads = D4 >= 192 ? 192 : (D4 > 64 ? 128 : 64);  // D = 768 -> one float4 column per thread, 3 waves
+  KernelTimer timer(DRIN_KC_POOL, st);
+  hipLaunchKernelGGL(k_entity_token_mean, dim3((unsigned)pairs), dim3(threads), 0, st, feat, mask, out, T, D4);
+  DRIN_CHECK_LAUNCH("k_entity_token_mean");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b*N+n] = scale * cos(x[b], y[pair])  -- one wave per pair.  Used for the tt edge (model.py:71-76,
+// y = entity pooler vector or token 0 of the token block) and for the final score (model.py:207-209).
+__global__ void __launch_bounds__(256) k_cosine_rows(const float* __restrict__ x, const float* __restrict__ y,
+                                                     int64_t y_stride, float* __restrict__ out, int64_t pairs, int N,
+                                                     int D4, float eps, float scale) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= pairs) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (p / N) * (int64_t)D4 * 4;
+  const float* yr = y + p * y_stride;
+  float xy = 0.f, xx = 0.f, yy = 0.f;
+  for (int c4 = lane; c4 < D4; c4 += 64) {
+    const float4 a = ld4(xr + c4 * 4), b = ld4(yr + c4 * 4);
+    xy += dot4(a, b);
+    xx += dot4(a, a);
+    yy += dot4(b, b);
+  }
+  xy = wave_sum(xy);
+  xx = wave_sum(xx);
+  yy = wave_sum(yy);
+  if (lane == 0) out[p] = scale * cosine_from_sums(xy, xx, yy, eps);
+}
+
+int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
+                       float scale, hipStream_t st) {
+  const int64_t pairs = (int64_t)B * N;
+  if (pairs <= 0) return DRIN_OK;
+  if (D % 4 != 0 || y_stride % 4 != 0) {
+    set_error("cosine_rows: D=%d and stride=%lld must be multiples of 4", D, (long long)y_stride);
+    return DRIN_E_SHAPE;
+  }
+  KernelTimer timer(DRIN_KC_EDGE, st);
+  hipLaunchKernelGGL(k_cosine_rows, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, x, y, y_stride, out, pairs, N,
+                     D / 4, eps, scale);
+  DRIN_CHECK_LAUNCH("k_cosine_rows");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// miei (model.py:84-92): sum_{i<Km, j<Ke} cos(mobj[b,i], eobj[b,n,j]) ms[b,i] es[b,n,j] / (sum ms es + 1e-9)
+// One wave per pair.  The entity object rows are streamed once per (i); the Km mention rows are
+// re-used by all N candidates of the mention and stay in L1/L2.
+__global__ void __launch_bounds__(256) k_miei(const float* __restrict__ mobj, const float* __restrict__ mscore,
+                                              const float* __restrict__ eobj, const float* __restrict__ escore,
+                                              float* __restrict__ out, int64_t pairs, int N, int Km, int Ke, int R4,
+                                              float cos_eps, float miei_eps, float scale) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= pairs) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = p / N;
+  float sim = 0.f, wsum = 0.f;
+  for (int i = 0; i < Km; ++i) {
+    const float* xr = mobj + (b * Km + i) * (int64_t)R4 * 4;
+    const float ms = mscore[b * Km + i];
+    for (int j = 0; j < Ke; ++j) {
+      const float* yr = eobj + (p * Ke + j) * (int64_t)R4 * 4;
+      float xy = 0.f, xx = 0.f, yy = 0.f;
+      for (int c4 = lane; c4 < R4; c4 += 64) {
+        const float4 a = ld4(xr + c4 * 4), v = ld4(yr + c4 * 4);
+        xy += dot4(a, v);
+        xx += dot4(a, a);
+        yy += dot4(v, v);
+      }
+      xy = wave_sum(xy);
+      xx = wave_sum(xx);
+      yy = wave_sum(yy);
+      const float w = ms * escore[p * Ke + j];
+      sim += cosine_from_sums(xy, xx, yy, cos_eps) * w;
+      wsum += w;
+    }
+  }
+  if (lane == 0) out[p] = scale * (sim / (wsum + miei_eps));
+}
+
+int launch_miei(const float* mobj, const float* mscore, const float* eobj, const float* escore, float* out, int B,
+                int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st) {
+  const int64_t pairs = (int64_t)B * N;
+  if (pairs <= 0) return DRIN_OK;
+  if (R % 4 != 0) {
+    set_error("miei: R=%d must be a multiple of 4", R);
+    return DRIN_E_SHAPE;
+  }
+  KernelTimer timer(DRIN_KC_EDGE, st);
+  hipLaunchKernelGGL(k_miei, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, mobj, mscore, eobj, escore, out, pairs,
+                     N, Km, Ke, R / 4, cos_eps, miei_eps, scale);
+  DRIN_CHECK_LAUNCH("k_miei");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[i] = in[i] * mul / div   (model.py:203 divides the CLIP logits by 100: a true division, since
+// x / 100 and x * 0.01f round differently; model.py:122 multiplies by the 0/1 edge switch)
+__global__ void __launch_bounds__(256) k_scale_div(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                   float mul, float div) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (in[i] * mul) / div;
+}
+
+int launch_scale_div(const float* in, float* out, int64_t n, float mul, float div, hipStream_t st) {
+  if (n <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_EDGE, st);
+  hipLaunchKernelGGL(k_scale_div, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, in, out, n, mul, div);
+  DRIN_CHECK_LAUNCH("k_scale_div");
+  return DRIN_OK;
+}
+
+}  // namespace drin

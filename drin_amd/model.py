@@ -1,0 +1,256 @@
+"""Drop-in `Model` for the reference's `drin/model.py:156-209`, running on hand-written HIP kernels.
+
+Same constructor side effects (parameter creation order, hence same-seed initial weights,
+`train.py:134-136`), same `state_dict` keys, same `forward(batch)` signature
+(the 14-sequence of `drin/data.py:110-126` already on the device, `train.py:33`) and the same
+`[B, N]` fp32 result.  The arithmetic itself happens in `libdrin_hip.so` behind the C ABI of
+`include/drin_hip.h`; PyTorch only owns memory, the stream and the autograd graph edge.
+
+There is no eager/PyTorch fallback: if the library is missing or the tensors are not on an
+AMD GPU, `forward` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib
+from .config import DrinConfig
+
+
+# ---- parameter containers mirroring the reference's module tree (keys of SURVEY.md §8b) -------------
+class _AvgLinear(nn.Module):  # baselines/ghmfc.py:63-69
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.linear = nn.Linear(in_dim, out_dim)
+
+
+class _MentionEncoder(nn.Module):  # baselines/ghmfc.py:152-165 (linear / offline branch)
+    def __init__(self, dim: int):
+        super().__init__()
+        self.final_layer = _AvgLinear(dim, dim)
+
+
+class _EntityEncoder(nn.Module):  # baselines/ghmfc.py:202-214 (linear / offline branch)
+    def __init__(self, dim: int):
+        super().__init__()
+        self.final_layer = nn.Linear(dim, dim)
+
+
+class VertexEncoder(nn.Module):  # drin/model.py:13-24
+    def __init__(self, cfg: DrinConfig):
+        super().__init__()
+        self.mention_text_encoder = _MentionEncoder(cfg.bert_embed_dim)
+        self.entity_text_encoder = _EntityEncoder(cfg.bert_embed_dim)
+        self.mention_image_linear = nn.Linear(cfg.resnet_embed_dim, cfg.gcn_embed_dim)
+        self.entity_image_linear = nn.Linear(cfg.resnet_embed_dim, cfg.gcn_embed_dim)
+
+
+class GCNLayer(nn.Module):  # drin/model.py:109-119 (scaler edges: w_m is Identity and owns nothing)
+    def __init__(self, cfg: DrinConfig):
+        super().__init__()
+        d = cfg.gcn_embed_dim
+        self.w_h = nn.Linear(d, d)
+        self.w_u, self.w_v = [nn.Linear(d, d) for _ in range(2)]
+        self.layer_norm = nn.LayerNorm(d)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _param_list(model: "Model") -> List[torch.Tensor]:
+    ve = model.vertex_encoder
+    ps = [
+        ve.mention_text_encoder.final_layer.linear.weight, ve.mention_text_encoder.final_layer.linear.bias,
+        ve.entity_text_encoder.final_layer.weight, ve.entity_text_encoder.final_layer.bias,
+        ve.mention_image_linear.weight, ve.mention_image_linear.bias,
+        ve.entity_image_linear.weight, ve.entity_image_linear.bias,
+    ]
+    for layer in model.gcn_layers:
+        ps += [layer.w_h.weight, layer.w_h.bias, layer.w_u.weight, layer.w_u.bias, layer.w_v.weight, layer.w_v.bias,
+               layer.layer_norm.weight, layer.layer_norm.bias]
+    return ps
+
+
+def _fill_params(struct, tensors: Sequence[Optional[torch.Tensor]]) -> None:
+    names = ("w_mention_text", "b_mention_text", "w_entity_text", "b_entity_text",
+             "w_mention_image", "b_mention_image", "w_entity_image", "b_entity_image")
+    for n, t in zip(names, tensors[:8]):
+        setattr(struct, n, _ptr(t))
+    lnames = ("w_h", "b_h", "w_u", "b_u", "w_v", "b_v", "ln_weight", "ln_bias")
+    for l in range((len(tensors) - 8) // 8):
+        for j, n in enumerate(lnames):
+            setattr(struct.layer[l], n, _ptr(tensors[8 + 8 * l + j]))
+
+
+class _Call:
+    """One forward's C structs; keeps the tensors they point into alive."""
+
+    def __init__(self, cfg: DrinConfig, batch: Sequence[torch.Tensor], precision: int):
+        if len(batch) not in (14, 15):
+            raise ValueError(f"batch must be the 14-sequence of drin/data.py:110-126 (got {len(batch)} items)")
+        (mtf, _mask, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei) = batch[:14]
+        dev = mtf.device
+        if dev.type != "cuda":
+            raise RuntimeError("drin_amd.Model runs on an AMD GPU only (no CPU / eager fallback); move the batch to 'cuda'")
+
+        def f32(t):
+            if t.device != dev:
+                raise RuntimeError("all batch tensors must be on the same device")
+            return t.to(torch.float32).contiguous()
+
+        def i64(t):
+            return t.to(device=dev, dtype=torch.int64).contiguous()
+
+        mtf, mimg, mobj, mscore, etf, eimg, eobj, escore, miet, mtei = map(
+            f32, (mtf, mimg, mobj, mscore, etf, eimg, eobj, escore, miet, mtei))
+        start, end = i64(start), i64(end)
+        B, L, D = mtf.shape
+        N = cfg.num_candidates_model
+        R = mimg.shape[-1]
+        token_level = etf.dim() == 4                                  # model.py:73-75
+        if D != cfg.bert_embed_dim or R != cfg.resnet_embed_dim:
+            raise ValueError(f"feature dims ({D}, {R}) do not match the config ({cfg.bert_embed_dim}, {cfg.resnet_embed_dim})")
+        if etf.shape[:2] != (B, N):
+            raise ValueError(f"entity_text_feature leads with {tuple(etf.shape[:2])}, expected {(B, N)}")
+        if mobj.dim() not in (3, 4) or eobj.dim() not in (4, 5) or eimg.dim() not in (3, 4):
+            raise ValueError("unexpected rank for object / image features (model.py:43-44,78-83)")
+        Km = mobj.shape[1]
+        Ke = eobj.shape[2]
+        for name, t, shape in (
+            ("mention_image_feature", mimg, (B, mimg.shape[1], R)),
+            ("mention_object_score", mscore, (B, Km)),
+            ("entity_object_score", escore, (B, N, Ke)),
+            ("miet_similarity", miet, (B, N)),
+            ("mtei_similarity", mtei, (B, N)),
+            ("mention_start_pos", start, (B,)),
+            ("mention_end_pos", end, (B,)),
+        ):
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shape}")
+        if eimg.shape[0:2] != (B, N) or eobj.shape[0:2] != (B, N) or eimg.shape[-1] != R or eobj.shape[-1] != R or mobj.shape[-1] != R:
+            raise ValueError("entity/mention image or object feature shape mismatch")
+        if token_level:
+            emask = i64(emask)
+            if tuple(emask.shape) != tuple(etf.shape[:3]):
+                raise ValueError(f"entity_text_mask has shape {tuple(emask.shape)}, expected {tuple(etf.shape[:3])}")
+        else:
+            emask = None
+        self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei]
+        self.device = dev
+        self.B, self.N, self.D = B, N, D
+        c = _lib.DrinConfigC()
+        _lib.check(_lib.load().drin_default_config(C.byref(c)))
+        c.batch, c.num_candidates, c.embed_dim, c.image_dim = B, N, D, R
+        c.mention_tokens, c.image_regions = L, mimg.shape[1]
+        c.mention_objects, c.entity_objects = Km, Ke
+        c.entity_tokens = etf.shape[2] if token_level else 0
+        c.mention_object_inner = mobj.shape[2] if mobj.dim() == 4 else 0
+        c.entity_image_inner = eimg.shape[2] if eimg.dim() == 4 else 0
+        c.entity_object_inner = eobj.shape[3] if eobj.dim() == 5 else 0
+        c.num_layers = cfg.num_gcn_layers
+        c.dynamic_edges = 1 if cfg.gcn_edge_type == "dynamic" else 0
+        for k in range(4):
+            c.edge_enabled[k] = float(cfg.gcn_edge_enabled[k])
+        c.layer_norm_eps, c.cosine_eps, c.miei_eps, c.clip_scale = (
+            cfg.layer_norm_eps, cfg.cosine_eps, cfg.miei_eps, cfg.clip_logit_scale)
+        c.precision = precision
+        self.cfg = c
+        b = _lib.DrinBatchC()
+        for name, t in zip(("mention_text", "mention_start", "mention_end", "mention_image", "mention_object",
+                            "mention_object_score", "entity_text", "entity_text_mask", "entity_image",
+                            "entity_object", "entity_object_score", "miet_similarity", "mtei_similarity"), self.keep):
+            setattr(b, name, _ptr(t))
+        self.batch = b
+
+    def workspace(self, training: bool) -> torch.Tensor:
+        n = _lib.load().drin_workspace_bytes(C.byref(self.cfg), 1 if training else 0)
+        if n == 0 and self.B > 0:
+            raise _lib.DrinError(_lib.E_SHAPE, _lib.load().drin_last_error().decode())
+        return torch.empty(max(n, 16), dtype=torch.uint8, device=self.device)
+
+
+class _DrinScore(torch.autograd.Function):
+    """Autograd edge around drin_forward / drin_backward (loss.backward() of train.py:33-34)."""
+
+    @staticmethod
+    def forward(ctx, call: _Call, *params: torch.Tensor):
+        lib = _lib.load()
+        # grad mode is already off inside Function.forward; needs_input_grad carries the caller's mode
+        training = any(ctx.needs_input_grad[1:])
+        params = tuple(p.detach().contiguous() for p in params)
+        pc = _lib.DrinParamsC()
+        _fill_params(pc, params)
+        ws = call.workspace(training)
+        scores = torch.empty(call.B, call.N, dtype=torch.float32, device=call.device)
+        stream = torch.cuda.current_stream(call.device).cuda_stream
+        _lib.check(lib.drin_forward(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), ws.data_ptr(), ws.numel(),
+                                    scores.data_ptr(), 1 if training else 0, None, stream))
+        ctx.call, ctx.ws, ctx.pc, ctx.params = call, ws, pc, params
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores: torch.Tensor):
+        lib = _lib.load()
+        call, params = ctx.call, ctx.params
+        grads = [torch.zeros_like(p) for p in params]
+        gc = _lib.DrinParamGradsC()
+        _fill_params(gc, grads)
+        g = grad_scores.to(torch.float32).contiguous()
+        stream = torch.cuda.current_stream(call.device).cuda_stream
+        _lib.check(lib.drin_backward(C.byref(call.cfg), C.byref(call.batch), C.byref(ctx.pc), ctx.ws.data_ptr(),
+                                     ctx.ws.numel(), g.data_ptr(), C.byref(gc), stream))
+        nl = (len(params) - 8) // 8
+        out = list(grads)
+        if nl > 0 and call.cfg.dynamic_edges:
+            # the last layer's edge update never reaches the score: the reference leaves .grad = None
+            base = 8 + 8 * (nl - 1)
+            for j in (2, 3, 4, 5):
+                out[base + j] = None
+        return (None, *out)
+
+
+class Model(nn.Module):
+    """`model_module.Model()` of `train.py:136` (drin/model.py:156-162)."""
+
+    def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "f32"):
+        super().__init__()
+        self.cfg = cfg or DrinConfig()
+        self.cfg.validate()
+        self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[precision]
+        self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
+        self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
+
+    def forward(self, batch: Sequence[torch.Tensor]) -> torch.Tensor:
+        call = _Call(self.cfg, batch, self.precision)
+        return _DrinScore.apply(call, *_param_list(self))
+
+    @torch.no_grad()
+    def forward_traced(self, batch: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Scores plus every stage's vertices and edges (tests / debugging)."""
+        lib = _lib.load()
+        call = _Call(self.cfg, batch, self.precision)
+        params = tuple(p.detach().contiguous() for p in _param_list(self))
+        pc = _lib.DrinParamsC()
+        _fill_params(pc, params)
+        B, N, D, nl, dev = call.B, call.N, call.D, self.cfg.num_gcn_layers, call.device
+        tr = _lib.DrinTraceC()
+        out: Dict[str, torch.Tensor] = {}
+        for l in range(nl + 1):
+            for field, key, shape in (("mention_text_vertex", f"mt{l}", (B, D)), ("mention_image_vertex", f"mi{l}", (B, D)),
+                                      ("entity_text_vertex", f"et{l}", (B, N, D)), ("entity_image_vertex", f"ei{l}", (B, N, D)),
+                                      ("edges", f"edges{l}", (4, B, N))):
+                t = torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
+                out[key] = t
+                getattr(tr, field)[l] = t.data_ptr()
+        ws = call.workspace(False)
+        scores = torch.empty(B, N, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.drin_forward(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), ws.data_ptr(), ws.numel(),
+                                    scores.data_ptr(), 0, C.byref(tr), stream))
+        out["scores"] = scores
+        return out

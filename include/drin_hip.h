@@ -1,0 +1,198 @@
+/*
+ * drin_hip.h - C ABI of libdrin_hip.so: the MI355X (gfx950) DRIN scoring path.
+ *
+ * The reference (starreeze/drin, /root/reference) has no FFI: its boundary for this path is the
+ * Python nn.Module `drin/model.py:156-209` (`Model()` / `Model.forward(batch)`), called from
+ * `train.py:27-33`.  This library sits directly underneath a drop-in replacement of that Module
+ * (`drin_amd/model.py`) and is what a maintainer of the reference would bind with ctypes
+ * (INTEGRATION.md).  Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions across the boundary.
+ *   - every function returns DRIN_OK (0) or a negative drin_status; drin_last_error() gives a
+ *     thread-local message for the last failure on the calling thread.
+ *   - all data pointers are DEVICE pointers unless a parameter says "host".  The caller owns every
+ *     buffer, including the workspace (size from drin_workspace_bytes); the library allocates
+ *     nothing and keeps no mutable global state, so calls are re-entrant.
+ *   - every kernel is launched on the caller's `stream` (a hipStream_t passed as void*); the
+ *     library never synchronises.
+ *   - tensors are dense row-major fp32 (`float`), index/mask tensors int64 exactly as
+ *     `drin/data.py:110-126` collates them.
+ */
+#ifndef DRIN_HIP_H_
+#define DRIN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRIN_ABI_VERSION 1
+#define DRIN_API __attribute__((visibility("default")))
+
+typedef enum {
+  DRIN_OK = 0,
+  DRIN_E_SHAPE = -1,     /* a dimension is out of the supported range / inconsistent            */
+  DRIN_E_NULL = -2,      /* a required pointer is NULL                                           */
+  DRIN_E_ALIGN = -3,     /* a pointer or leading dimension misses the 16-byte alignment contract */
+  DRIN_E_WORKSPACE = -4, /* workspace smaller than drin_workspace_bytes()                        */
+  DRIN_E_HIP = -5,       /* a HIP runtime call failed (launch error, bad stream, ...)            */
+  DRIN_E_UNSUPPORTED = -6 /* configuration not built (e.g. vector edge features)                */
+} drin_status;
+
+/* Arithmetic of the contractions.  All other arithmetic is fp32. */
+typedef enum {
+  DRIN_PREC_F32 = 0,    /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): k-ordered fmaf chain        */
+  DRIN_PREC_BF16X3 = 1, /* operands split hi+lo bf16, 3 bf16 MFMAs, fp32 accumulate (~fp32)      */
+  DRIN_PREC_BF16 = 2    /* operands rounded to bf16, fp32 accumulate (inference config 2)        */
+} drin_precision;
+
+/* Geometry + switches of one forward.  Names follow common/args.py. */
+typedef struct {
+  int32_t batch;            /* B mentions in this call                                            */
+  int32_t num_candidates;   /* N = num_candidates_model (args.py:101), answer slot included       */
+  int32_t embed_dim;        /* D = bert_embed_dim = gcn_embed_dim (args.py:25,45)                 */
+  int32_t image_dim;        /* R = resnet_embed_dim (args.py:52)                                  */
+  int32_t mention_tokens;   /* L = tokens per mention sentence (args.py:72)                       */
+  int32_t image_regions;    /* P = resnet_num_region (args.py:53)                                 */
+  int32_t mention_objects;  /* Km (args.py:57)                                                    */
+  int32_t entity_objects;   /* Ke (args.py:57)                                                    */
+  int32_t entity_tokens;    /* T > 0: WikiMEL token-level entity text [B,N,T,D] + mask [B,N,T];
+                               0: WikiDiverse pooled entity text [B,N,D] (ghmfc.py:239-249)       */
+  int32_t mention_object_inner; /* size of the dim averaged at model.py:78-79 (1 in both datasets)*/
+  int32_t entity_image_inner;   /* size of the dim averaged at model.py:43-44 (0 = tensor is 3-D) */
+  int32_t entity_object_inner;  /* size of the dim averaged at model.py:82-83 (0 = tensor is 4-D) */
+  int32_t num_layers;       /* num_gcn_layers (args.py:26)                                        */
+  int32_t dynamic_edges;    /* gcn_edge_type == "dynamic" (args.py:32)                            */
+  float edge_enabled[4];    /* gcn_edge_enabled for (tt, ti, it, ii) (args.py:34, model.py:122)   */
+  float layer_norm_eps;     /* 1e-5  (nn.LayerNorm default, model.py:119)                         */
+  float cosine_eps;         /* 1e-8  (nn.CosineSimilarity default, model.py:57,162)               */
+  float miei_eps;           /* 1e-9  (model.py:92)                                                */
+  float clip_scale;         /* 100   (model.py:203)                                               */
+  int32_t precision;        /* drin_precision                                                     */
+  int32_t reserved[3];
+} drin_config;
+
+/* The 14 tensors `Model.forward` unpacks (drin/model.py:165-180), device pointers.
+ * mention_text_mask is carried by the reference but never read by the DRIN compute, so it is absent. */
+typedef struct {
+  const float* mention_text;          /* [B, L, D]                                               */
+  const int64_t* mention_start;       /* [B]   already +1 for CLS (data.py:113)                  */
+  const int64_t* mention_end;         /* [B]                                                     */
+  const float* mention_image;         /* [B, P, R]                                               */
+  const float* mention_object;        /* [B, Km, inner, R]                                       */
+  const float* mention_object_score;  /* [B, Km]                                                 */
+  const float* entity_text;           /* T>0: [B, N, T, D]   T==0: [B, N, D]                     */
+  const int64_t* entity_text_mask;    /* T>0: [B, N, T]      T==0: ignored (may be NULL)         */
+  const float* entity_image;          /* [B, N, (inner,) R]                                      */
+  const float* entity_object;         /* [B, N, Ke, (inner,) R]                                  */
+  const float* entity_object_score;   /* [B, N, Ke]                                              */
+  const float* miet_similarity;       /* [B, N]  CLIP logits (model.py:178,203)                  */
+  const float* mtei_similarity;       /* [B, N]                                                  */
+} drin_batch;
+
+/* One GCNLayer's parameters (drin/model.py:109-119); nn.Linear layout weight[out][in]. */
+typedef struct {
+  const float *w_h, *b_h, *w_u, *b_u, *w_v, *b_v, *ln_weight, *ln_bias;
+} drin_layer_params;
+
+#define DRIN_MAX_LAYERS 8
+
+/* The 24 state_dict tensors. */
+typedef struct {
+  const float *w_mention_text, *b_mention_text;   /* vertex_encoder.mention_text_encoder.final_layer.linear */
+  const float *w_entity_text, *b_entity_text;     /* vertex_encoder.entity_text_encoder.final_layer         */
+  const float *w_mention_image, *b_mention_image; /* vertex_encoder.mention_image_linear  [D, R]            */
+  const float *w_entity_image, *b_entity_image;   /* vertex_encoder.entity_image_linear   [D, R]            */
+  drin_layer_params layer[DRIN_MAX_LAYERS];
+} drin_params;
+
+/* Gradients w.r.t. the same tensors; every non-NULL pointer is ACCUMULATED into (+=), so the caller
+ * zeroes them (torch .grad semantics).  Parameters the output does not depend on (last layer's
+ * w_u / w_v, model.py:130-134) are left untouched. */
+typedef struct {
+  float *w_mention_text, *b_mention_text, *w_entity_text, *b_entity_text;
+  float *w_mention_image, *b_mention_image, *w_entity_image, *b_entity_image;
+  struct { float *w_h, *b_h, *w_u, *b_u, *w_v, *b_v, *ln_weight, *ln_bias; } layer[DRIN_MAX_LAYERS];
+} drin_param_grads;
+
+/* Optional taps of intermediate values for tests/debugging (any pointer may be NULL).
+ * Index l = 0 is the VertexEncoder/EdgeEncoder output, l >= 1 the output of GCN layer l. */
+typedef struct {
+  float* mention_text_vertex[DRIN_MAX_LAYERS + 1];  /* [B, D]    */
+  float* mention_image_vertex[DRIN_MAX_LAYERS + 1]; /* [B, D]    */
+  float* entity_text_vertex[DRIN_MAX_LAYERS + 1];   /* [B, N, D] */
+  float* entity_image_vertex[DRIN_MAX_LAYERS + 1];  /* [B, N, D] */
+  float* edges[DRIN_MAX_LAYERS + 1];                /* [4, B, N] order tt, ti, it, ii */
+} drin_trace;
+
+/* ---- housekeeping ------------------------------------------------------------------------- */
+DRIN_API int drin_version(void);                 /* DRIN_ABI_VERSION the library was built with           */
+DRIN_API const char* drin_last_error(void);      /* thread-local, never NULL                              */
+DRIN_API const char* drin_build_info(void);      /* "gfx950 <compiler> <date>"                            */
+
+/* Fills `cfg` with the reference defaults (eps values, scale, all edges enabled, 2 dynamic layers,
+ * WikiDiverse geometry).  Replaces the import-time globals of common/args.py. */
+DRIN_API int drin_default_config(drin_config* cfg);
+
+/* Bytes of device workspace drin_forward / drin_backward need for `cfg` (0 on error). */
+DRIN_API size_t drin_workspace_bytes(const drin_config* cfg, int for_training);
+
+/* ---- the path ----------------------------------------------------------------------------- */
+
+/* Parameter-free edge builder: EdgeEncoder.forward (drin/model.py:60-94) + edge assembly
+ * (model.py:201-204).  Writes edges[4][B][N] in order (tt, ti, it, ii) and, if non-NULL, the
+ * span mean of the mention text [B, D] (ghmfc.py:54-60), which the vertex encoder reuses. */
+DRIN_API int drin_edges_fwd(const drin_config* cfg, const drin_batch* batch, float* edges, float* span_mean,
+                   void* stream);
+
+/* Input pooling of VertexEncoder.forward: entity token mean (ghmfc.py:245-249, only T>0),
+ * mention region mean (model.py:41), entity image inner mean (model.py:43-44).  Any output may be
+ * NULL to skip it.  pooled_entity_text [B,N,D], pooled_mention_image [B,R], pooled_entity_image [B,N,R]. */
+DRIN_API int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled_entity_text,
+                  float* pooled_mention_image, float* pooled_entity_image, void* stream);
+
+/* y[m, n] = sum_k x[m, k] * w[n, k] + bias[n]   (nn.Linear, weight [n_out][k]); bias may be NULL.
+ * The building block behind every Linear of the path (ghmfc.py:69,250; model.py:42,45,128,150-153). */
+DRIN_API int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t rows,
+                    int32_t n_out, int32_t k, int32_t precision, void* stream);
+
+/* Model.forward (drin/model.py:164-209): scores[B, N] = cos(mt'', et'').
+ * `keep_for_backward` != 0 lays the intermediates backward needs out in `workspace`, which must
+ * then stay untouched until drin_backward returns.  `trace` may be NULL. */
+DRIN_API int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
+                 void* workspace, size_t workspace_bytes, float* scores, int keep_for_backward,
+                 const drin_trace* trace, void* stream);
+
+/* Backward of drin_forward: given grad_scores[B, N], accumulates parameter gradients into `grads`
+ * (loss.backward() of train.py:33-34 through model.py:164-209).  Inputs carry no gradient in the
+ * reference (precomputed features), so none is produced. */
+DRIN_API int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
+                  void* workspace, size_t workspace_bytes, const float* grad_scores,
+                  const drin_param_grads* grads, void* stream);
+
+/* ---- in-process kernel timing (bench.py's roofline leg) ---------------------------------------- */
+
+/* Kernel classes the launches are attributed to. */
+typedef enum {
+  DRIN_KC_GEMM = 0,   /* MFMA contractions (gemm_f32.hip and the fused row kernels)               */
+  DRIN_KC_POOL = 1,   /* input pooling: span / region / token means                               */
+  DRIN_KC_EDGE = 2,   /* static edge builders: cosine rows, miei, scaling                          */
+  DRIN_KC_GCN = 3,    /* aggregation, LayerNorm+GELU, edge update, their backward                  */
+  DRIN_KC_COUNT = 4
+} drin_kernel_class;
+
+/* While a profile is open on the calling thread, every launch made from that thread is bracketed by
+ * hipEvents on its stream.  drin_profile_end synchronises those events, returns per-class GPU
+ * milliseconds and launch counts (arrays of DRIN_KC_COUNT) and closes the profile.  State is
+ * thread-local; launches from other threads are not affected. */
+DRIN_API int drin_profile_begin(int max_launches);
+DRIN_API int drin_profile_end(double* ms_by_class, int64_t* launches_by_class);
+DRIN_API const char* drin_kernel_class_name(int kernel_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRIN_HIP_H_ */

@@ -1,0 +1,74 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports exactly what
+include/drin_hip.h declares, and its host-only entry points behave."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from drin_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "drin_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"DRIN_API\s+[\w\s\*]+?\b(drin_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/drin_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "python binding and header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "__device_stub__" not in l)
+    assert exported == declared, "library exports symbols the header does not declare"
+
+
+def test_version_and_defaults():
+    lib = _lib.load()
+    assert lib.drin_version() == _lib.ABI_VERSION
+    assert b"gfx950" in lib.drin_build_info()
+    c = _lib.DrinConfigC()
+    assert lib.drin_default_config(C.byref(c)) == _lib.OK
+    assert (c.num_candidates, c.embed_dim, c.image_dim, c.num_layers, c.dynamic_edges) == (11, 768, 2048, 2, 1)
+    assert list(c.edge_enabled) == [1.0] * 4
+    assert abs(c.layer_norm_eps - 1e-5) < 1e-12 and abs(c.cosine_eps - 1e-8) < 1e-15 and c.clip_scale == 100.0
+    assert lib.drin_default_config(None) == _lib.E_NULL
+
+
+def test_workspace_query_and_validation():
+    lib = _lib.load()
+    c = _lib.DrinConfigC()
+    lib.drin_default_config(C.byref(c))
+    c.batch = 64
+    inf, trn = lib.drin_workspace_bytes(C.byref(c), 0), lib.drin_workspace_bytes(C.byref(c), 1)
+    assert 0 < inf < trn
+    c.batch = 128
+    assert lib.drin_workspace_bytes(C.byref(c), 0) > inf
+    c.embed_dim = 770
+    assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
+    assert b"multiples of 4" in lib.drin_last_error()
+    c.embed_dim = 768
+    c.precision = 7
+    assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
+    c.precision = 0
+    c.num_layers = 9
+    assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
+
+
+def test_null_arguments_are_reported_not_crashed():
+    lib = _lib.load()
+    c = _lib.DrinConfigC()
+    lib.drin_default_config(C.byref(c))
+    c.batch = 1
+    b = _lib.DrinBatchC()
+    assert lib.drin_edges_fwd(C.byref(c), C.byref(b), None, None, None) == _lib.E_NULL
+    assert b"NULL" in lib.drin_last_error()
+    assert lib.drin_forward(C.byref(c), C.byref(b), None, None, 0, None, 0, None, None) == _lib.E_NULL
+    assert lib.drin_profile_end(None, None) == _lib.E_SHAPE

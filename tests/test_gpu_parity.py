@@ -1,0 +1,227 @@
+"""-m gpu: the HIP path (through the C ABI of libdrin_hip.so) against the CPU oracle and the golden
+vectors of the reference.  Tolerance of the path per BASELINE.json north_star: 1e-4 fp32 on scores."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from drin_amd import _lib, synth
+from drin_amd.config import DrinConfig, wikimel_config
+from drin_amd.model import Model
+from oracle import drin_oracle as O
+from oracle.cases import CASES, TINY, build_case
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-4   # north_star: "within 1e-4 fp32"
+DEV = "cuda"
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"{name}.npz"))
+
+
+def _model(cfg, sd):
+    m = Model(cfg).to(DEV)
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def _to_dev(batch):
+    return [t.to(DEV) for t in batch]
+
+
+# ---- building blocks through the C ABI ---------------------------------------------------------------
+@pytest.mark.parametrize("rows,n_out,k", [(1, 64, 64), (5, 64, 128), (44, 768, 768), (129, 768, 2048), (404, 768, 768),
+                                          (1000, 200, 96), (128, 128, 32), (257, 130, 40)])
+def test_linear_fwd(rows, n_out, k):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows * 7 + k)
+    x = torch.randn(rows, k, generator=g)
+    w = torch.randn(n_out, k, generator=g) / k ** 0.5
+    b = torch.randn(n_out, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = torch.full((rows, n_out), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.drin_linear_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, n_out, k, 0, st))
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    # exact-fp32 claim: a permuted fmaf chain is as accurate as torch's own fp32 matmul
+    err32 = (torch.nn.functional.linear(x, w, b).double() - ref).abs().max().item()
+    assert err <= 4 * err32 + 1e-6
+
+
+def test_linear_fwd_errors():
+    lib = _lib.load()
+    x = torch.zeros(4, 6, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.drin_linear_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 4, 4, 6, 0, st) == _lib.E_SHAPE   # K % 4
+    assert b"multiple of 4" in lib.drin_last_error()
+    assert lib.drin_linear_fwd(None, x.data_ptr(), None, x.data_ptr(), 4, 4, 8, 0, st) == _lib.E_NULL
+
+
+@pytest.mark.parametrize("name", ["tiny_wd", "tiny_wm", "wm_b2", "wd_b4"])
+def test_pool_and_edges(name):
+    """drin_pool_fwd / drin_edges_fwd == ghmfc.py:54-60,245-249 and model.py:60-94,201-204."""
+    lib = _lib.load()
+    cfg, sd, batch = build_case(name)
+    from drin_amd.model import _Call
+    call = _Call(cfg, _to_dev(batch), 0)
+    B, N, D, R = call.B, call.N, call.D, cfg.resnet_embed_dim
+    st = torch.cuda.current_stream().cuda_stream
+    edges = torch.full((4, B, N), float("nan"), device=DEV)
+    span = torch.full((B, D), float("nan"), device=DEV)
+    _lib.check(lib.drin_edges_fwd(C.byref(call.cfg), C.byref(call.batch), edges.data_ptr(), span.data_ptr(), st))
+    mtet, miei = O.edge_encoder(batch)
+    np.testing.assert_allclose(span.cpu().numpy(), O.span_mean(batch[0], batch[2], batch[3]).numpy(), atol=1e-6)
+    np.testing.assert_allclose(edges[0].cpu().numpy(), mtet.numpy(), atol=2e-6)
+    np.testing.assert_allclose(edges[1].cpu().numpy(), (batch[13] / 100).numpy(), atol=0)
+    np.testing.assert_allclose(edges[2].cpu().numpy(), (batch[12] / 100).numpy(), atol=0)
+    np.testing.assert_allclose(edges[3].cpu().numpy(), miei.numpy(), atol=2e-6)
+    mimg = torch.full((B, R), float("nan"), device=DEV)
+    eimg = torch.full((B, N, R), float("nan"), device=DEV)
+    xet = torch.full((B, N, D), float("nan"), device=DEV) if cfg.token_level_entities else None
+    _lib.check(lib.drin_pool_fwd(C.byref(call.cfg), C.byref(call.batch), xet.data_ptr() if xet is not None else None,
+                                 mimg.data_ptr(), eimg.data_ptr(), st))
+    np.testing.assert_allclose(mimg.cpu().numpy(), batch[4].mean(-2).numpy(), atol=1e-6)
+    e = batch[9].mean(-2) if batch[9].dim() == 4 else batch[9]
+    np.testing.assert_allclose(eimg.cpu().numpy(), e.numpy(), atol=1e-6)
+    if xet is not None:
+        np.testing.assert_allclose(xet.cpu().numpy(), O.entity_token_mean(batch[7], batch[8]).numpy(), atol=1e-6)
+
+
+def test_entity_token_mean_slice_corner_cases():
+    """ntok in {0, 1, 2, 3, T}: python slice semantics of ghmfc.py:249, NaN for empty slices."""
+    lib = _lib.load()
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=4, max_entity_attr_token_len=6, **TINY)
+    batch = synth.make_batch(cfg, 2, 31)
+    ntoks = [[0, 1, 2, 3, 6], [6, 5, 4, 3, 2]]
+    for b in range(2):
+        for n in range(5):
+            batch[8][b, n] = 0
+            batch[8][b, n, : ntoks[b][n]] = 1
+    from drin_amd.model import _Call
+    call = _Call(cfg, _to_dev(batch), 0)
+    xet = torch.zeros(2, 5, 64, device=DEV)
+    _lib.check(lib.drin_pool_fwd(C.byref(call.cfg), C.byref(call.batch), xet.data_ptr(), None, None,
+                                 torch.cuda.current_stream().cuda_stream))
+    ref = O.entity_token_mean(batch[7], batch[8])
+    got = xet.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    np.testing.assert_allclose(torch.nan_to_num(got).numpy(), torch.nan_to_num(ref).numpy(), atol=1e-6)
+
+
+# ---- the whole path against the reference's golden vectors -----------------------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference_golden(golden_dir, name):
+    cfg, sd, batch = build_case(name)
+    g = _golden(golden_dir, name)
+    model = _model(cfg, sd)
+    out = {k: v.cpu() for k, v in model.forward_traced(_to_dev(batch)).items()}
+    err = np.abs(out["scores"].numpy() - g["scores"]).max()
+    print(f"{name}: max |score - reference| = {err:.3e}")
+    assert err <= SCORE_TOL
+    assert err <= 2e-5, "fp32 MFMA path should sit at fp32 rounding level, far inside the 1e-4 budget"
+    full = CASES[name][4]
+    nl = cfg.num_gcn_layers
+    np.testing.assert_allclose(out["edges0"][0].numpy(), g["mtet"], atol=2e-6)
+    np.testing.assert_allclose(out["edges0"][3].numpy(), g["miei"], atol=2e-6)
+    for l in range(nl + 1):
+        np.testing.assert_allclose(out[f"mt{l}"].numpy(), g[f"mt{l}"], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(out[f"mi{l}"].numpy(), g[f"mi{l}"], atol=2e-5, rtol=1e-4)
+        for nm in ("et", "ei"):
+            t = out[f"{nm}{l}"]
+            np.testing.assert_allclose((t if full else t[0]).numpy(), g[f"{nm}{l}"], atol=2e-5, rtol=1e-4)
+            assert abs(t.double().norm().item() - float(g[f"{nm}{l}_l2"])) <= 1e-5 * float(g[f"{nm}{l}_l2"])
+        if l > 0:
+            np.testing.assert_allclose(out[f"edges{l}"].numpy(), g[f"edges{l}"], atol=5e-6)
+    # the Module call (dead work of the last layer skipped) gives the same scores
+    with torch.no_grad():
+        s2 = model(_to_dev(batch)).cpu()
+    assert torch.equal(s2, out["scores"])
+
+
+def test_empty_span_nan_row(golden_dir):
+    cfg = DrinConfig(**TINY)
+    model = _model(cfg, synth.make_state_dict(cfg, 8))
+    batch = synth.make_batch(cfg, 3, 11)
+    batch[3][1] = batch[2][1]
+    with torch.no_grad():
+        s = model(_to_dev(batch)).cpu().numpy()
+    g = _golden(golden_dir, "tiny_wd_nan")["scores"]
+    assert np.isnan(s[1]).all()
+    np.testing.assert_allclose(s[[0, 2]], g[[0, 2]], atol=SCORE_TOL)
+
+
+def test_same_seed_init_matches_reference(golden_dir):
+    """train.py:134-136: seed -> Model() gives the reference's initial weights."""
+    g = _golden(golden_dir, "init_order")
+    torch.manual_seed(0)
+    m = Model(DrinConfig())
+    sd = m.state_dict()
+    assert [k for k in sd] == [k[len("l2/"):] for k in g.files if k.startswith("l2/")]
+    for k, v in sd.items():
+        np.testing.assert_array_equal(v.flatten()[:8].numpy(), g[f"head/{k}"])
+        assert abs(v.double().norm().item() - float(g[f"l2/{k}"])) < 1e-9
+
+
+@pytest.mark.parametrize("maker,B", [(DrinConfig, 64), (wikimel_config, 8)])
+def test_reference_batch_sizes_vs_oracle(maker, B):
+    """Reference-sized batches (args.py:118,126) against the oracle on the same seeded inputs."""
+    cfg = maker()
+    sd = synth.make_state_dict(cfg, 7)
+    batch = synth.make_batch(cfg, B, 41)
+    ref = O.forward(sd, batch)
+    with torch.no_grad():
+        got = _model(cfg, sd)(_to_dev(batch)).cpu()
+    err = (got - ref).abs().max().item()
+    print(f"{cfg.dataset_name} B={B}: max err {err:.3e}")
+    assert err <= SCORE_TOL
+    # top-1 agreement (the candidate columns, answer slot dropped as common/utils.py:61-62)
+    assert torch.equal(got[:, :-1].argmax(1), ref[:, :-1].argmax(1))
+
+
+def test_full_size_properties():
+    """BASELINE-sized WikiMEL batch drawn on the device: mention independence (a sub-batch scores
+    bit-identically), candidate-permutation equivariance, and slices against the oracle."""
+    cfg = wikimel_config()
+    sd = synth.make_state_dict(cfg, 7)
+    model = _model(cfg, sd)
+    B = 96
+    batch = synth.make_device_batch(cfg, B, 5, DEV)
+    with torch.no_grad():
+        full = model(batch)
+        sub = model([t[32:40] for t in batch])
+    assert torch.isfinite(full).all() and full.abs().max() <= 1 + 1e-5
+    assert torch.equal(full[32:40], sub), "mentions must not interact"
+    # permuting the candidates of every mention permutes its scores (the mean over n is symmetric)
+    perm = torch.randperm(cfg.num_candidates_model, device=DEV)
+    pb = list(batch)
+    for i in (7, 8, 9, 10, 11, 12, 13):
+        pb[i] = batch[i][:, perm].contiguous()
+    with torch.no_grad():
+        permuted = model(pb)
+    assert (permuted - full[:, perm]).abs().max().item() <= 2e-6
+    # three mentions against the oracle on the host
+    idx = [0, 47, 95]
+    host = [t[idx].cpu() for t in batch]
+    ref = O.forward(sd, host)
+    assert (full[idx].cpu() - ref).abs().max().item() <= SCORE_TOL
+
+
+def test_refuses_cpu_tensors():
+    cfg = DrinConfig(**TINY)
+    m = Model(cfg)
+    with pytest.raises(RuntimeError, match="AMD GPU only"):
+        m(synth.make_batch(cfg, 2, 1))
+
+
+def test_determinism():
+    cfg, sd, batch = build_case("wd_b4")
+    model = _model(cfg, sd)
+    with torch.no_grad():
+        a = model(_to_dev(batch))
+        b = model(_to_dev(batch))
+    assert torch.equal(a, b)

@@ -61,10 +61,22 @@ def algorithmic_bytes_per_pair(cfg, batch):
     return ent + men / N + 4
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use (affinity and cgroup quota, not the node's total)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("DRIN_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(cfg, sd, seconds=12.0):
     from oracle import drin_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     B = 8 if cfg.token_level_entities else 64
     batch = synth.make_batch(cfg, B, 3)

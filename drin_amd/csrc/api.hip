@@ -146,6 +146,19 @@ static int validate_params(const drin_config* c, const drin_params* p) {
   return DRIN_OK;
 }
 
+// Operand pointers of the vertex / edge encoders: pooled copies in the workspace where the reference
+// averages an axis, the caller's tensors where it does not.
+void resolve_pooled(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out) {
+  const int D = c->embed_dim;
+  out->span_mean = ws + L.span_mean;
+  out->mention_image = ws + L.mimg_pool;
+  out->mention_object = c->mention_object_inner > 1 ? ws + L.mobj_pool : b->mention_object;
+  out->entity_object = c->entity_object_inner > 1 ? ws + L.eobj_pool : b->entity_object;
+  out->entity_image = c->entity_image_inner > 1 ? ws + L.eimg_pool : b->entity_image;
+  out->entity_text = c->entity_tokens > 0 ? ws + L.xet_pool : b->entity_text;
+  out->entity_text_raw_stride = c->entity_tokens > 0 ? (int64_t)c->entity_tokens * D : D;
+}
+
 // Resolves the pooled / raw operand pointers of the vertex and edge encoders and runs the pooling.
 int run_pooling(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out, hipStream_t st) {
   const int B = c->batch, N = c->num_candidates, D = c->embed_dim, R = c->image_dim;
@@ -502,9 +515,149 @@ const char* drin_kernel_class_name(int kernel_class) {
 
 int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                   size_t workspace_bytes, const float* grad_scores, const drin_param_grads* grads, void* stream) {
-  (void)cfg; (void)batch; (void)params; (void)workspace; (void)workspace_bytes; (void)grad_scores; (void)grads; (void)stream;
-  set_error("drin_backward: not built yet");
-  return DRIN_E_UNSUPPORTED;
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(validate_batch(cfg, batch));
+  DRIN_TRY(validate_params(cfg, params));
+  if (!grad_scores || !grads) {
+    set_error("drin_backward: grad_scores / grads is NULL");
+    return DRIN_E_NULL;
+  }
+  Layout L;
+  L.build(*cfg, true);
+  if (!workspace || !aligned16(workspace)) {
+    set_error("workspace is NULL or not 16-byte aligned");
+    return workspace ? DRIN_E_ALIGN : DRIN_E_NULL;
+  }
+  if (workspace_bytes < L.total_floats * sizeof(float)) {
+    set_error("workspace has %zu bytes, needs %zu (was drin_forward run with keep_for_backward?)", workspace_bytes,
+              L.total_floats * sizeof(float));
+    return DRIN_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
+  const size_t M = (size_t)B * N, BD = (size_t)B * D, MD = M * D;
+  const int nl = cfg->num_layers;
+  const int prec = cfg->precision;
+  if (B == 0) return DRIN_OK;
+  Pooled P;
+  resolve_pooled(cfg, batch, L, ws, &P);
+
+  // carve the backward scratch (Layout::bwd_scratch): two generations of vertex / edge gradients,
+  // W_h-input gradients, edge-update gradients
+  float* sp = ws + L.bwd_scratch;
+  auto carve = [&sp](size_t n) {
+    float* p = sp;
+    sp += (n + 63) & ~(size_t)63;
+    return p;
+  };
+  float* g_vm[2] = {carve(2 * BD), carve(2 * BD)};
+  float* g_ve[2] = {carve(2 * MD), carve(2 * MD)};
+  float* g_e[2] = {carve(4 * M), carve(4 * M)};
+  float* dA_m = carve(2 * BD);
+  float* dA_e = carve(2 * MD);
+  float* dfu = carve(2 * BD);
+  float* dfv = carve(2 * MD);
+  float* dpre = carve(4 * M);
+  float* cos_scratch = carve(3 * M);
+  if ((size_t)(sp - (ws + L.bwd_scratch)) > L.bwd_scratch_floats) {
+    set_error("internal: backward scratch overflow");
+    return DRIN_E_WORKSPACE;
+  }
+
+  bool all_enabled = true;
+  for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
+
+  // score = cos(mt_L, et_L) (model.py:207-209)
+  int cur = 0;
+  DRIN_TRY(launch_cosine_bwd(ws + L.vm[nl], ws + L.ve[nl], grad_scores, g_vm[cur], g_ve[cur], cos_scratch, B, N, D,
+                             cfg->cosine_eps, st));
+  bool have_image = false;  // gradients w.r.t. the image vertices of the current level exist
+  bool have_edge = false;   // gradients w.r.t. the current level's edges exist
+
+  for (int l = nl - 1; l >= 0; --l) {
+    const drin_layer_params& W = params->layer[l];
+    const auto& G = grads->layer[l];
+    const int nxt = cur ^ 1;
+    const int types = have_image ? 2 : 1;
+    float* gm = g_vm[cur];  // dL/d(new mention vertices) -> dL/dH in place
+    float* ge = g_ve[cur];
+    const float* st_m = ws + L.ln_stat_m[l];
+    const float* st_e = ws + L.ln_stat_e[l];
+    // (a) LayerNorm + GELU backward; column sums give dgamma, dbeta and db_h
+    DRIN_TRY(launch_layernorm_gelu_bwd(ws + L.h_m[l], st_m, st_m + 2 * (size_t)B, W.ln_weight, W.ln_bias, gm,
+                                       G.ln_weight, G.ln_bias, G.b_h, (int64_t)types * B, D, st));
+    DRIN_TRY(launch_layernorm_gelu_bwd(ws + L.h_e[l], st_e, st_e + 2 * M, W.ln_weight, W.ln_bias, ge, G.ln_weight,
+                                       G.ln_bias, G.b_h, (int64_t)types * M, D, st));
+    // (b) dW_h += dH^T A
+    if (G.w_h) {
+      DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st));
+      DRIN_TRY(launch_gemm_tn(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D, prec, st));
+    }
+    // (c) dA = dH W_h
+    DRIN_TRY(launch_gemm_nn(gm, D, W.w_h, D, dA_m, D, (int64_t)types * B, D, D, false, prec, st));
+    DRIN_TRY(launch_gemm_nn(ge, D, W.w_h, D, dA_e, D, (int64_t)types * M, D, D, false, prec, st));
+    const float* dA_mt = dA_m;
+    const float* dA_mi = types == 2 ? dA_m + BD : nullptr;
+    const float* dA_et = dA_e;
+    const float* dA_ei = types == 2 ? dA_e + MD : nullptr;
+
+    const float* e = all_enabled ? ws + L.edges[l] : ws + L.masked[l];
+    const float* mt = ws + L.vm[l];
+    const float* mi = mt + BD;
+    const float* et = ws + L.ve[l];
+    const float* ei = et + MD;
+    const bool edge_update = cfg->dynamic_edges && have_edge;  // this layer's edge update is live
+    const float* de_extra = nullptr;
+    if (edge_update) {
+      // (d) e'_k = sigmoid(mean_d(fu fv) + e_k)  (model.py:148-153,133)
+      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)M, st));
+      const float* fu = ws + L.fu[l];
+      const float* fv = ws + L.fv[l];
+      const float inv_d = 1.0f / (float)D;
+      // dfv_t = (dpre_tt fu_t + dpre_it fu_i) / D ; dfv_i = (dpre_ti fu_t + dpre_ii fu_i) / D
+      DRIN_TRY(launch_entity_combine(dpre, fu, dpre + 2 * M, fu + BD, dfv, B, N, D, inv_d, st));
+      DRIN_TRY(launch_entity_combine(dpre + M, fu, dpre + 3 * M, fu + BD, dfv + MD, B, N, D, inv_d, st));
+      // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
+      DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
+      DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
+      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, prec, st));
+      DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, D, st));
+      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st));
+      DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, D, st));
+      de_extra = dpre;
+    } else if (!cfg->dynamic_edges && have_edge) {
+      de_extra = g_e[cur];  // static edges pass through (model.py:136)
+    }
+    // (e) entity side of the aggregation backward + edge gradients
+    DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
+                                    g_e[nxt], B, N, D, cfg->edge_enabled, st));
+    if (edge_update) DRIN_TRY(launch_gemm_nn(dfv, D, W.w_v, D, g_ve[nxt], D, 2 * (int64_t)M, D, D, true, prec, st));
+    // (f) mention side
+    DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
+    DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
+    if (edge_update) DRIN_TRY(launch_gemm_nn(dfu, D, W.w_u, D, g_vm[nxt], D, 2 * (int64_t)B, D, D, true, prec, st));
+    have_image = true;
+    have_edge = true;
+    cur = nxt;
+  }
+
+  // VertexEncoder (model.py:26-46): four Linears over the pooled inputs
+  const float* g_mt = g_vm[cur];
+  const float* g_mi = g_vm[cur] + BD;
+  const float* g_et = g_ve[cur];
+  const float* g_ei = g_ve[cur] + MD;
+  if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st));
+  DRIN_TRY(launch_colsum(g_mt, grads->b_mention_text, B, D, st));
+  if (grads->w_entity_text) DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st));
+  DRIN_TRY(launch_colsum(g_et, grads->b_entity_text, (int64_t)M, D, st));
+  if (have_image) {
+    if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st));
+    DRIN_TRY(launch_colsum(g_mi, grads->b_mention_image, B, D, st));
+    if (grads->w_entity_image) DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st));
+    DRIN_TRY(launch_colsum(g_ei, grads->b_entity_image, (int64_t)M, D, st));
+  }
+  return DRIN_OK;
 }
 
 }  // extern "C"

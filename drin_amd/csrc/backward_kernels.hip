@@ -1,0 +1,416 @@
+// Backward of the row kernels of the path (loss.backward() through drin/model.py:121-153,207-209).
+// Same style as the forward: one wave per row / pair, 16-byte lane accesses, shuffle reductions;
+// column sums that feed bias / LayerNorm gradients are accumulated per lane across a grid-stride
+// row loop, combined across the block's waves in LDS and added to the caller's gradient buffer
+// with one fp32 atomic per column per block.
+#include "device_utils.h"
+#include "internal.h"
+
+namespace drin {
+
+constexpr int MAXV = 4;  // float4 columns per lane: D <= 1024
+
+// ------------------------------------------------------------------------------------------------
+// score = cos(x[b], y[p]) (model.py:207-209), torch>=2 form: xn = x / max(|x|, eps), yn likewise.
+//   dy[p]   = g (xn - [|y|>eps] c yn) / ny
+//   coef[p] = g / ny,  gc[p] = g c,  xnorm[p] = |x[b]|          (consumed by the mention-side kernel)
+__global__ void __launch_bounds__(256) k_cosine_bwd_entity(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ g, float* __restrict__ dy,
+                                                           float* __restrict__ coef, float* __restrict__ gc,
+                                                           float* __restrict__ xnorm, int64_t pairs, int N, int D4,
+                                                           float eps) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= pairs) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (p / N) * (int64_t)D4 * 4;
+  const float* yr = y + p * (int64_t)D4 * 4;
+  float4 xv[MAXV], yv[MAXV];
+  float xy = 0.f, xx = 0.f, yy = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      xv[j] = ld4(xr + c4 * 4);
+      yv[j] = ld4(yr + c4 * 4);
+    } else {
+      xv[j] = yv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    xy += dot4(xv[j], yv[j]);
+    xx += dot4(xv[j], xv[j]);
+    yy += dot4(yv[j], yv[j]);
+  }
+  xy = wave_sum(xy);
+  xx = wave_sum(xx);
+  yy = wave_sum(yy);
+  const float nxr = sqrtf(xx), nyr = sqrtf(yy);
+  const float nx = fmaxf(nxr, eps), ny = fmaxf(nyr, eps);
+  const float c = xy / (nx * ny);
+  const float gg = g[p];
+  const float a = gg / (nx * ny);                         // multiplies x
+  const float bcoef = nyr > eps ? gg * c / (ny * ny) : 0.f;  // multiplies y
+  float* dr = dy + p * (int64_t)D4 * 4;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      float4 r;
+      r.x = a * xv[j].x - bcoef * yv[j].x;
+      r.y = a * xv[j].y - bcoef * yv[j].y;
+      r.z = a * xv[j].z - bcoef * yv[j].z;
+      r.w = a * xv[j].w - bcoef * yv[j].w;
+      st4(dr + c4 * 4, r);
+    }
+  }
+  if (lane == 0) {
+    coef[p] = gg / ny;
+    gc[p] = gg * c;
+    xnorm[p] = nxr;
+  }
+}
+
+//   dx[b] = (sum_n coef[p] y[p] - [|x|>eps] xn[b] sum_n gc[p]) / nx
+__global__ void __launch_bounds__(64) k_cosine_bwd_mention(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ gc,
+                                                           const float* __restrict__ xnorm, float* __restrict__ dx,
+                                                           int N, int D4, float eps) {
+  const int c4 = blockIdx.x * 64 + threadIdx.x;
+  if (c4 >= D4) return;
+  const int64_t b = blockIdx.y;
+  const float* yp = y + (b * N) * (int64_t)D4 * 4 + (int64_t)c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sg = 0.f;
+  for (int n = 0; n < N; ++n) {
+    s = fma4(coef[b * N + n], ld4(yp + (int64_t)n * D4 * 4), s);
+    sg += gc[b * N + n];
+  }
+  const float nxr = xnorm[b * N];
+  const float nx = fmaxf(nxr, eps);
+  const float4 xv = ld4(x + b * (int64_t)D4 * 4 + (int64_t)c4 * 4);
+  const float k = nxr > eps ? sg / (nx * nx) : 0.f;
+  float4 r;
+  r.x = s.x / nx - k * xv.x;
+  r.y = s.y / nx - k * xv.y;
+  r.z = s.z / nx - k * xv.z;
+  r.w = s.w / nx - k * xv.w;
+  st4(dx + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, r);
+}
+
+int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx, float* dy, float* scratch3,
+                      int B, int N, int D, float eps, hipStream_t st) {
+  const int64_t pairs = (int64_t)B * N;
+  if (pairs <= 0) return DRIN_OK;
+  float* coef = scratch3;
+  float* gcv = scratch3 + pairs;
+  float* xn = scratch3 + 2 * pairs;
+  {
+    KernelTimer timer(DRIN_KC_GCN, st);
+    hipLaunchKernelGGL(k_cosine_bwd_entity, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, x, y, g, dy, coef, gcv,
+                       xn, pairs, N, D / 4, eps);
+    DRIN_CHECK_LAUNCH("k_cosine_bwd_entity");
+  }
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    const int64_t po = (int64_t)b0 * N;
+    KernelTimer timer(DRIN_KC_GCN, st);
+    hipLaunchKernelGGL(k_cosine_bwd_mention, dim3((unsigned)cdiv(D / 4, 64), (unsigned)nb), dim3(64), 0, st,
+                       x + (int64_t)b0 * D, y + po * D, coef + po, gcv + po, xn + po, dx + (int64_t)b0 * D, N, D / 4,
+                       eps);
+    DRIN_CHECK_LAUNCH("k_cosine_bwd_mention");
+  }
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of y = gelu(LN(h)) (model.py:128), in place: on entry `g` holds dL/dy, on exit dL/dh.
+//   z = xhat gamma + beta, dz = g gelu'(z), dxhat = dz gamma,
+//   dh = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
+// and the three column sums  dgamma += sum_rows dz xhat,  dbeta += sum_rows dz,  dbias += sum_rows dh
+// (dbias is the W_h bias gradient: h = a W_h^T + b_h).
+__global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restrict__ h, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* g,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dbias, int64_t rows, int D4) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 gm[MAXV], bt[MAXV];
+  float4 a_dg[MAXV], a_db[MAXV], a_dh[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c4 = lane + 64 * j;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[j] = c4 < D4 ? ld4(gamma + c4 * 4) : z;
+    bt[j] = c4 < D4 ? ld4(beta + c4 * 4) : z;
+    a_dg[j] = a_db[j] = a_dh[j] = z;
+  }
+  const float inv_d = 1.0f / (float)(D4 * 4);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* hr = h + row * (int64_t)D4 * 4;
+    float* gr = g + row * (int64_t)D4 * 4;
+    float4 xh[MAXV], dxh[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c4 = lane + 64 * j;
+      if (c4 < D4) {
+        const float4 hv = ld4(hr + c4 * 4), gv = ld4(gr + c4 * 4);
+        xh[j] = make_float4((hv.x - mu) * rs, (hv.y - mu) * rs, (hv.z - mu) * rs, (hv.w - mu) * rs);
+        float4 dz;
+        dz.x = gv.x * gelu_erf_grad(xh[j].x * gm[j].x + bt[j].x);
+        dz.y = gv.y * gelu_erf_grad(xh[j].y * gm[j].y + bt[j].y);
+        dz.z = gv.z * gelu_erf_grad(xh[j].z * gm[j].z + bt[j].z);
+        dz.w = gv.w * gelu_erf_grad(xh[j].w * gm[j].w + bt[j].w);
+        a_dg[j] = make_float4(fmaf(dz.x, xh[j].x, a_dg[j].x), fmaf(dz.y, xh[j].y, a_dg[j].y),
+                              fmaf(dz.z, xh[j].z, a_dg[j].z), fmaf(dz.w, xh[j].w, a_dg[j].w));
+        a_db[j] = a_db[j] + dz;
+        dxh[j] = make_float4(dz.x * gm[j].x, dz.y * gm[j].y, dz.z * gm[j].z, dz.w * gm[j].w);
+        s1 += (dxh[j].x + dxh[j].y) + (dxh[j].z + dxh[j].w);
+        s2 += dot4(dxh[j], xh[j]);
+      } else {
+        xh[j] = dxh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c4 = lane + 64 * j;
+      if (c4 < D4) {
+        float4 dh;
+        dh.x = rs * (dxh[j].x - s1 - xh[j].x * s2);
+        dh.y = rs * (dxh[j].y - s1 - xh[j].y * s2);
+        dh.z = rs * (dxh[j].z - s1 - xh[j].z * s2);
+        dh.w = rs * (dxh[j].w - s1 - xh[j].w * s2);
+        a_dh[j] = a_dh[j] + dh;
+        st4(gr + c4 * 4, dh);
+      }
+    }
+  }
+  // combine the four waves' column sums through LDS, then one atomic per column per block
+  // three passes (one quantity at a time) keep LDS at 4 waves * MAXV * 64 float4 = 16 KiB
+  __shared__ float4 comb[4][MAXV][64];
+  for (int q = 0; q < 3; ++q) {
+    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) comb[wave][j][lane] = q == 0 ? a_dg[j] : (q == 1 ? a_db[j] : a_dh[j]);
+    __syncthreads();
+    if (dst != nullptr && wave == 0) {
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < D4) {
+          const float4 t = (comb[0][j][lane] + comb[1][j][lane]) + (comb[2][j][lane] + comb[3][j][lane]);
+          atomicAdd(dst + c4 * 4 + 0, t.x);
+          atomicAdd(dst + c4 * 4 + 1, t.y);
+          atomicAdd(dst + c4 * 4 + 2, t.z);
+          atomicAdd(dst + c4 * 4 + 3, t.w);
+        }
+      }
+    }
+  }
+}
+
+int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, int64_t rows,
+                              int D, hipStream_t st) {
+  if (rows <= 0) return DRIN_OK;
+  if (D % 4 || D > 256 * MAXV) {
+    set_error("layernorm_gelu_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
+    return DRIN_E_SHAPE;
+  }
+  const int64_t blocks = cdiv(rows, 4) < 1024 ? cdiv(rows, 4) : 1024;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_layernorm_gelu_bwd, dim3((unsigned)blocks), dim3(256), 0, st, h, mean, rstd, gamma, beta, g,
+                     dgamma, dbeta, dbias, rows, D / 4);
+  DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[c] += sum_rows x[row, c]      (bias gradients of W_u / W_v / the vertex encoders)
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                int C4) {
+  __shared__ float4 comb[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c4 = blockIdx.x * 64 + lane;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < C4)
+    for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < rows; row += (int64_t)gridDim.y * 4)
+      acc = acc + ld4(x + row * (int64_t)C4 * 4 + (int64_t)c4 * 4);
+  comb[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c4 < C4) {
+    const float4 t = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
+    atomicAdd(out + c4 * 4 + 0, t.x);
+    atomicAdd(out + c4 * 4 + 1, t.y);
+    atomicAdd(out + c4 * 4 + 2, t.z);
+    atomicAdd(out + c4 * 4 + 3, t.w);
+  }
+}
+
+int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st) {
+  if (rows <= 0 || !out) return DRIN_OK;
+  if (C % 4) {
+    set_error("colsum: C=%d must be a multiple of 4", C);
+    return DRIN_E_SHAPE;
+  }
+  const int64_t by = cdiv(rows, 4 * 16) < 256 ? cdiv(rows, 4 * 16) : 256;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(C / 4, 64), (unsigned)(by < 1 ? 1 : by)), dim3(256), 0, st, x, out,
+                     rows, C / 4);
+  DRIN_CHECK_LAUNCH("k_colsum");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dpre[k][p] = g[k][p] * e'[k][p] * (1 - e'[k][p])     (sigmoid of model.py:133)
+__global__ void __launch_bounds__(256) k_sigmoid_bwd(const float* __restrict__ g, const float* __restrict__ e_new,
+                                                     float* __restrict__ dpre, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = e_new[i];
+    dpre[i] = g[i] * s * (1.0f - s);
+  }
+}
+
+int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st) {
+  if (n <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_sigmoid_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, g, e_new, dpre, n);
+  DRIN_CHECK_LAUNCH("k_sigmoid_bwd");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b, :] = scale * (sum_n w1[b,n] v1[b,n,:] + sum_n w2[b,n] v2[b,n,:]) + u[b, :]
+// (v2 / u may be NULL).  The transposes of the entity<-mention and edge-update products.
+__global__ void __launch_bounds__(64) k_mention_reduce(const float* __restrict__ w1, const float* __restrict__ v1,
+                                                       const float* __restrict__ w2, const float* __restrict__ v2,
+                                                       const float* __restrict__ u, float* __restrict__ out, int N,
+                                                       int D4, float scale) {
+  const int c4 = blockIdx.x * 64 + threadIdx.x;
+  if (c4 >= D4) return;
+  const int64_t b = blockIdx.y;
+  const int64_t off = (b * N) * (int64_t)D4 * 4 + (int64_t)c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < N; ++n) {
+    s = fma4(w1[b * N + n], ld4(v1 + off + (int64_t)n * D4 * 4), s);
+    if (v2 != nullptr) s = fma4(w2[b * N + n], ld4(v2 + off + (int64_t)n * D4 * 4), s);
+  }
+  s = s * scale;
+  if (u != nullptr) s = s + ld4(u + b * (int64_t)D4 * 4 + (int64_t)c4 * 4);
+  st4(out + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, s);
+}
+
+int launch_mention_reduce(const float* w1, const float* v1, const float* w2, const float* v2, const float* u,
+                          float* out, int B, int N, int D, float scale, hipStream_t st) {
+  if (B <= 0) return DRIN_OK;
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    const int64_t po = (int64_t)b0 * N, vo = po * D;
+    KernelTimer timer(DRIN_KC_GCN, st);
+    hipLaunchKernelGGL(k_mention_reduce, dim3((unsigned)cdiv(D / 4, 64), (unsigned)nb), dim3(64), 0, st, w1 + po,
+                       v1 + vo, w2 ? w2 + po : nullptr, v2 ? v2 + vo : nullptr, u ? u + (int64_t)b0 * D : nullptr,
+                       out + (int64_t)b0 * D, N, D / 4, scale);
+    DRIN_CHECK_LAUNCH("k_mention_reduce");
+  }
+  return DRIN_OK;
+}
+
+// out[p, :] = scale * (w1[p] m1[b, :] + w2[p] m2[b, :])        (m2 may be NULL)
+__global__ void __launch_bounds__(256) k_entity_combine(const float* __restrict__ w1, const float* __restrict__ m1,
+                                                        const float* __restrict__ w2, const float* __restrict__ m2,
+                                                        float* __restrict__ out, int64_t total4, int N, int D4,
+                                                        float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int64_t p = i / D4;
+  const int c4 = (int)(i - p * D4);
+  const int64_t b = p / N;
+  float4 s = ld4(m1 + b * (int64_t)D4 * 4 + c4 * 4) * w1[p];
+  if (m2 != nullptr) s = fma4(w2[p], ld4(m2 + b * (int64_t)D4 * 4 + c4 * 4), s);
+  st4(out + i * 4, s * scale);
+}
+
+int launch_entity_combine(const float* w1, const float* m1, const float* w2, const float* m2, float* out, int B, int N,
+                          int D, float scale, hipStream_t st) {
+  const int64_t total4 = (int64_t)B * N * (D / 4);
+  if (total4 <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_entity_combine, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st, w1, m1, w2, m2, out, total4,
+                     N, D / 4, scale);
+  DRIN_CHECK_LAUNCH("k_entity_combine");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Entity side of the aggregation backward (transposes of model.py:143-146), one wave per pair.
+// With A_mt/A_mi/A_et/A_ei the W_h inputs of the four vertex types and e = (tt, ti, it, ii):
+//   d_et[p] = dA_et[p] + (e_tt dA_mt[b] + e_it dA_mi[b]) / N
+//   d_ei[p] = dA_ei[p] + (e_ti dA_mt[b] + e_ii dA_mi[b]) / N
+//   de_tt = dA_mt.et / N + dA_et.mt     de_ti = dA_mt.ei / N + dA_ei.mt
+//   de_it = dA_mi.et / N + dA_et.mi     de_ii = dA_mi.ei / N + dA_ei.mi
+// de_k additionally receives `de_extra[k]` (the edge-update / static pass-through gradient) and is
+// multiplied by the edge switch m_k (model.py:122).  dA_mi / dA_ei are NULL in the last layer, whose
+// image vertices are dead.
+__global__ void __launch_bounds__(256)
+    k_entity_side_bwd(const float* __restrict__ dA_mt, const float* __restrict__ dA_mi, const float* __restrict__ dA_et,
+                      const float* __restrict__ dA_ei, const float* __restrict__ mt, const float* __restrict__ mi,
+                      const float* __restrict__ et, const float* __restrict__ ei, const float* __restrict__ e,
+                      const float* __restrict__ de_extra, float* __restrict__ d_et, float* __restrict__ d_ei,
+                      float* __restrict__ de, int64_t pairs, int N, int D4, float m0, float m1, float m2, float m3) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= pairs) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = p / N;
+  const float inv_n = 1.0f / (float)N;
+  const float e_tt = e[p], e_ti = e[pairs + p], e_it = e[2 * pairs + p], e_ii = e[3 * pairs + p];
+  float s_tt = 0.f, s_ti = 0.f, s_it = 0.f, s_ii = 0.f;
+  const int64_t mo = b * (int64_t)D4 * 4, po = p * (int64_t)D4 * 4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c4 = lane; c4 < D4; c4 += 64) {
+    const int o = c4 * 4;
+    const float4 gmt = ld4(dA_mt + mo + o);
+    const float4 gmi = dA_mi ? ld4(dA_mi + mo + o) : zero;
+    const float4 get = ld4(dA_et + po + o);
+    const float4 gei = dA_ei ? ld4(dA_ei + po + o) : zero;
+    const float4 vmt = ld4(mt + mo + o), vmi = ld4(mi + mo + o);
+    const float4 vet = ld4(et + po + o), vei = ld4(ei + po + o);
+    s_tt += dot4(gmt, vet) * inv_n + dot4(get, vmt);
+    s_ti += dot4(gmt, vei) * inv_n + dot4(gei, vmt);
+    s_it += dot4(gmi, vet) * inv_n + dot4(get, vmi);
+    s_ii += dot4(gmi, vei) * inv_n + dot4(gei, vmi);
+    st4(d_et + po + o, fma4(e_tt * inv_n, gmt, fma4(e_it * inv_n, gmi, get)));
+    st4(d_ei + po + o, fma4(e_ti * inv_n, gmt, fma4(e_ii * inv_n, gmi, gei)));
+  }
+  s_tt = wave_sum(s_tt);
+  s_ti = wave_sum(s_ti);
+  s_it = wave_sum(s_it);
+  s_ii = wave_sum(s_ii);
+  if (lane == 0) {
+    const float x0 = de_extra ? de_extra[p] : 0.f, x1 = de_extra ? de_extra[pairs + p] : 0.f;
+    const float x2 = de_extra ? de_extra[2 * pairs + p] : 0.f, x3 = de_extra ? de_extra[3 * pairs + p] : 0.f;
+    de[p] = (s_tt + x0) * m0;
+    de[pairs + p] = (s_ti + x1) * m1;
+    de[2 * pairs + p] = (s_it + x2) * m2;
+    de[3 * pairs + p] = (s_ii + x3) * m3;
+  }
+}
+
+int launch_entity_side_bwd(const float* dA_mt, const float* dA_mi, const float* dA_et, const float* dA_ei,
+                           const float* mt, const float* mi, const float* et, const float* ei, const float* e,
+                           const float* de_extra, float* d_et, float* d_ei, float* de, int B, int N, int D,
+                           const float* mask, hipStream_t st) {
+  const int64_t pairs = (int64_t)B * N;
+  if (pairs <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_entity_side_bwd, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, dA_mt, dA_mi, dA_et, dA_ei,
+                     mt, mi, et, ei, e, de_extra, d_et, d_ei, de, pairs, N, D / 4, mask[0], mask[1], mask[2], mask[3]);
+  DRIN_CHECK_LAUNCH("k_entity_side_bwd");
+  return DRIN_OK;
+}
+
+}  // namespace drin

@@ -78,4 +78,28 @@ int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta,
 int launch_edge_update(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
                        hipStream_t st);
 
+// ---- backward row kernels (backward_kernels.hip) ------------------------------------------------
+// d cos(x[b], y[p]) : dx [B, D], dy [B*N, D]; scratch3 holds 3 * B*N floats
+int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx, float* dy, float* scratch3, int B,
+                      int N, int D, float eps, hipStream_t st);
+// in place: g (dL/dy) -> dL/dh for y = gelu(LN(h)); accumulates dgamma, dbeta and dbias (= column sum of dL/dh)
+int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, int64_t rows,
+                              int D, hipStream_t st);
+// out[c] += sum_rows x[row, c]
+int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st);
+// dpre = g * e' * (1 - e')
+int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st);
+// out[b,:] = scale (sum_n w1 v1 + sum_n w2 v2) + u      (v2, u optional)
+int launch_mention_reduce(const float* w1, const float* v1, const float* w2, const float* v2, const float* u,
+                          float* out, int B, int N, int D, float scale, hipStream_t st);
+// out[p,:] = scale (w1[p] m1[b,:] + w2[p] m2[b,:])       (m2 optional)
+int launch_entity_combine(const float* w1, const float* m1, const float* w2, const float* m2, float* out, int B, int N,
+                          int D, float scale, hipStream_t st);
+// entity side of the aggregation backward + edge gradients (see kernel comment); mask = edge_enabled[4]
+int launch_entity_side_bwd(const float* dA_mt, const float* dA_mi, const float* dA_et, const float* dA_ei,
+                           const float* mt, const float* mi, const float* et, const float* ei, const float* e,
+                           const float* de_extra, float* d_et, float* d_ei, float* de, int B, int N, int D,
+                           const float* mask, hipStream_t st);
+
 }  // namespace drin

@@ -77,7 +77,7 @@ struct Layout {
         fv[l] = take(2 * M * D);
       }
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
-      bwd_scratch_floats = 6 * (2 * M * D) + 8 * (2 * B * D) + 4 * (4 * M) + 4 * M + 4 * B + 1024;
+      bwd_scratch_floats = 4 * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M + 64) + (3 * M + 64);
       bwd_scratch = take(bwd_scratch_floats);
     } else {
       size_t e2[2] = {take(4 * M), take(4 * M)};
@@ -106,6 +106,7 @@ struct Layout {
 };
 
 int validate_config(const drin_config* c);
+void resolve_pooled(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out);
 int run_pooling(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out, hipStream_t st);
 int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P, float* edges, hipStream_t st);
 

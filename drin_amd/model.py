@@ -206,11 +206,12 @@ class _DrinScore(torch.autograd.Function):
                                      ctx.ws.numel(), g.data_ptr(), C.byref(gc), stream))
         nl = (len(params) - 8) // 8
         out = list(grads)
-        if nl > 0 and call.cfg.dynamic_edges:
-            # the last layer's edge update never reaches the score: the reference leaves .grad = None
-            base = 8 + 8 * (nl - 1)
+        # parameters the score does not depend on get no gradient at all in the reference (.grad is None):
+        # the last layer's edge update is dead (model.py:130-134), and static edges never use w_u / w_v
+        dead_layers = range(nl) if not call.cfg.dynamic_edges else range(nl - 1, nl)
+        for l in dead_layers:
             for j in (2, 3, 4, 5):
-                out[base + j] = None
+                out[8 + 8 * l + j] = None
         return (None, *out)
 
 

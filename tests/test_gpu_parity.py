@@ -225,3 +225,76 @@ def test_determinism():
         a = model(_to_dev(batch))
         b = model(_to_dev(batch))
     assert torch.equal(a, b)
+
+
+# ---- backward (loss.backward() of train.py:33-34) ---------------------------------------------------------
+def _grads_of(model, loss):
+    model.zero_grad()
+    loss.backward()
+    return {k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n][5]])
+def test_backward_matches_reference_golden(golden_dir, name):
+    """Gradient of a fixed linear functional of the scores, and of the triplet loss, against the
+    reference's autograd (golden) - including which parameters get no gradient at all."""
+    from drin_amd.metrics import TripletLoss
+    cfg, sd, batch = build_case(name)
+    g = _golden(golden_dir, name)
+    model = Model(cfg).to(DEV)
+    model.load_state_dict(sd)
+    dbatch = _to_dev(batch)
+    scores = model(dbatch[:-1])
+    rng = np.random.Generator(np.random.Philox(key=[int(g["functional_weights_seed"]), 99]))
+    w = torch.from_numpy(rng.standard_normal(size=tuple(scores.shape), dtype=np.float32)).to(DEV)
+    grads = _grads_of(model, (scores * w).sum())
+    assert sorted(k for k, v in grads.items() if v is None) == sorted(g["grad_none"].tolist())
+    full = CASES[name][4]
+    worst = 0.0
+    for k, gr in grads.items():
+        if gr is None:
+            continue
+        l2 = float(g[f"lin_grad_l2/{k}"])
+        rel = abs(gr.double().norm().item() - l2) / (l2 + 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 2e-4, (k, rel)
+        ref = g[f"lin_grad/{k}"]
+        got = gr.numpy() if full else gr.flatten()[:16].numpy()
+        np.testing.assert_allclose(got, ref, atol=3e-4 * l2 / np.sqrt(gr.numel()) + 1e-7, rtol=2e-3, err_msg=k)
+    print(f"{name}: worst relative grad-norm error {worst:.2e}")
+    loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
+    assert abs(loss.item() - float(g["triplet_loss"])) <= 1e-5
+    grads = _grads_of(model, loss)
+    for k, gr in grads.items():
+        if gr is not None:
+            l2 = float(g[f"loss_grad_l2/{k}"])
+            assert abs(gr.double().norm().item() - l2) <= 1e-3 * l2 + 1e-9, k
+    # one Adam step (train.py:55-56) lands on the reference's weights
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate)
+    opt.step()
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.detach().flatten()[:8].cpu().numpy(), g[f"adam_head/{k}"], atol=2e-5, rtol=1e-4, err_msg=k)
+
+
+def test_backward_vs_oracle_autograd_reference_batch():
+    """WikiDiverse reference batch (B=64): every parameter gradient against autograd through the oracle."""
+    from drin_amd.metrics import TripletLoss
+    cfg = DrinConfig()
+    sd = synth.make_state_dict(cfg, 7)
+    batch = synth.make_batch(cfg, 64, 43)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss = O.triplet_loss(batch[-1], O.forward(p, batch), cfg.triplet_margin)
+    ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
+    model = Model(cfg).to(DEV)
+    model.load_state_dict(sd)
+    dbatch = _to_dev(batch)
+    loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5
+    grads = _grads_of(model, loss)
+    for (k, got), r in zip(grads.items(), ref):
+        assert (got is None) == (r is None), k
+        if r is None:
+            continue
+        denom = r.norm().item() + 1e-12
+        rel = (got - r).norm().item() / denom
+        assert rel <= 2e-3, (k, rel)

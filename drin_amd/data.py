@@ -1,0 +1,195 @@
+"""`.npy` -> 15-tuple batches, the boundary feeder of the path (`drin/data.py`).
+
+File names, array layouts, the WikiDiverse reshapes (`data.py:30-38`), the WikiMEL entity-table
+gather through `qid2idx.json` (`data.py:40-46,87-93`), the +1 CLS shift of the span (`data.py:113-114`)
+and the one-hot answer table with its all-zero last row (`data.py:159-161`) follow the reference, so a
+directory preprocessed by the reference's `preprocess/*.py` loads unchanged.  Since neither dataset is
+available offline, `write_synthetic_dataset` produces a directory of the same layout from seeds.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import synth
+from .config import DrinConfig
+
+SPLITS = ("train", "valid", "test")
+
+
+def _load(path: str, mmap: Optional[str] = None) -> np.ndarray:
+    return np.load(path, mmap_mode=mmap)
+
+
+class MELData(Dataset):
+    """One split.  `__getitem__` returns the 15-tuple of `drin/data.py:110-126`."""
+
+    def __init__(self, cfg: DrinConfig, root: str, split: str, shared: Dict[str, np.ndarray],
+                 mention_mmap: Optional[str] = None):
+        self.cfg = cfg
+        N, D, R = cfg.num_candidates_model, cfg.bert_embed_dim, cfg.resnet_embed_dim
+        p = lambda name: os.path.join(root, name)  # noqa: E731
+        self.onehot = shared["onehot"]
+        if cfg.dataset_name == "wikidiverse":
+            self.entity_text_feature = shared[f"entity_text_{split}"].reshape((-1, N, D))            # data.py:31
+            self.entity_image_feature = shared[f"entity_image_{split}"].reshape((-1, N, R))          # data.py:32
+            self.entity_object_feature = shared[f"entity_object_{split}"].reshape((-1, N, cfg.object_topk_entity, R))
+            self.entity_object_score = shared[f"entity_object_score_{split}"].reshape((-1, N, cfg.object_topk_entity))
+        else:
+            self.entity_text_feature = shared["entity_text"]
+            self.entity_text_mask = shared["entity_text_mask"]
+            self.entity_image_feature = shared["entity_image"]
+            self.entity_object_feature = shared["entity_object"]
+            self.entity_object_score = shared["entity_object_score"]
+            with open(p("qid2idx.json")) as f:
+                self.qid2idx = json.load(f)                                                         # data.py:42-43
+            self.entity_qid = _load(p(f"entity-name-raw_{split}.npy")).reshape((-1, N))              # data.py:45-46
+        self.mention_text_feature = _load(p(f"mention-text-feature_{split}.npy"), mention_mmap)
+        self.mention_text_mask = _load(p(f"mention-text-mask_{split}.npy"))
+        self.mention_start_pos = _load(p(f"start-pos_{split}.npy"))
+        self.mention_end_pos = _load(p(f"end-pos_{split}.npy"))
+        self.mention_image_feature = _load(p(f"mention-image-feature_{split}.npy"), mention_mmap)
+        self.mention_object_feature = _load(p(f"mention-object-feature_{split}.npy"), mention_mmap)
+        self.mention_object_score = _load(p(f"mention-object-score_{split}.npy"))
+        self.miet_similarity = _load(p(f"similarity-miet_{split}.npy"))
+        self.mtei_similarity = _load(p(f"similarity-eimt_{split}.npy"))
+        self.answer = _load(p(f"answer_{split}.npy"))
+        n = len(self.answer)
+        for name in ("mention_text_feature", "mention_start_pos", "mention_image_feature", "mention_object_feature",
+                     "miet_similarity"):
+            if len(getattr(self, name)) != n:                                                       # data.py:73-80
+                raise ValueError(f"{name} has {len(getattr(self, name))} rows, answer has {n}")
+
+    def __len__(self) -> int:
+        return len(self.answer)
+
+    @staticmethod
+    def _t(x) -> torch.Tensor:
+        return torch.as_tensor(np.array(x) if isinstance(x, np.memmap) else x)
+
+    def __getitem__(self, idx):
+        t = self._t
+        entity_text_mask = 0                                                                        # data.py:86
+        if self.cfg.dataset_name == "wikimel":
+            rows = [self.qid2idx[str(q)] for q in self.entity_qid[idx]]                              # data.py:88
+            etf, emask = t(self.entity_text_feature[rows]), t(self.entity_text_mask[rows])
+            eimg, eobj, escore = (t(self.entity_image_feature[rows]), t(self.entity_object_feature[rows]),
+                                  t(self.entity_object_score[rows]))
+            entity_text_mask = emask
+        else:
+            etf, eimg = t(self.entity_text_feature[idx]), t(self.entity_image_feature[idx])
+            eobj, escore = t(self.entity_object_feature[idx]), t(self.entity_object_score[idx])
+        return (
+            t(self.mention_text_feature[idx]), t(self.mention_text_mask[idx]),
+            t(self.mention_start_pos[idx]) + 1, t(self.mention_end_pos[idx]) + 1,                    # data.py:113-114
+            t(self.mention_image_feature[idx]), t(self.mention_object_feature[idx]), t(self.mention_object_score[idx]),
+            etf, entity_text_mask, eimg, eobj, escore,
+            t(self.miet_similarity[idx]), t(self.mtei_similarity[idx]),
+            t(self.onehot[self.answer[idx]]),                                                       # data.py:109
+        )
+
+
+def create_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int] = None, num_workers: int = 0,
+                    rank: int = 0, world_size: int = 1, mention_mmap: Optional[str] = None,
+                    entity_mmap: Optional[str] = None) -> List[DataLoader]:
+    """`create_datasets()` of `drin/data.py:158-200`: [train, valid, test] loaders.
+
+    With `world_size > 1` every rank iterates its own contiguous shard of each split (mentions are
+    independent); shuffling of the train split uses the same seeded permutation on all
+    ranks so the shards stay disjoint.
+    """
+    N = cfg.num_candidates_model
+    onehot = np.concatenate([np.eye(N - 1, dtype=np.uint8), np.zeros((1, N - 1), dtype=np.uint8)], 0)   # data.py:159-161
+    shared: Dict[str, np.ndarray] = {"onehot": onehot}
+    p = lambda name: os.path.join(root, name)  # noqa: E731
+    if cfg.dataset_name == "wikimel":                                                               # data.py:163-175
+        shared["entity_text"] = _load(p("entity-attr-feature.npy"), entity_mmap)
+        shared["entity_text_mask"] = _load(p("entity-attr-mask.npy"))
+        shared["entity_image"] = _load(p("entity-image-feature_all.npy"), entity_mmap)
+        shared["entity_object"] = _load(p("entity-object-feature_all.npy"), entity_mmap)
+        shared["entity_object_score"] = _load(p("entity-object-score_all.npy"))
+    else:                                                                                           # data.py:188-200
+        for s in SPLITS:
+            shared[f"entity_text_{s}"] = _load(p(f"entity-attr-feature_{s}.npy"), entity_mmap)
+            shared[f"entity_image_{s}"] = _load(p(f"entity-image-feature_{s}.npy"), entity_mmap)
+            shared[f"entity_object_{s}"] = _load(p(f"entity-object-feature_{s}.npy"), entity_mmap)
+            shared[f"entity_object_score_{s}"] = _load(p(f"entity-object-score_{s}.npy"))
+    loaders = []
+    for s in SPLITS:
+        ds = MELData(cfg, root, s, shared, mention_mmap)
+        shuffle = s == "train" and cfg.shuffle_train_data                                           # data.py:155
+        sampler = ShardSampler(len(ds), rank, world_size, shuffle, cfg.seed) if (world_size > 1 or shuffle) else None
+        loaders.append(DataLoader(ds, batch_size or cfg.batch_size, shuffle=False, sampler=sampler, num_workers=num_workers))
+    return loaders
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Rank r of w draws indices perm[r::w] of one permutation shared by all ranks (re-seeded per epoch)."""
+
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool, seed: int):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def _order(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            return torch.randperm(self.n, generator=g).tolist()
+        return list(range(self.n))
+
+    def __iter__(self):
+        return iter(self._order()[self.rank::self.world])
+
+    def __len__(self) -> int:
+        return len(range(self.rank, self.n, self.world))
+
+
+def write_synthetic_dataset(cfg: DrinConfig, root: str, sizes=(256, 64, 64), seed: int = 1, num_entities: int = 512) -> None:
+    """A directory in the reference's preprocessed layout, drawn from `synth` seeds.
+
+    WikiDiverse stores per-split candidate tensors flattened over (mention, candidate); WikiMEL stores
+    one entity table plus per-split QID lists and `qid2idx.json` (`preprocess/bert.py:100-109`,
+    `preprocess/resnet.py:159-185`, `preprocess/clip.py:143`).  Span positions are stored WITHOUT the CLS
+    shift (the loader adds it); answers are indices into the one-hot table.
+    """
+    os.makedirs(root, exist_ok=True)
+    N = cfg.num_candidates_model
+    save = lambda name, arr: np.save(os.path.join(root, name), arr)  # noqa: E731
+    wm = cfg.dataset_name == "wikimel"
+    if wm:
+        tab = synth.make_batch(cfg.with_(num_candidates_data=num_entities - 1), 1, seed + 1000, as_torch=False)
+        save("entity-attr-feature.npy", tab[7][0])                   # [E, T, D]
+        save("entity-attr-mask.npy", tab[8][0])                      # [E, T]
+        save("entity-image-feature_all.npy", tab[9][0])              # [E, 1, R]
+        save("entity-object-feature_all.npy", tab[10][0])            # [E, Ke, 1, R]
+        save("entity-object-score_all.npy", tab[11][0])              # [E, Ke]
+        qids = [f"Q{100000 + 7 * i}" for i in range(num_entities)]
+        with open(os.path.join(root, "qid2idx.json"), "w") as f:
+            json.dump({q: i for i, q in enumerate(qids)}, f)
+    for split, m in zip(SPLITS, sizes):
+        b = synth.make_batch(cfg, m, seed + SPLITS.index(split), as_torch=False)
+        save(f"mention-text-feature_{split}.npy", b[0])
+        save(f"mention-text-mask_{split}.npy", b[1])
+        save(f"start-pos_{split}.npy", b[2] - 1)
+        save(f"end-pos_{split}.npy", b[3] - 1)
+        save(f"mention-image-feature_{split}.npy", b[4])
+        save(f"mention-object-feature_{split}.npy", b[5])
+        save(f"mention-object-score_{split}.npy", b[6])
+        save(f"similarity-miet_{split}.npy", b[12])
+        save(f"similarity-eimt_{split}.npy", b[13])
+        save(f"answer_{split}.npy", np.where(b[14].any(1), b[14].argmax(1), N - 1).astype(np.int64))
+        if wm:
+            g = np.random.Generator(np.random.Philox(key=[seed, 50 + SPLITS.index(split)]))
+            pick = g.integers(0, num_entities, size=(m, N))
+            save(f"entity-name-raw_{split}.npy", np.array(qids)[pick].reshape(-1))
+        else:
+            save(f"entity-attr-feature_{split}.npy", b[7].reshape(m * N, -1))
+            save(f"entity-image-feature_{split}.npy", b[9].reshape(m * N, -1))
+            save(f"entity-object-feature_{split}.npy", b[10].reshape(m * N, cfg.object_topk_entity, -1))
+            save(f"entity-object-score_{split}.npy", b[11].reshape(m * N, cfg.object_topk_entity))

@@ -1,0 +1,237 @@
+"""Lightning-free equivalent of the reference driver `train.py` for `model_type = "drin"`.
+
+Reproduces the semantics a `train.py` user observes:
+  * `seed_everything(seed)` before data and model construction (`train.py:134-136`);
+  * `num_epoch // test_epoch_interval` rounds, each with a NEW Adam(lr) over all parameters - i.e. the
+    optimizer state is reset every `test_epoch_interval` epochs (`train.py:55-56,112-122,141-144`) -
+    followed by a test pass;
+  * per step: `y_hat = model(batch[:-1])`, `TripletLoss(margin)(y, y_hat)`, top-k metrics updated on every
+    step and reset at every epoch start, reported divided by `1 - acc_correction[split]`
+    (`train.py:30-44,72-77`).
+Data-parallel (one process per GPU, `torch.distributed`): every rank steps through its own shard of the
+mentions; the only collectives are one all-reduce of the flat fp32 gradient bucket per step and the
+metric counters / loss scalar.  Per-rank batch = the reference's batch (64), gradients
+averaged; `global_batch_loss=True` instead all-gathers the scores so the TripletLoss couples the whole
+global batch exactly like a single-process run on `world * batch` mentions would.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .config import DrinConfig
+from .metrics import TopkAccuracy, TripletLoss
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class GradBucket:
+    """One flat fp32 buffer for the gradients of all parameters that receive one (26.8 MB
+    of the 31.5 MB carry gradients), all-reduced with a single collective per step."""
+
+    def __init__(self, params: Sequence[nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        self.flat: Optional[torch.Tensor] = None
+
+    def allreduce_mean(self) -> None:
+        world = _world()
+        if world == 1:
+            return
+        live = [p for p in self.params if p.grad is not None]
+        n = sum(p.numel() for p in live)
+        if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].device:
+            self.flat = torch.empty(n, dtype=torch.float32, device=live[0].device)
+        off = 0
+        for p in live:
+            self.flat[off: off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(world)
+        off = 0
+        for p in live:
+            p.grad.copy_(self.flat[off: off + p.numel()].view_as(p.grad))
+            off += p.numel()
+
+
+class _GatherScores(torch.autograd.Function):
+    """all_gather of the [B_local, N] scores with the matching reduce-scatter-free backward (each rank
+    keeps the slice of the gradient that belongs to its own mentions; the loss is replicated)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        world = _world()
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous())
+        ctx.rows = x.shape[0]
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        r = _rank()
+        return g[r * ctx.rows: (r + 1) * ctx.rows]
+
+
+@dataclass
+class StepLog:
+    loss: float
+    topk: List[float]
+
+
+@dataclass
+class History:
+    train: List[StepLog] = field(default_factory=list)
+    valid: List[StepLog] = field(default_factory=list)
+    test: List[StepLog] = field(default_factory=list)
+    seconds: float = 0.0
+
+
+class MELRunner:
+    """`MELModel` of `train.py:20-56` without Lightning."""
+
+    def __init__(self, cfg: DrinConfig, model: nn.Module, device, global_batch_loss: bool = False,
+                 log: Optional[Callable[[str], None]] = None):
+        self.cfg, self.model, self.device = cfg, model, torch.device(device)
+        self.loss = TripletLoss(cfg.triplet_margin)
+        self.metrics = [TopkAccuracy(k, self.device) for k in cfg.metrics_topk]
+        self.bucket = GradBucket(list(model.parameters()))
+        self.global_batch_loss = global_batch_loss
+        self.log = log
+
+    def _to_device(self, batch):
+        return [t.to(self.device, non_blocking=True) for t in batch]
+
+    def forward_step(self, batch, split: int):
+        """`_forward_step` (`train.py:30-44`)."""
+        batch = self._to_device(batch)
+        y = batch[-1]
+        y_hat = self.model(batch[:-1])
+        if self.global_batch_loss and _world() > 1:
+            world = _world()
+            ys = [torch.empty_like(y) for _ in range(world)]
+            dist.all_gather(ys, y.contiguous())
+            # the gathered loss is the GLOBAL mean; scale so that averaging grads over ranks reproduces it
+            loss = self.loss(torch.cat(ys, 0), _GatherScores.apply(y_hat)) * world
+        else:
+            loss = self.loss(y, y_hat)
+        with torch.no_grad():
+            for m in self.metrics:
+                m.update(y_hat.detach(), y)
+        return loss
+
+    def _topk(self, split: int) -> List[float]:
+        return [float(m.compute()) / (1 - self.cfg.acc_correction[split]) for m in self.metrics]
+
+    def run_epoch(self, loader, split: int, optimizer: Optional[torch.optim.Optimizer]) -> StepLog:
+        for m in self.metrics:                                         # EpochLogger.epoch_start (train.py:72-74)
+            m.reset()
+        training = optimizer is not None
+        self.model.train(training)
+        total, steps = 0.0, 0
+        for batch in loader:
+            if training:
+                optimizer.zero_grad(set_to_none=True)
+                loss = self.forward_step(batch, split)
+                loss.backward()
+                self.bucket.allreduce_mean()
+                optimizer.step()
+            else:
+                with torch.no_grad():
+                    loss = self.forward_step(batch, split)
+            total += float(loss.detach())
+            steps += 1
+        for m in self.metrics:
+            m.sync()
+        mean_loss = total / max(steps, 1)
+        if _world() > 1:
+            t = torch.tensor([mean_loss], device=self.device)
+            dist.all_reduce(t)
+            mean_loss = float(t) / _world()
+        return StepLog(mean_loss, self._topk(split))
+
+    def fit(self, loaders, num_epoch: Optional[int] = None, test_epoch_interval: Optional[int] = None) -> History:
+        """`main()` of `train.py:141-144`."""
+        cfg = self.cfg
+        num_epoch = cfg.num_epoch if num_epoch is None else num_epoch
+        interval = cfg.test_epoch_interval if test_epoch_interval is None else test_epoch_interval
+        hist = History()
+        t0 = time.perf_counter()
+        epoch = 0
+        for _round in range(num_epoch // interval):
+            optimizer = torch.optim.Adam(self.model.parameters(), lr=cfg.learning_rate)   # configure_optimizers, per Trainer
+            for _ in range(interval):
+                sampler = getattr(loaders[0], "sampler", None)
+                if hasattr(sampler, "set_epoch"):
+                    sampler.set_epoch(epoch)
+                tr = self.run_epoch(loaders[0], 0, optimizer)
+                va = self.run_epoch(loaders[1], 1, None)
+                hist.train.append(tr)
+                hist.valid.append(va)
+                epoch += 1
+                if self.log and _rank() == 0:
+                    self.log(f"epoch {epoch}/{num_epoch} train loss {tr.loss:.5f} top-k {tr.topk} | valid loss {va.loss:.5f} top-k {va.topk}")
+            te = self.run_epoch(loaders[2], 2, None)
+            hist.test.append(te)
+            if self.log and _rank() == 0:
+                self.log(f"test after epoch {epoch}: loss {te.loss:.5f} top-k {te.topk}")
+        hist.seconds = time.perf_counter() - t0
+        return hist
+
+
+def seed_everything(seed: int) -> None:
+    """`pl.seed_everything` (`train.py:134`): python, numpy and torch generators."""
+    import random
+
+    import numpy as np
+
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def main(argv: Optional[Sequence[str]] = None) -> None:
+    """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I]"""
+    import argparse
+    import os
+
+    from .config import wikimel_config
+    from .data import create_datasets
+    from .model import Model
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", required=True)
+    ap.add_argument("--dataset", default="wikidiverse")
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--interval", type=int, default=None)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--global-batch-loss", action="store_true")
+    a = ap.parse_args(argv)
+    cfg = wikimel_config() if a.dataset == "wikimel" else DrinConfig()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    seed_everything(cfg.seed)
+    loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())
+    model = Model(cfg).to(dev)
+    runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print)
+    runner.fit(loaders, a.epochs, a.interval)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

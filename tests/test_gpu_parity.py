@@ -298,3 +298,24 @@ def test_backward_vs_oracle_autograd_reference_batch():
         denom = r.norm().item() + 1e-12
         rel = (got - r).norm().item() / denom
         assert rel <= 2e-3, (k, rel)
+
+
+def test_training_loop_on_device_tracks_cpu_oracle_loop(tmp_path):
+    """config 1/3 plumbing on the GPU: .npy -> loader -> HIP forward/backward -> Adam, against the same
+    loop driven by the CPU oracle (same seed, same data): per-epoch losses and top-k agree."""
+    from drin_amd.data import create_datasets, write_synthetic_dataset
+    from drin_amd.train import MELRunner, seed_everything
+    from tests.helpers import OracleModel
+    cfg = DrinConfig(batch_size=8, num_epoch=2, test_epoch_interval=1, shuffle_train_data=False, **TINY)
+    write_synthetic_dataset(cfg, str(tmp_path), sizes=(32, 8, 8), seed=2)
+    hist = {}
+    for kind in ("hip", "oracle"):
+        seed_everything(cfg.seed)
+        loaders = create_datasets(cfg, str(tmp_path))
+        model = Model(cfg).to(DEV) if kind == "hip" else OracleModel(cfg)
+        hist[kind] = MELRunner(cfg, model, DEV if kind == "hip" else "cpu").fit(loaders)
+    for a, b in zip(hist["hip"].train + hist["hip"].valid + hist["hip"].test,
+                    hist["oracle"].train + hist["oracle"].valid + hist["oracle"].test):
+        assert abs(a.loss - b.loss) <= 2e-5, (a, b)
+        assert a.topk == pytest.approx(b.topk, abs=1e-9)
+    assert hist["hip"].train[-1].loss < hist["hip"].train[0].loss

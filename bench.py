@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="wikimel", choices=["wikimel", "wikidiverse"])
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 256 wikimel / 4096 wikidiverse)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,7 +123,7 @@ def main():
     cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
     B = args.batch or (256 if args.workload == "wikimel" else 4096)
     sd = synth.make_state_dict(cfg, 7)
-    model = Model(cfg).to(dev).eval()
+    model = Model(cfg, precision=args.precision).to(dev).eval()
     model.load_state_dict(sd)
     batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
     N = cfg.num_candidates_model

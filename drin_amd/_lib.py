@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 ABI_VERSION = 1
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
 
 fp = C.POINTER(C.c_float)
 ip = C.POINTER(C.c_int64)
@@ -78,6 +78,12 @@ EXPORTS = {
                                C.c_size_t, C.c_void_p, C.c_int, C.POINTER(DrinTraceC), C.c_void_p]),
     "drin_backward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                 C.c_size_t, C.c_void_p, C.POINTER(DrinParamGradsC), C.c_void_p]),
+    "drin_fused_supported": (C.c_int, [C.POINTER(DrinConfigC)]),
+    "drin_prepared_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
+    "drin_fused_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
+    "drin_prepare": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinParamsC), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "drin_forward_prepared": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "drin_profile_begin": (C.c_int, [C.c_int]),
     "drin_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "drin_kernel_class_name": (C.c_char_p, [C.c_int]),

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdrin_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "stream_kernels.hip", "gemm_f32.hip", "gcn_kernels.hip", "backward_kernels.hip"]
+SOURCES = ["api.hip", "stream_kernels.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gcn_kernels.hip", "backward_kernels.hip", "fused_kernels.hip", "fused_forward.hip"]
 
 
 def _hipcc() -> str:
@@ -39,6 +39,7 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str
     hipcc = _hipcc()
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden",
              f"-I{INCLUDE}", f"-I{CSRC}"]
+    flags += os.environ.get("DRIN_EXTRA_FLAGS", "").split()
     if debug:
         flags += ["-g", "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     hdr_t = _newest_header()

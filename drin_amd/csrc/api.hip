@@ -84,8 +84,8 @@ int validate_config(const drin_config* c) {
     set_error("config: batch * num_candidates too large for one call; split the batch");
     return DRIN_E_SHAPE;
   }
-  if (c->precision != DRIN_PREC_F32) {
-    set_error("config: precision %d is not built yet (fp32 MFMA only)", c->precision);
+  if (c->precision != DRIN_PREC_F32 && c->precision != DRIN_PREC_BF16X3 && c->precision != DRIN_PREC_BF16X3_ALL) {
+    set_error("config: precision %d is not built (DRIN_PREC_F32 and DRIN_PREC_BF16X3 are)", c->precision);
     return DRIN_E_UNSUPPORTED;
   }
   return DRIN_OK;

@@ -1,0 +1,76 @@
+// Argument blocks and launch wrappers of the fused two-layer inference pipeline.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace drin {
+
+struct StreamArgs {
+  // batch (entity side) - device pointers into the caller's tensors
+  const float* entity_text;          // TOKENS: [M, T, D]   else [M, D]
+  const int64_t* entity_mask;        // TOKENS: [M, T]
+  const float* entity_image;         // [M, R]
+  const float* entity_object;        // [M, Ke, R]
+  const float* entity_object_score;  // [M, Ke]
+  const float* miet;                 // [M]
+  const float* mtei;                 // [M]
+  // mention side
+  const float* span_mean;            // [B, D]
+  const float* mobj;                 // [B, Km, R]
+  const float* mscore;               // [B, Km]
+  const float* fu;                   // rows b and B + b, row stride ldfu: W_u(mt0), W_u(mi0)  (dynamic edges only)
+  const float* q;                    // [2 B][ldq]  fu * [W_v W_et | W_v W_ei]     (dynamic edges only)
+  const float* k_t;                  // [D]  W_v b_et + b_v
+  const float* k_i;                  // [D]  W_v b_ei + b_v
+  // outputs
+  float* xt_out;                     // TOKENS: pooled entity text [M, D]
+  float* e0m;                        // [4][M] layer-1 edges (already multiplied by the edge switch)
+  float* e1m;                        // [4][M] layer-2 edges (ditto)
+  float* s_part;                     // [B][chunks][2 D + 2 R + 4]
+  int B, N, D4, R4, T, Km, Ke, chunks, ldq, ldfu, dynamic;
+  float mask[4];
+  float cos_eps, miei_eps, clip;
+};
+
+struct PairArgs {
+  const float* h_text;   // [M, D]  X_t (W_h W_et)^T
+  const float* h_image;  // [M, D]  X_i (W_h W_ei)^T
+  const float* hm;       // rows b and B + b, row stride ldhm: W_h mt0, W_h mi0 (no bias)
+  const float* c_t;      // [D]  W_h b_et + b_h
+  const float* c_i;      // [D]  W_h b_ei + b_h
+  const float* gamma;
+  const float* beta;
+  const float* e0m;
+  const float* e1m;
+  float* et1;            // [M, D]
+  float* s2_part;        // [B][chunks][2 D]
+  int B, N, D4, chunks, ldhm;
+  float ln_eps;
+};
+
+struct FinalArgs {
+  const float* h2;       // [M, D]  et1 W_h2^T
+  const float* hm2;      // [2][B][D]  W_h2 mt1, W_h2 mi1 (no bias)
+  const float* b_h2;
+  const float* gamma;
+  const float* beta;
+  const float* e1m;
+  const float* mt2;      // [B, D]
+  float* scores;         // [M]
+  int B, N, D4;
+  float ln_eps, cos_eps;
+};
+
+size_t entity_stream_lds_bytes(const StreamArgs& a);
+int launch_entity_stream(const StreamArgs& a, hipStream_t st);
+int launch_reduce_stream_partials(const float* part, float* s_text, float* s_img, float* sig, int B, int D, int R,
+                                  int chunks, hipStream_t st);
+int launch_mention_input1(const float* T, const float* sig, const float* b_et, const float* b_ei, const float* v0,
+                          float* out, int B, int D, int N, hipStream_t st);
+int launch_pair_layer1(const PairArgs& a, hipStream_t st);
+int launch_mention_input2(const float* part, const float* mt1, float* out, int B, int D, int N, int chunks,
+                          hipStream_t st);
+int launch_pair_final(const FinalArgs& a, hipStream_t st);
+
+}  // namespace drin

@@ -1,0 +1,319 @@
+// Fused two-layer inference pipeline: drin_prepare / drin_forward_prepared.
+//
+// The reference evaluates, per (mention, candidate) pair, six D x D and one D x R contractions
+// (10.2 MFLOP after dead-code elimination).  For inference most of them are linear maps applied to
+// linear maps, so they fold (fp32 re-association only; parity is pinned by the same golden tests):
+//
+//   layer-1 entity vertices (model.py:128,146):   W_h(e_a mt + e_b mi + W_et x + b_et) + b_h
+//        = x (W_h W_et)^T + e_a (W_h mt) + e_b (W_h mi) + (W_h b_et + b_h)        -> C_t, hm, c_t
+//   layer-1 dynamic edges (model.py:148-153):     mean_d(W_u(u) * (W_v(W_et x + b_et) + b_v))
+//        = ((W_v W_et)^T W_u(u)) . x / D + W_u(u) . (W_v b_et + b_v) / D           -> q, kappa
+//   layer-1 mention vertices (model.py:143-144):  mean_n(e W_et x + e b_et)
+//        = W_et (sum_n e x) / N + b_et (sum_n e) / N                               -> S, sigma
+//   layer-2 (last): only mt'' and et'' reach the score (model.py:207-209); its edge update, mi'', ei''
+//   are dead, and  W_h2(e_a mt' + e_b mi' + et') = et' W_h2^T + e_a (W_h2 mt') + e_b (W_h2 mi').
+//
+// Per pair this leaves three contractions - x_t C_t^T (D x D), x_i C_i^T (D x R), et' W_h2^T (D x D):
+// 5.5 MFLOP - plus ONE streaming pass over the entity bytes (k_entity_stream) and two row kernels.
+// The folded matrices depend only on the weights: drin_prepare computes them once per weight version
+// into a caller-owned buffer.
+#include <string.h>
+
+#include "fused.h"
+#include "internal.h"
+#include "layout.h"
+
+namespace drin {
+
+struct Prepared {  // offsets in floats
+  size_t wcat1, bcat1, ecat, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
+  void build(const drin_config& c) {
+    const size_t D = c.embed_dim, R = c.image_dim;
+    size_t off = 0;
+    auto take = [&off](size_t n) {
+      const size_t o = off;
+      off += (n + 63) & ~(size_t)63;
+      return o;
+    };
+    wcat1 = take(2 * D * D);      // [W_h1; W_u1]           [2D, D]
+    bcat1 = take(2 * D);          // [0; b_u1]
+    ecat = take(D * (D + R));     // [W_v1 W_et | W_v1 W_ei] [D, D + R]
+    k_t = take(D);                // W_v1 b_et + b_v1
+    k_i = take(D);                // W_v1 b_ei + b_v1
+    c_txt = take(D * D);          // W_h1 W_et              [D, D]
+    c_img = take(D * R);          // W_h1 W_ei              [D, R]
+    cb_t = take(D);               // W_h1 b_et + b_h1
+    cb_i = take(D);               // W_h1 b_ei + b_h1
+    total = off;
+  }
+};
+
+struct FusedLayout {  // workspace offsets in floats
+  size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, agg1, vm1, hm2, h_text, h_image,
+      et1, s2_part, agg2, mt2, total;
+  int chunks;
+  void build(const drin_config& c) {
+    const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
+    // enough workgroups to fill 256 CUs a few times over, at least one candidate per wave
+    int ch = (int)((768 + B - 1) / (B ? B : 1));
+    const int max_ch = (int)((N + 3) / 4);
+    chunks = ch < 1 ? 1 : (ch > max_ch ? max_ch : (ch > 16 ? 16 : ch));
+    size_t off = 0;
+    auto take = [&off](size_t n) {
+      const size_t o = off;
+      off += (n + 63) & ~(size_t)63;
+      return o;
+    };
+    span_mean = take(B * D);
+    mimg = take(B * R);
+    vm0 = take(2 * B * D);
+    hmfu = take(2 * B * 2 * D);
+    q = take(2 * B * (D + R));
+    e0m = take(4 * M);
+    e1m = take(4 * M);
+    xt = take(c.entity_tokens > 0 ? M * D : 0);
+    s_part = take(B * chunks * (2 * D + 2 * R + 4));
+    s_text = take(2 * B * D);
+    s_img = take(2 * B * R);
+    sig = take(4 * B);
+    tm = take(2 * B * D);
+    agg1 = take(2 * B * D);
+    vm1 = take(2 * B * D);
+    hm2 = take(2 * B * D);
+    h_text = take(M * D);   // re-used for et1 W_h2^T once layer 1 is done
+    h_image = take(M * D);
+    et1 = take(M * D);
+    s2_part = take(B * chunks * 2 * D);
+    agg2 = take(B * D);
+    mt2 = take(B * D);
+    total = off;
+  }
+};
+
+static int fused_supported(const drin_config* c) {
+  if (c->num_layers != 2) {
+    set_error("fused path: built for num_layers == 2 (got %d); use drin_forward", c->num_layers);
+    return DRIN_E_UNSUPPORTED;
+  }
+  if (c->mention_object_inner > 1 || c->entity_object_inner > 1 || c->entity_image_inner > 1) {
+    set_error("fused path: inner feature dims > 1 need the pooled path of drin_forward");
+    return DRIN_E_UNSUPPORTED;
+  }
+  const bool tiny = c->embed_dim <= 256 && c->image_dim <= 256;
+  const bool full = c->embed_dim <= 768 && c->image_dim <= 2048;
+  if (!tiny && !full) {
+    set_error("fused path: D=%d R=%d outside the built instantiations", c->embed_dim, c->image_dim);
+    return DRIN_E_UNSUPPORTED;
+  }
+  return DRIN_OK;
+}
+
+}  // namespace drin
+
+using namespace drin;
+
+extern "C" {
+
+int drin_fused_supported(const drin_config* cfg) {
+  DRIN_TRY(validate_config(cfg));
+  return fused_supported(cfg);
+}
+
+size_t drin_prepared_bytes(const drin_config* cfg) {
+  if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
+  Prepared P;
+  P.build(*cfg);
+  return P.total * sizeof(float);
+}
+
+size_t drin_fused_workspace_bytes(const drin_config* cfg) {
+  if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
+  FusedLayout L;
+  L.build(*cfg);
+  return L.total * sizeof(float);
+}
+
+int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepared, size_t prepared_bytes,
+                 void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(fused_supported(cfg));
+  if (!params || !prepared) {
+    set_error("drin_prepare: NULL argument");
+    return DRIN_E_NULL;
+  }
+  Prepared P;
+  P.build(*cfg);
+  if (prepared_bytes < P.total * sizeof(float) || !aligned16(prepared)) {
+    set_error("drin_prepare: buffer has %zu bytes (needs %zu) or is not 16-byte aligned", prepared_bytes,
+              P.total * sizeof(float));
+    return DRIN_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* pb = (float*)prepared;
+  const int D = cfg->embed_dim, R = cfg->image_dim;
+  const drin_layer_params& L1 = params->layer[0];
+  const int F32 = DRIN_PREC_F32;  // the folds are computed once, in exact fp32
+  auto copy = [&](float* dst, const float* src, size_t n) -> int {
+    hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? DRIN_OK : hip_fail(e, "hipMemcpyAsync(prepare)");
+  };
+  DRIN_TRY(copy(pb + P.wcat1, L1.w_h, (size_t)D * D));
+  DRIN_TRY(copy(pb + P.wcat1 + (size_t)D * D, L1.w_u, (size_t)D * D));
+  {
+    hipError_t e = hipMemsetAsync(pb + P.bcat1, 0, D * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(prepare)");
+  }
+  DRIN_TRY(copy(pb + P.bcat1 + D, L1.b_u, D));
+  // E = W_v1 [W_et | W_ei]   (y[m, n] = sum_k x[m, k] w[k, n])
+  DRIN_TRY(launch_gemm_nn(L1.w_v, D, params->w_entity_text, D, pb + P.ecat, D + R, D, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nn(L1.w_v, D, params->w_entity_image, R, pb + P.ecat + D, D + R, D, R, D, false, F32, st));
+  // k = b_e W_v1^T + b_v1 as row vectors
+  DRIN_TRY(launch_gemm_nt(params->b_entity_text, D, L1.w_v, D, L1.b_v, pb + P.k_t, D, 1, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(params->b_entity_image, D, L1.w_v, D, L1.b_v, pb + P.k_i, D, 1, D, D, false, F32, st));
+  // C = W_h1 [W_et | W_ei],  cb = b_e W_h1^T + b_h1
+  DRIN_TRY(launch_gemm_nn(L1.w_h, D, params->w_entity_text, D, pb + P.c_txt, D, D, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nn(L1.w_h, D, params->w_entity_image, R, pb + P.c_img, R, D, R, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(params->b_entity_text, D, L1.w_h, D, L1.b_h, pb + P.cb_t, D, 1, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(params->b_entity_image, D, L1.w_h, D, L1.b_h, pb + P.cb_i, D, 1, D, D, false, F32, st));
+  return DRIN_OK;
+}
+
+int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
+                          void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(fused_supported(cfg));
+  if (!b || !params || !prepared || !workspace || !scores) {
+    set_error("drin_forward_prepared: NULL argument");
+    return DRIN_E_NULL;
+  }
+  FusedLayout L;
+  L.build(*cfg);
+  if (workspace_bytes < L.total * sizeof(float) || !aligned16(workspace)) {
+    set_error("drin_forward_prepared: workspace has %zu bytes (needs %zu) or is not 16-byte aligned", workspace_bytes,
+              L.total * sizeof(float));
+    return DRIN_E_WORKSPACE;
+  }
+  Prepared P;
+  P.build(*cfg);
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const float* pb = (const float*)prepared;
+  const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
+  const int64_t M = (int64_t)B * N;
+  if (B == 0) return DRIN_OK;
+  const int prec = cfg->precision;
+  const int F32 = DRIN_PREC_F32;
+  const bool dyn = cfg->dynamic_edges != 0;
+  const bool tokens = cfg->entity_tokens > 0;
+  const drin_layer_params& L1 = params->layer[0];
+  const drin_layer_params& L2 = params->layer[1];
+
+  // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears
+  DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
+                            cfg->mention_tokens, D, st));
+  DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
+  float* vm0 = ws + L.vm0;
+  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, F32, st));
+  // (2) [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1], then q = fu [W_v1 W_et | W_v1 W_ei]
+  float* hmfu = ws + L.hmfu;
+  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, F32, st));
+  if (dyn)
+    DRIN_TRY(launch_gemm_nn(hmfu + D, 2 * D, pb + P.ecat, D + R, ws + L.q, D + R, 2 * (int64_t)B, D + R, D, false, F32, st));
+  // (3) one pass over the entity-side bytes
+  StreamArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.entity_text = b->entity_text;
+  sa.entity_mask = b->entity_text_mask;
+  sa.entity_image = b->entity_image;
+  sa.entity_object = b->entity_object;
+  sa.entity_object_score = b->entity_object_score;
+  sa.miet = b->miet_similarity;
+  sa.mtei = b->mtei_similarity;
+  sa.span_mean = ws + L.span_mean;
+  sa.mobj = b->mention_object;
+  sa.mscore = b->mention_object_score;
+  sa.fu = hmfu + D;
+  sa.ldfu = 2 * D;
+  sa.q = ws + L.q;
+  sa.ldq = D + R;
+  sa.k_t = pb + P.k_t;
+  sa.k_i = pb + P.k_i;
+  sa.xt_out = ws + L.xt;
+  sa.e0m = ws + L.e0m;
+  sa.e1m = ws + L.e1m;
+  sa.s_part = ws + L.s_part;
+  sa.B = B;
+  sa.N = N;
+  sa.D4 = D / 4;
+  sa.R4 = R / 4;
+  sa.T = cfg->entity_tokens;
+  sa.Km = cfg->mention_objects;
+  sa.Ke = cfg->entity_objects;
+  sa.chunks = L.chunks;
+  sa.dynamic = dyn ? 1 : 0;
+  for (int k = 0; k < 4; ++k) sa.mask[k] = cfg->edge_enabled[k];
+  sa.cos_eps = cfg->cosine_eps;
+  sa.miei_eps = cfg->miei_eps;
+  sa.clip = cfg->clip_scale;
+  DRIN_TRY(launch_entity_stream(sa, st));
+  DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
+  // (4) layer-1 mention vertices: T = S_text W_et^T + S_img W_ei^T, then the W_h input, W_h, LN, GELU
+  DRIN_TRY(launch_gemm_nt(ws + L.s_text, D, params->w_entity_text, D, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.s_img, R, params->w_entity_image, R, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, R, true, F32, st));
+  DRIN_TRY(launch_mention_input1(ws + L.tm, ws + L.sig, params->b_entity_text, params->b_entity_image, vm0, ws + L.agg1, B, D, N, st));
+  float* vm1 = ws + L.vm1;
+  DRIN_TRY(launch_gemm_nt(ws + L.agg1, D, L1.w_h, D, L1.b_h, vm1, D, 2 * (int64_t)B, D, D, false, F32, st));
+  DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
+  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, F32, st));
+  // (5) the two pair-sized layer-1 contractions on the folded weights
+  const float* x_t = tokens ? ws + L.xt : b->entity_text;
+  DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, false, prec, st));
+  // (6) layer-1 entity vertices + layer-2 mention aggregates
+  PairArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.h_text = ws + L.h_text;
+  pa.h_image = ws + L.h_image;
+  pa.hm = hmfu;
+  pa.ldhm = 2 * D;
+  pa.c_t = pb + P.cb_t;
+  pa.c_i = pb + P.cb_i;
+  pa.gamma = L1.ln_weight;
+  pa.beta = L1.ln_bias;
+  pa.e0m = ws + L.e0m;
+  pa.e1m = ws + L.e1m;
+  pa.et1 = ws + L.et1;
+  pa.s2_part = ws + L.s2_part;
+  pa.B = B;
+  pa.N = N;
+  pa.D4 = D / 4;
+  pa.chunks = L.chunks;
+  pa.ln_eps = cfg->layer_norm_eps;
+  DRIN_TRY(launch_pair_layer1(pa, st));
+  // (7) layer-2 mention-text vertex
+  DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, F32, st));
+  DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
+  // (8) layer-2 entity-text contraction, vertex and score
+  float* h2 = ws + L.h_text;
+  DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
+  FinalArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.h2 = h2;
+  fa.hm2 = ws + L.hm2;
+  fa.b_h2 = L2.b_h;
+  fa.gamma = L2.ln_weight;
+  fa.beta = L2.ln_bias;
+  fa.e1m = ws + L.e1m;
+  fa.mt2 = ws + L.mt2;
+  fa.scores = scores;
+  fa.B = B;
+  fa.N = N;
+  fa.D4 = D / 4;
+  fa.ln_eps = cfg->layer_norm_eps;
+  fa.cos_eps = cfg->cosine_eps;
+  return launch_pair_final(fa, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,539 @@
+// Kernels of the fused two-layer inference pipeline (fused_forward.hip explains the algebra).
+//
+// k_entity_stream is the HBM-bound heart of the path: ONE pass over the entity-side bytes of a
+// mention (token features, image row, object rows) produces everything the first GCN layer needs from
+// them - pooled text, the static edges, the dynamic edges of layer 1 (as dot products with
+// per-mention vectors instead of a W_v contraction), and the edge-weighted sums that feed the
+// mention vertices.  One 256-thread workgroup owns a chunk of one mention's candidates, so all the
+// cross-candidate reductions stay on chip and no atomics are needed (results are bit-reproducible).
+#include "device_utils.h"
+#include "fused.h"
+#include "internal.h"
+
+namespace drin {
+
+template <int V>
+struct Row {
+  float4 v[V];
+};
+
+template <int V>
+__device__ __forceinline__ Row<V> load_row(const float* __restrict__ p, int lane, int n4) {
+  Row<V> r;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c4 = lane + 64 * j;
+    r.v[j] = c4 < n4 ? ld4(p + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const Row<V>& r, int lane, int n4) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < n4) st4(p + c4 * 4, r.v[j]);
+  }
+}
+template <int V>
+__device__ __forceinline__ float dot_rows(const Row<V>& a, const Row<V>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) s += dot4(a.v[j], b.v[j]);
+  return s;
+}
+template <int V>
+__device__ __forceinline__ void axpy_row(Row<V>& acc, float w, const Row<V>& x) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc.v[j] = fma4(w, x.v[j], acc.v[j]);
+}
+template <int V>
+__device__ __forceinline__ Row<V> zero_row() {
+  Row<V> r;
+#pragma unroll
+  for (int j = 0; j < V; ++j) r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  return r;
+}
+// dot with a vector that lives in LDS (same lane -> column map)
+template <int V>
+__device__ __forceinline__ float dot_row_lds(const Row<V>& a, const float* lds, int lane, int n4) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < n4) s += dot4(a.v[j], ld4(lds + c4 * 4));
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid (chunks, B), 256 threads.  Wave w of the workgroup takes candidates c0 + w, c0 + w + 4, ...
+template <int DV, int RV, bool TOKENS>
+__global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D4 = a.D4, R4 = a.R4, D = D4 * 4, R = R4 * 4;
+  float* l_mobj = lds;                          // [Km][R]
+  float* l_q = l_mobj + a.Km * R;               // [2][R]   q_ti, q_ii
+  float* l_red = l_q + 2 * R;                   // [2 D + 2 R] cross-wave reduction of the weighted sums
+  float* l_mt = l_red + 2 * D + 2 * R;          // [3][D]   span mean, q_tt, q_it (kept out of the register file)
+  float* l_small = l_mt + 3 * D;                // [Km] clamped object norms, then [4] edge sums
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.y;
+  const int per = (a.N + a.chunks - 1) / a.chunks;
+  const int n_begin = blockIdx.x * per, n_end = min(a.N, n_begin + per);
+  const bool dyn = a.dynamic != 0;
+
+  // ---- per-workgroup prologue: mention-side vectors into LDS / registers -----------------------------
+  for (int i = threadIdx.x; i < a.Km * R4; i += 256) st4(l_mobj + i * 4, ld4(a.mobj + (b * a.Km) * R + i * 4));
+  for (int i = threadIdx.x; i < D4; i += 256) st4(l_mt + i * 4, ld4(a.span_mean + b * D + i * 4));
+  if (dyn) {
+    for (int i = threadIdx.x; i < 2 * R4; i += 256) {
+      const int which = i / R4, c4 = i - which * R4;  // rows fu_t (b) and fu_i (B + b) of q, columns D .. D + R
+      st4(l_q + i * 4, ld4(a.q + ((int64_t)which * a.B + b) * a.ldq + D + c4 * 4));
+    }
+    for (int i = threadIdx.x; i < 2 * D4; i += 256) {
+      const int which = i / D4, c4 = i - which * D4;  // columns 0 .. D of the same rows
+      st4(l_mt + D + i * 4, ld4(a.q + ((int64_t)which * a.B + b) * a.ldq + c4 * 4));
+    }
+  }
+  __syncthreads();
+  for (int i = wave; i < a.Km; i += 4) {  // |mobj_i| (model.py:88: every pair re-normalises the same rows)
+    float s = 0.f;
+    for (int c4 = lane; c4 < R4; c4 += 64) {
+      const float4 v = ld4(l_mobj + i * R + c4 * 4);
+      s += dot4(v, v);
+    }
+    s = wave_sum(s);
+    if (lane == 0) l_small[i] = fmaxf(sqrtf(s), a.cos_eps);
+  }
+  float m_t_norm;
+  {
+    const Row<DV> m_t = load_row<DV>(l_mt, lane, D4);
+    m_t_norm = fmaxf(sqrtf(wave_sum(dot_rows<DV>(m_t, m_t))), a.cos_eps);
+  }
+  float kap_tt = 0.f, kap_ti = 0.f, kap_it = 0.f, kap_ii = 0.f;
+  if (dyn) {
+    const Row<DV> fu_t = load_row<DV>(a.fu + b * a.ldfu, lane, D4);
+    const Row<DV> fu_i = load_row<DV>(a.fu + ((int64_t)a.B + b) * a.ldfu, lane, D4);
+    const Row<DV> k_t = load_row<DV>(a.k_t, lane, D4), k_i = load_row<DV>(a.k_i, lane, D4);
+    kap_tt = wave_sum(dot_rows<DV>(fu_t, k_t));
+    kap_ti = wave_sum(dot_rows<DV>(fu_t, k_i));
+    kap_it = wave_sum(dot_rows<DV>(fu_i, k_t));
+    kap_ii = wave_sum(dot_rows<DV>(fu_i, k_i));
+  }
+  __syncthreads();
+
+  Row<DV> S_tt = zero_row<DV>(), S_it = zero_row<DV>();
+  Row<RV> S_ti = zero_row<RV>(), S_ii = zero_row<RV>();
+  float sg_tt = 0.f, sg_ti = 0.f, sg_it = 0.f, sg_ii = 0.f;
+  const float inv_d = 1.0f / (float)D;
+
+  for (int n = n_begin + wave; n < n_end; n += 4) {
+    const int64_t p = b * a.N + n;
+    // ---- text: CLS / pooler cosine (model.py:71-76) and token mean (ghmfc.py:245-249) ---------------
+    Row<DV> xt;
+    float tt;
+    if (TOKENS) {
+      const int T = a.T;
+      int cnt = 0;
+      for (int t = lane; t < T; t += 64) cnt += (int)a.entity_mask[p * T + t];
+      cnt = (int)wave_sum((float)cnt);
+      int stop = cnt - 1;
+      if (stop < 0) stop += T;
+      stop = stop < 0 ? 0 : (stop > T ? T : stop);
+      const float* base = a.entity_text + p * (int64_t)T * D;
+      const Row<DV> cls = load_row<DV>(base, lane, D4);
+      Row<DV> acc = zero_row<DV>();
+      int t = 1;
+      for (; t + 4 <= stop; t += 4) {  // 4 token rows (12 KB at D = 768) in flight per wave
+        const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
+        const Row<DV> r1 = load_row<DV>(base + (int64_t)(t + 1) * D, lane, D4);
+        const Row<DV> r2 = load_row<DV>(base + (int64_t)(t + 2) * D, lane, D4);
+        const Row<DV> r3 = load_row<DV>(base + (int64_t)(t + 3) * D, lane, D4);
+#pragma unroll
+        for (int j = 0; j < DV; ++j) acc.v[j] = (((acc.v[j] + r0.v[j]) + r1.v[j]) + r2.v[j]) + r3.v[j];
+      }
+      for (; t < stop; ++t) {
+        const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
+#pragma unroll
+        for (int j = 0; j < DV; ++j) acc.v[j] = acc.v[j] + r0.v[j];
+      }
+      const float den = stop > 1 ? (float)(stop - 1) : 0.0f;  // empty slice: 0 / 0 = NaN like the reference
+#pragma unroll
+      for (int j = 0; j < DV; ++j)
+        xt.v[j] = make_float4(acc.v[j].x / den, acc.v[j].y / den, acc.v[j].z / den, acc.v[j].w / den);
+      store_row<DV>(a.xt_out + p * D, xt, lane, D4);
+      const float xy = wave_sum(dot_row_lds<DV>(cls, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(cls, cls));
+      tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
+    } else {
+      xt = load_row<DV>(a.entity_text + p * D, lane, D4);
+      const float xy = wave_sum(dot_row_lds<DV>(xt, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(xt, xt));
+      tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
+    }
+    // ---- objects: weighted pair similarity (model.py:84-92) ------------------------------------------
+    float sim = 0.f, wsum = 0.f;
+    for (int j = 0; j < a.Ke; ++j) {
+      const Row<RV> eo = load_row<RV>(a.entity_object + (p * a.Ke + j) * R, lane, R4);
+      const float ny = fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps);
+      const float es = a.entity_object_score[p * a.Ke + j];
+      for (int i = 0; i < a.Km; ++i) {
+        const float xy = wave_sum(dot_row_lds<RV>(eo, l_mobj + i * R, lane, R4));
+        const float w = a.mscore[b * a.Km + i] * es;
+        sim += xy / (l_small[i] * ny) * w;
+        wsum += w;
+      }
+    }
+    // the reference sums i-major, j-minor; with Ke = 1 (both datasets) the orders coincide
+    const float ii = sim / (wsum + a.miei_eps);
+    // ---- image row + edges ----------------------------------------------------------------------------
+    const Row<RV> xi = load_row<RV>(a.entity_image + p * R, lane, R4);
+    const float e_tt = tt * a.mask[0];
+    const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
+    const float e_it = (a.miet[p] / a.clip) * a.mask[2];
+    const float e_ii = ii * a.mask[3];
+    float n_tt = e_tt, n_ti = e_ti, n_it = e_it, n_ii = e_ii;  // layer-2 edges (static: pass-through, model.py:136)
+    if (dyn) {  // e' = sigmoid(mean_d(W_u(u) * W_v(v)) + e) with W_v folded into q, kappa (model.py:148-153)
+      const float d_tt = wave_sum(dot_row_lds<DV>(xt, l_mt + D, lane, D4));
+      const float d_it = wave_sum(dot_row_lds<DV>(xt, l_mt + 2 * D, lane, D4));
+      const float d_ti = wave_sum(dot_row_lds<RV>(xi, l_q, lane, R4));
+      const float d_ii = wave_sum(dot_row_lds<RV>(xi, l_q + R, lane, R4));
+      n_tt = sigmoidf((d_tt + kap_tt) * inv_d + e_tt);
+      n_ti = sigmoidf((d_ti + kap_ti) * inv_d + e_ti);
+      n_it = sigmoidf((d_it + kap_it) * inv_d + e_it);
+      n_ii = sigmoidf((d_ii + kap_ii) * inv_d + e_ii);
+    }
+    if (lane == 0) {
+      const int64_t M = (int64_t)a.B * a.N;
+      a.e0m[p] = e_tt;
+      a.e0m[M + p] = e_ti;
+      a.e0m[2 * M + p] = e_it;
+      a.e0m[3 * M + p] = e_ii;
+      a.e1m[p] = n_tt * a.mask[0];
+      a.e1m[M + p] = n_ti * a.mask[1];
+      a.e1m[2 * M + p] = n_it * a.mask[2];
+      a.e1m[3 * M + p] = n_ii * a.mask[3];
+    }
+    // ---- edge-weighted sums for the mention vertices (model.py:143-144, before the Linear) -----------
+    axpy_row<DV>(S_tt, e_tt, xt);
+    axpy_row<DV>(S_it, e_it, xt);
+    axpy_row<RV>(S_ti, e_ti, xi);
+    axpy_row<RV>(S_ii, e_ii, xi);
+    sg_tt += e_tt;
+    sg_ti += e_ti;
+    sg_it += e_it;
+    sg_ii += e_ii;
+  }
+
+  // ---- fixed-order cross-wave reduction through LDS, then one partial per (mention, chunk) -----------
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < D4) {
+          float* p0 = l_red + c4 * 4;
+          float* p1 = l_red + D + c4 * 4;
+          st4(p0, w == 0 ? S_tt.v[j] : ld4(p0) + S_tt.v[j]);
+          st4(p1, w == 0 ? S_it.v[j] : ld4(p1) + S_it.v[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RV; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < R4) {
+          float* p0 = l_red + 2 * D + c4 * 4;
+          float* p1 = l_red + 2 * D + R + c4 * 4;
+          st4(p0, w == 0 ? S_ti.v[j] : ld4(p0) + S_ti.v[j]);
+          st4(p1, w == 0 ? S_ii.v[j] : ld4(p1) + S_ii.v[j]);
+        }
+      }
+      if (lane == 0) {
+        float* s4 = l_small + a.Km;
+        s4[0] = (w == 0 ? 0.f : s4[0]) + sg_tt;
+        s4[1] = (w == 0 ? 0.f : s4[1]) + sg_ti;
+        s4[2] = (w == 0 ? 0.f : s4[2]) + sg_it;
+        s4[3] = (w == 0 ? 0.f : s4[3]) + sg_ii;
+      }
+    }
+  }
+  __syncthreads();
+  float* out = a.s_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D + 2 * R + 4);
+  for (int i = threadIdx.x; i < (2 * D + 2 * R) / 4; i += 256) st4(out + i * 4, ld4(l_red + i * 4));
+  if (threadIdx.x < 4) out[2 * D + 2 * R + threadIdx.x] = l_small[a.Km + threadIdx.x];
+}
+
+size_t entity_stream_lds_bytes(const StreamArgs& a) {
+  const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;
+  return sizeof(float) * (a.Km * R + 2 * R + 2 * D + 2 * R + 3 * D + a.Km + 4);
+}
+
+template <int DV, int RV, bool TOKENS>
+static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
+  const size_t lds = entity_stream_lds_bytes(a);
+  auto kern = k_entity_stream<DV, RV, TOKENS>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(entity_stream)");
+    attr_done = true;
+  }
+  KernelTimer timer(DRIN_KC_POOL, st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), lds, st, a);
+  DRIN_CHECK_LAUNCH("k_entity_stream");
+  return DRIN_OK;
+}
+
+int launch_entity_stream(const StreamArgs& a, hipStream_t st) {
+  if (a.B <= 0) return DRIN_OK;
+  if (a.B > 65535) {
+    set_error("entity_stream: batch %d exceeds the grid limit; split the batch", a.B);
+    return DRIN_E_SHAPE;
+  }
+  const bool tok = a.T > 0;
+  if (a.D4 <= 64 && a.R4 <= 64) return tok ? launch_stream_t<1, 1, true>(a, st) : launch_stream_t<1, 1, false>(a, st);
+  if (a.D4 <= 192 && a.R4 <= 512) return tok ? launch_stream_t<3, 8, true>(a, st) : launch_stream_t<3, 8, false>(a, st);
+  set_error("entity_stream: D=%d R=%d outside the built instantiations", a.D4 * 4, a.R4 * 4);
+  return DRIN_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum the per-chunk partials in chunk order and lay them out for the mention-side GEMMs:
+//   s_text [2][B][D] = (S_tt, S_it), s_img [2][B][R] = (S_ti, S_ii), sig [4][B] = (tt, ti, it, ii)
+__global__ void __launch_bounds__(256) k_reduce_stream_partials(const float* __restrict__ part, float* __restrict__ s_text,
+                                                                float* __restrict__ s_img, float* __restrict__ sig,
+                                                                int B, int D, int R, int chunks) {
+  const int64_t b = blockIdx.y;
+  const int width = 2 * D + 2 * R + 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= width) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(b * chunks + c) * (int64_t)width + i];
+  if (i < D) {
+    s_text[b * D + i] = s;
+  } else if (i < 2 * D) {
+    s_text[((int64_t)B + b) * D + (i - D)] = s;
+  } else if (i < 2 * D + R) {
+    s_img[b * R + (i - 2 * D)] = s;
+  } else if (i < 2 * D + 2 * R) {
+    s_img[((int64_t)B + b) * R + (i - 2 * D - R)] = s;
+  } else {
+    sig[(int64_t)(i - 2 * D - 2 * R) * B + b] = s;
+  }
+}
+
+int launch_reduce_stream_partials(const float* part, float* s_text, float* s_img, float* sig, int B, int D, int R,
+                                  int chunks, hipStream_t st) {
+  if (B <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_reduce_stream_partials, dim3((unsigned)cdiv(2 * D + 2 * R + 4, 256), (unsigned)B), dim3(256), 0,
+                     st, part, s_text, s_img, sig, B, D, R, chunks);
+  DRIN_CHECK_LAUNCH("k_reduce_stream_partials");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// W_h input of the two mention vertices of layer 1 (model.py:143-144 + :128 self term), from the
+// contracted sums:  out[t][b] = (T[t][b] + sig_a[t][b] b_et + sig_b[t][b] b_ei) / N + v0[t][b]
+// with (sig_a, sig_b) = (tt, ti) for t = 0 (mention text) and (it, ii) for t = 1 (mention image).
+__global__ void __launch_bounds__(256) k_mention_input1(const float* __restrict__ T, const float* __restrict__ sig,
+                                                        const float* __restrict__ b_et, const float* __restrict__ b_ei,
+                                                        const float* __restrict__ v0, float* __restrict__ out, int B,
+                                                        int D, float inv_n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * (int64_t)B * D) return;
+  const int d = (int)(i % D);
+  const int64_t row = i / D;  // t * B + b
+  const int t = (int)(row / B);
+  const int64_t b = row - (int64_t)t * B;
+  const float sa = sig[(int64_t)(t == 0 ? 0 : 2) * B + b], sb = sig[(int64_t)(t == 0 ? 1 : 3) * B + b];
+  out[i] = (T[i] + sa * b_et[d] + sb * b_ei[d]) * inv_n + v0[i];
+}
+
+int launch_mention_input1(const float* T, const float* sig, const float* b_et, const float* b_ei, const float* v0,
+                          float* out, int B, int D, int N, hipStream_t st) {
+  if (B <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_mention_input1, dim3((unsigned)cdiv(2 * (int64_t)B * D, 256)), dim3(256), 0, st, T, sig, b_et,
+                     b_ei, v0, out, B, D, 1.0f / (float)N);
+  DRIN_CHECK_LAUNCH("k_mention_input1");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm + GELU of one row held in registers (model.py:128)
+template <int DV>
+__device__ __forceinline__ Row<DV> ln_gelu_row(const Row<DV>& h, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, int lane, int D4, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
+  const float inv_d = 1.0f / (float)(D4 * 4);
+  const float mu = wave_sum(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      const float dx = h.v[j].x - mu, dy = h.v[j].y - mu, dz = h.v[j].z - mu, dw = h.v[j].w - mu;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+  Row<DV> y;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
+      y.v[j].x = gelu_erf((h.v[j].x - mu) * rstd * g.x + bt.x);
+      y.v[j].y = gelu_erf((h.v[j].y - mu) * rstd * g.y + bt.y);
+      y.v[j].z = gelu_erf((h.v[j].z - mu) * rstd * g.z + bt.z);
+      y.v[j].w = gelu_erf((h.v[j].w - mu) * rstd * g.w + bt.w);
+    } else {
+      y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  return y;
+}
+
+// out = base + w1 u1 + w2 u2 + c
+template <int DV>
+__device__ __forceinline__ Row<DV> combine_rows(const Row<DV>& base, float w1, const Row<DV>& u1, float w2,
+                                                const Row<DV>& u2, const Row<DV>& c) {
+  Row<DV> r;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) r.v[j] = fma4(w1, u1.v[j], fma4(w2, u2.v[j], base.v[j] + c.v[j]));
+  return r;
+}
+
+// Layer-1 entity vertices from the folded contractions (grid (chunks, B), 256 threads):
+//   et1[p] = gelu(LN(Hraw_t[p] + e_tt hm_t[b] + e_it hm_i[b] + c_t))          -> written (layer-2 GEMM operand)
+//   ei1[p] = gelu(LN(Hraw_i[p] + e_ti hm_t[b] + e_ii hm_i[b] + c_i))          -> registers only
+// and the layer-2 mention aggregates  S2_t[b] = sum_n e1_tt et1,  S2_i[b] = sum_n e1_ti ei1  per chunk.
+template <int DV>
+__global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
+  __shared__ float l_red[2 * DV * 256];
+  const int D4 = a.D4, D = D4 * 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.y;
+  const int64_t M = (int64_t)a.B * a.N;
+  const int per = (a.N + a.chunks - 1) / a.chunks;
+  const int n_begin = blockIdx.x * per, n_end = min(a.N, n_begin + per);
+  const Row<DV> hm_t = load_row<DV>(a.hm + b * a.ldhm, lane, D4);
+  const Row<DV> hm_i = load_row<DV>(a.hm + ((int64_t)a.B + b) * a.ldhm, lane, D4);
+  const Row<DV> c_t = load_row<DV>(a.c_t, lane, D4), c_i = load_row<DV>(a.c_i, lane, D4);
+  Row<DV> S_t = zero_row<DV>(), S_i = zero_row<DV>();
+  for (int n = n_begin + wave; n < n_end; n += 4) {
+    const int64_t p = b * a.N + n;
+    const Row<DV> ht = load_row<DV>(a.h_text + p * D, lane, D4);
+    const Row<DV> hi = load_row<DV>(a.h_image + p * D, lane, D4);
+    const float e_tt = a.e0m[p], e_ti = a.e0m[M + p], e_it = a.e0m[2 * M + p], e_ii = a.e0m[3 * M + p];
+    const Row<DV> et1 = ln_gelu_row<DV>(combine_rows<DV>(ht, e_tt, hm_t, e_it, hm_i, c_t), a.gamma, a.beta, lane, D4, a.ln_eps);
+    const Row<DV> ei1 = ln_gelu_row<DV>(combine_rows<DV>(hi, e_ti, hm_t, e_ii, hm_i, c_i), a.gamma, a.beta, lane, D4, a.ln_eps);
+    store_row<DV>(a.et1 + p * D, et1, lane, D4);
+    axpy_row<DV>(S_t, a.e1m[p], et1);
+    axpy_row<DV>(S_i, a.e1m[M + p], ei1);
+  }
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        float* p0 = l_red + (j * 64 + lane) * 4;
+        float* p1 = l_red + DV * 256 + (j * 64 + lane) * 4;
+        st4(p0, w == 0 ? S_t.v[j] : ld4(p0) + S_t.v[j]);
+        st4(p1, w == 0 ? S_i.v[j] : ld4(p1) + S_i.v[j]);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = a.s2_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D);
+  for (int i = threadIdx.x; i < 2 * D4; i += 256) {
+    const int which = i / D4, c4 = i - which * D4;
+    st4(out + which * D + c4 * 4, ld4(l_red + which * DV * 256 + c4 * 4));
+  }
+}
+
+int launch_pair_layer1(const PairArgs& a, hipStream_t st) {
+  if (a.B <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  if (a.D4 <= 64)
+    hipLaunchKernelGGL(k_pair_layer1<1>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 <= 192)
+    hipLaunchKernelGGL(k_pair_layer1<3>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else {
+    set_error("pair_layer1: D=%d outside the built instantiations", a.D4 * 4);
+    return DRIN_E_UNSUPPORTED;
+  }
+  DRIN_CHECK_LAUNCH("k_pair_layer1");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// W_h input of the layer-2 mention-text vertex: out[b] = (sum_chunks (S2_t + S2_i)) / N + mt1[b]
+__global__ void __launch_bounds__(256) k_mention_input2(const float* __restrict__ part, const float* __restrict__ mt1,
+                                                        float* __restrict__ out, int D, int chunks, float inv_n) {
+  const int64_t b = blockIdx.y;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float st = 0.f, si = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float* p = part + (b * chunks + c) * (int64_t)(2 * D);
+    st += p[d];
+    si += p[D + d];
+  }
+  out[b * D + d] = (st * inv_n + si * inv_n) + mt1[b * D + d];
+}
+
+int launch_mention_input2(const float* part, const float* mt1, float* out, int B, int D, int N, int chunks,
+                          hipStream_t st) {
+  if (B <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_mention_input2, dim3((unsigned)cdiv(D, 256), (unsigned)B), dim3(256), 0, st, part, mt1, out, D,
+                     chunks, 1.0f / (float)N);
+  DRIN_CHECK_LAUNCH("k_mention_input2");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer-2 entity-text vertex and the score, one wave per pair (model.py:128 for et'', :207-209):
+//   et2 = gelu(LN(H2raw[p] + e1_tt hm2_t[b] + e1_it hm2_i[b] + b_h2)),  score[p] = cos(mt2[b], et2)
+template <int DV>
+__global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
+  const int64_t M = (int64_t)a.B * a.N;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= M) return;
+  const int lane = threadIdx.x & 63, D4 = a.D4, D = D4 * 4;
+  const int64_t b = p / a.N;
+  const Row<DV> h = load_row<DV>(a.h2 + p * D, lane, D4);
+  const Row<DV> hm_t = load_row<DV>(a.hm2 + b * D, lane, D4);
+  const Row<DV> hm_i = load_row<DV>(a.hm2 + ((int64_t)a.B + b) * D, lane, D4);
+  const Row<DV> bias = load_row<DV>(a.b_h2, lane, D4);
+  const Row<DV> et2 = ln_gelu_row<DV>(combine_rows<DV>(h, a.e1m[p], hm_t, a.e1m[2 * M + p], hm_i, bias), a.gamma, a.beta,
+                                      lane, D4, a.ln_eps);
+  const Row<DV> mt2 = load_row<DV>(a.mt2 + b * D, lane, D4);
+  const float xy = wave_sum(dot_rows<DV>(mt2, et2));
+  const float xx = wave_sum(dot_rows<DV>(mt2, mt2));
+  const float yy = wave_sum(dot_rows<DV>(et2, et2));
+  if (lane == 0) a.scores[p] = cosine_from_sums(xy, xx, yy, a.cos_eps);
+}
+
+int launch_pair_final(const FinalArgs& a, hipStream_t st) {
+  const int64_t M = (int64_t)a.B * a.N;
+  if (M <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  if (a.D4 <= 64)
+    hipLaunchKernelGGL(k_pair_final<1>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, st, a);
+  else if (a.D4 <= 192)
+    hipLaunchKernelGGL(k_pair_final<3>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, st, a);
+  else {
+    set_error("pair_final: D=%d outside the built instantiations", a.D4 * 4);
+    return DRIN_E_UNSUPPORTED;
+  }
+  DRIN_CHECK_LAUNCH("k_pair_final");
+  return DRIN_OK;
+}
+
+}  // namespace drin

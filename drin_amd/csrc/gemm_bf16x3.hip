@@ -1,0 +1,222 @@
+// fp32-equivalent GEMM on the bf16 matrix cores ("bf16x3"): y[m, n] = sum_k x[m, k] w[n, k] + bias[n].
+//
+// Every fp32 operand is split on the fly into two bf16 numbers, v = hi + lo (+ <= 2^-17 |v|), and
+// the product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16: three MFMAs at the bf16 rate (16x the fp32 MFMA rate) instead of eight
+// fp32 MFMAs, i.e. 5.3x fewer matrix-core cycles per contraction.  bf16 x bf16 products are exact in
+// fp32, so the only error is the dropped lo*lo term and the split residue: ~1e-5 relative per
+// product with random sign, which measures as ~1e-6 on the final scores (75x inside the 1e-4
+// parity bar; tests/test_gpu_parity.py pins it).
+//
+// Tile 256 x 256 x 32, 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns 128 x 64 = 4 x 2 MFMA
+// tiles (128 accumulator VGPRs).  At the bf16 rate a 128 x 128 tile would need > 30 TB/s from L2;
+// 256 x 256 needs ~13 TB/s.  LDS: per buffer four planes (A hi, A lo, B hi, B lo) of 256 rows x 64 B
+// = 64 KiB, two buffers = 128 KiB -> one workgroup per CU, two waves per SIMD.  Rows are 64 B
+// (32 bf16); the 16-byte chunk index is XOR-swizzled with (row >> 2) & 3 so that every ds_read_b128
+// lane group (rows r .. at one chunk) lands on 16 distinct bank quads.
+#include "device_utils.h"
+#include "internal.h"
+
+namespace drin {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace x3 {
+
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int THREADS = 512;
+constexpr int PLANE_BYTES = 256 * 64;         // one operand plane of one buffer
+constexpr int BUF_BYTES = 4 * PLANE_BYTES;    // A hi, A lo, B hi, B lo
+constexpr int LDS_BYTES = 2 * BUF_BYTES;      // 131072
+
+// byte offset of (row, 16-byte chunk c) inside a plane
+__device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+struct Staged {
+  float4 v[4];
+};
+
+// 256 rows x 32 floats: thread t loads float4 #(t & 7) of rows (t >> 3) + 64 i.  Loads are
+// unconditional (no exec-masked branches in the K loop): rows past the end are clamped to the last
+// row - their products land in output rows / columns that are never stored - and K % 32 == 0.
+struct RowPtrs {
+  const float* p[4];
+};
+__device__ __forceinline__ RowPtrs row_ptrs(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows) {
+  const int t = threadIdx.x;
+  const int c4 = t & 7, r = t >> 3;
+  RowPtrs q;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t row = row0 + r + 64 * i;
+    row = row < rows ? row : rows - 1;
+    q.p[i] = src + row * ld + c4 * 4;
+  }
+  return q;
+}
+__device__ __forceinline__ void load_tile(Staged& s, const RowPtrs& q, int k0) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s.v[i] = ld4(q.p[i] + k0);
+}
+
+__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
+#ifdef ABL_NO_SPLIT  // ablation build: wrong numbers, timing only
+  hi = *reinterpret_cast<bf16x4*>(&v.x);
+  lo = *reinterpret_cast<bf16x4*>(&v.z);
+  return;
+#endif
+  hi[0] = (__bf16)v.x;
+  hi[1] = (__bf16)v.y;
+  hi[2] = (__bf16)v.z;
+  hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]);
+  lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]);
+  lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// registers -> (hi plane, lo plane): float4 #c4 of a row is the 8-byte half (c4 & 1) of chunk c4 >> 1
+__device__ __forceinline__ void store_tile(const Staged& s, char* __restrict__ hi_plane, char* __restrict__ lo_plane) {
+  const int t = threadIdx.x;
+  const int c4 = t & 7, r = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x4 hi, lo;
+    split4(s.v[i], hi, lo);
+    const int off = swz(r + 64 * i, c4 >> 1) + ((c4 & 1) << 3);
+    *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
+    *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+  }
+}
+
+__global__ void __launch_bounds__(THREADS, 2)
+    k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+                  const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int nkb = K / BK;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves; wave tile 128 x 64
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  Staged sa, sb;
+  const RowPtrs pa = row_ptrs(A, lda, m0, M);
+  const RowPtrs pb = row_ptrs(W, ldw, n0, N);
+  load_tile(sa, pa, 0);
+  load_tile(sb, pb, 0);
+  store_tile(sa, smem, smem + PLANE_BYTES);
+  store_tile(sb, smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES);
+  if (nkb > 1) {  // tile 1 is in flight while tile 0 is computed
+    load_tile(sa, pa, BK);
+    load_tile(sb, pb, BK);
+  }
+  __syncthreads();
+
+  // One k16 step (24 MFMAs per wave) of the current buffer.
+  auto k16_step = [&](const char* buf, int s) {
+    bf16x8 bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int off = swz(wn * 64 + j * 32 + r, 2 * s + h);
+      bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * PLANE_BYTES + off);
+      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE_BYTES + off);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = swz(wm * 128 + i * 32 + r, 2 * s + h);
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#ifdef ABL_NO_MFMA  // ablation build: keep the fragment reads alive, skip the matrix work
+        asm volatile("" ::"v"(al), "v"(ah), "v"(bh[j]), "v"(bl[j]));
+#else
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+#endif
+      }
+    }
+  };
+
+  // Steady state of iteration kb: tile kb is in LDS buffer kb & 1, tile kb+1 is in the staging
+  // registers (its loads were issued one full iteration ago).  Between the two k16 steps the staged
+  // tile is split and written to the other buffer and the loads of tile kb+2 are issued into the same
+  // registers, so every global load has a whole iteration of MFMA work to land under.
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    const char* buf = smem + cur * BUF_BYTES;
+    k16_step(buf, 0);
+    if (kb + 1 < nkb) {
+      char* nb = smem + (cur ^ 1) * BUF_BYTES;
+      store_tile(sa, nb, nb + PLANE_BYTES);
+      store_tile(sb, nb + 2 * PLANE_BYTES, nb + 3 * PLANE_BYTES);
+#ifndef ABL_NO_GLOBAL
+      if (kb + 2 < nkb) {
+        load_tile(sa, pa, (kb + 2) * BK);
+        load_tile(sb, pb, (kb + 2) * BK);
+      }
+#endif
+    }
+    k16_step(buf, 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + r;
+      if (col >= N) continue;
+      const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t row = m0 + wm * 128 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (row < M) C[row * ldc + col] = acc[i][j][v] + bv;
+      }
+    }
+}
+
+}  // namespace x3
+
+int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+                          int64_t ldy, int64_t M, int N, int K, hipStream_t st) {
+  if (M <= 0 || N <= 0) return DRIN_OK;
+  if ((K % x3::BK) || K <= 0)  // odd reduction lengths take the exact fp32 kernel (guarded loads)
+    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, M, N, K, false, DRIN_PREC_F32, st);
+  if ((ldx % 4) || (ldw % 4) || !aligned16(x) || !aligned16(w)) {
+    set_error("gemm_nt_bf16x3: leading dimensions must be multiples of 4, operands 16-byte aligned");
+    return DRIN_E_ALIGN;
+  }
+  const int64_t mt = cdiv(M, x3::BM);
+  if (mt > 65535) {
+    set_error("gemm_nt_bf16x3: %lld row tiles exceed the grid limit; split the batch", (long long)mt);
+    return DRIN_E_SHAPE;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3::k_gemm_bf16x3),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3::LDS_BYTES);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16x3)");
+    attr_done = true;
+  }
+  dim3 grid((unsigned)cdiv(N, x3::BN), (unsigned)mt);
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  hipLaunchKernelGGL(x3::k_gemm_bf16x3, grid, dim3(x3::THREADS), x3::LDS_BYTES, st, x, ldx, w, ldw, bias, y, ldy, M, N,
+                     K);
+  DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
+  return DRIN_OK;
+}
+
+}  // namespace drin

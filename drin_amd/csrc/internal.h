@@ -57,6 +57,9 @@ int launch_scale_div(const float* in, float* out, int64_t n, float mul, float di
 // y[m, n] (+)= sum_k x[m, k] * w[n, k] + bias[n];  x row stride ldx, w row stride ldw, y row stride ldy
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                    int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st);
+// same contraction, operands split into bf16 hi + lo, three bf16 MFMAs, fp32 accumulate (gemm_bf16x3.hip)
+int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+                          int64_t ldy, int64_t M, int N, int K, hipStream_t st);
 // y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
                    int K, bool accumulate, int precision, hipStream_t st);

@@ -174,17 +174,47 @@ class _Call:
         return torch.empty(max(n, 16), dtype=torch.uint8, device=self.device)
 
 
+class _Prepared:
+    """Weight-only products of the fused inference path (drin_prepare), cached per weight version."""
+
+    def __init__(self):
+        self.key = None
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, call: "_Call", params: Sequence[torch.Tensor], pc) -> torch.Tensor:
+        key = (call.cfg.embed_dim, call.cfg.image_dim, call.cfg.dynamic_edges) + tuple((p.data_ptr(), p._version) for p in params)
+        if key != self.key or self.buf is None or self.buf.device != call.device:
+            lib = _lib.load()
+            n = lib.drin_prepared_bytes(C.byref(call.cfg))
+            self.buf = torch.empty(n, dtype=torch.uint8, device=call.device)
+            stream = torch.cuda.current_stream(call.device).cuda_stream
+            _lib.check(lib.drin_prepare(C.byref(call.cfg), C.byref(pc), self.buf.data_ptr(), n, stream))
+            self.key = key
+        return self.buf
+
+
 class _DrinScore(torch.autograd.Function):
     """Autograd edge around drin_forward / drin_backward (loss.backward() of train.py:33-34)."""
 
     @staticmethod
-    def forward(ctx, call: _Call, *params: torch.Tensor):
+    def forward(ctx, call: _Call, prepared: Optional[_Prepared], *params: torch.Tensor):
         lib = _lib.load()
         # grad mode is already off inside Function.forward; needs_input_grad carries the caller's mode
-        training = any(ctx.needs_input_grad[1:])
+        training = any(ctx.needs_input_grad[2:])
+        versions = params
         params = tuple(p.detach().contiguous() for p in params)
         pc = _lib.DrinParamsC()
         _fill_params(pc, params)
+        if not training and prepared is not None and lib.drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
+            # inference: fused two-layer path on weights folded once per weight version
+            pbuf = prepared.get(call, versions, pc)
+            n = lib.drin_fused_workspace_bytes(C.byref(call.cfg))
+            ws = torch.empty(max(n, 16), dtype=torch.uint8, device=call.device)
+            scores = torch.empty(call.B, call.N, dtype=torch.float32, device=call.device)
+            stream = torch.cuda.current_stream(call.device).cuda_stream
+            _lib.check(lib.drin_forward_prepared(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), pbuf.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), scores.data_ptr(), stream))
+            return scores
         ws = call.workspace(training)
         scores = torch.empty(call.B, call.N, dtype=torch.float32, device=call.device)
         stream = torch.cuda.current_stream(call.device).cuda_stream
@@ -212,23 +242,26 @@ class _DrinScore(torch.autograd.Function):
         for l in dead_layers:
             for j in (2, 3, 4, 5):
                 out[8 + 8 * l + j] = None
-        return (None, *out)
+        return (None, None, *out)
 
 
 class Model(nn.Module):
     """`model_module.Model()` of `train.py:136` (drin/model.py:156-162)."""
 
-    def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "f32"):
+    def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "f32", fused: bool = True):
+        """`precision`: "f32" (exact fp32 MFMA) or "bf16x3" (split-bf16 MFMA, fp32-equivalent);
+        `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path."""
         super().__init__()
         self.cfg = cfg or DrinConfig()
         self.cfg.validate()
-        self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[precision]
+        self._prepared = _Prepared() if fused else None
+        self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL}[precision]
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 
     def forward(self, batch: Sequence[torch.Tensor]) -> torch.Tensor:
         call = _Call(self.cfg, batch, self.precision)
-        return _DrinScore.apply(call, *_param_list(self))
+        return _DrinScore.apply(call, self._prepared, *_param_list(self))
 
     @torch.no_grad()
     def forward_traced(self, batch: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -46,7 +46,9 @@ typedef enum {
 typedef enum {
   DRIN_PREC_F32 = 0,    /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): k-ordered fmaf chain        */
   DRIN_PREC_BF16X3 = 1, /* operands split hi+lo bf16, 3 bf16 MFMAs, fp32 accumulate (~fp32)      */
-  DRIN_PREC_BF16 = 2    /* operands rounded to bf16, fp32 accumulate (inference config 2)        */
+  DRIN_PREC_BF16 = 2,   /* operands rounded to bf16, fp32 accumulate (not built yet)             */
+  DRIN_PREC_BF16X3_ALL = 3 /* BF16X3 also for the mention-sized contractions that BF16X3 leaves on
+                              the fp32 kernel for latency reasons (used by the parity tests)      */
 } drin_precision;
 
 /* Geometry + switches of one forward.  Names follow common/args.py. */
@@ -172,6 +174,22 @@ DRIN_API int drin_forward(const drin_config* cfg, const drin_batch* batch, const
 DRIN_API int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
                   void* workspace, size_t workspace_bytes, const float* grad_scores,
                   const drin_param_grads* grads, void* stream);
+
+/* ---- fused two-layer inference path ------------------------------------------------------------
+ * Same result as drin_forward (fp32 re-association only) for the default geometry num_layers == 2,
+ * with the weight-only products folded once per weight version (csrc/fused_forward.hip):
+ *   drin_prepare           folds the weights into `prepared` (drin_prepared_bytes; caller-owned, reusable
+ *                          for every batch until a parameter changes)
+ *   drin_forward_prepared  Model.forward (drin/model.py:164-209) without autograd state
+ * drin_fused_supported returns DRIN_OK when `cfg` can take this path (else use drin_forward). */
+DRIN_API int drin_fused_supported(const drin_config* cfg);
+DRIN_API size_t drin_prepared_bytes(const drin_config* cfg);
+DRIN_API size_t drin_fused_workspace_bytes(const drin_config* cfg);
+DRIN_API int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepared, size_t prepared_bytes,
+                          void* stream);
+DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
+                                   const void* prepared, void* workspace, size_t workspace_bytes, float* scores,
+                                   void* stream);
 
 /* ---- in-process kernel timing (bench.py's roofline leg) ---------------------------------------- */
 

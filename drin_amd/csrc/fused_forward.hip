@@ -54,10 +54,9 @@ struct FusedLayout {  // workspace offsets in floats
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
-    // enough workgroups to fill 256 CUs a few times over, at least one candidate per wave
-    int ch = (int)((768 + B - 1) / (B ? B : 1));
-    const int max_ch = (int)((N + 3) / 4);
-    chunks = ch < 1 ? 1 : (ch > max_ch ? max_ch : (ch > 16 ? 16 : ch));
+    // a workgroup owns 16 consecutive candidates of one mention (4 per wave).  The chunking depends on N
+    // only - never on the batch size - so a mention scores bit-identically in any batch.
+    chunks = (int)((N + 15) / 16);
     size_t off = 0;
     auto take = [&off](size_t n) {
       const size_t o = off;

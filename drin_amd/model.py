@@ -197,10 +197,8 @@ class _DrinScore(torch.autograd.Function):
     """Autograd edge around drin_forward / drin_backward (loss.backward() of train.py:33-34)."""
 
     @staticmethod
-    def forward(ctx, call: _Call, prepared: Optional[_Prepared], *params: torch.Tensor):
+    def forward(ctx, call: _Call, prepared: Optional[_Prepared], training: bool, *params: torch.Tensor):
         lib = _lib.load()
-        # grad mode is already off inside Function.forward; needs_input_grad carries the caller's mode
-        training = any(ctx.needs_input_grad[2:])
         versions = params
         params = tuple(p.detach().contiguous() for p in params)
         pc = _lib.DrinParamsC()
@@ -242,7 +240,7 @@ class _DrinScore(torch.autograd.Function):
         for l in dead_layers:
             for j in (2, 3, 4, 5):
                 out[8 + 8 * l + j] = None
-        return (None, None, *out)
+        return (None, None, None, *out)
 
 
 class Model(nn.Module):
@@ -261,7 +259,11 @@ class Model(nn.Module):
 
     def forward(self, batch: Sequence[torch.Tensor]) -> torch.Tensor:
         call = _Call(self.cfg, batch, self.precision)
-        return _DrinScore.apply(call, self._prepared, *_param_list(self))
+        params = _param_list(self)
+        # grad mode is already off inside Function.forward (and needs_input_grad ignores no_grad), so the
+        # caller's mode is read here
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _DrinScore.apply(call, self._prepared, training, *params)
 
     @torch.no_grad()
     def forward_traced(self, batch: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -30,11 +30,18 @@ from drin_amd.config import DrinConfig, wikimel_config  # noqa: E402
 from drin_amd.model import Model  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 
-def path_flops_per_pair(D, R, layers, dynamic):
-    """FLOPs per pair the HIP path executes (dead work of the last layer removed, SURVEY.md 8a tail)."""
+def path_flops_per_pair(D, R, layers, dynamic, fused):
+    """Pair-sized contraction FLOPs per pair the HIP path executes.
+
+    generic path: dead work of the last layer removed (SURVEY.md 8a tail) -> 10.22 MFLOP;
+    fused path (csrc/fused_forward.hip): x_t C_t^T, x_i C_i^T, et' W_h2^T -> 5.51 MFLOP.
+    """
+    if fused and layers == 2:
+        return 2.0 * D * D + 2.0 * R * D + 2.0 * D * D
     f = 2.0 * D * D + 2.0 * R * D                       # W_et, W_ei
     for l in range(layers):
         last = l == layers - 1
@@ -42,6 +49,14 @@ def path_flops_per_pair(D, R, layers, dynamic):
         if dynamic and not last:
             f += 2.0 * D * D * 2                        # W_v on et, ei
     return f
+
+
+def mention_flops(D, R, fused):
+    """Mention-sized contraction FLOPs per mention (they ride in the same kernel class)."""
+    if fused:  # mt0, mi0, [hm|fu], q, T (two), W_h1 x2, hm2 x2, mt2
+        return 2.0 * D * D + 2.0 * R * D + 2 * (2.0 * D * 2 * D) + 2 * (2.0 * D * (D + R)) + 2 * (2.0 * D * D + 2.0 * R * D) \
+            + 2 * 2.0 * D * D + 2 * 2.0 * D * D + 2.0 * D * D
+    return 2.0 * D * D + 2.0 * R * D + 2 * 2.0 * D * D * 2 + 2.0 * D * D
 
 
 def algorithmic_bytes_per_pair(cfg, batch):
@@ -102,8 +117,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="wikimel", choices=["wikimel", "wikidiverse"])
-    ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 256 wikimel / 4096 wikidiverse)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 1024 wikimel / 8192 wikidiverse)")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
+                         "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
+    ap.add_argument("--generic", action="store_true", help="use the layer-by-layer path instead of the fused one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,9 +139,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
-    B = args.batch or (256 if args.workload == "wikimel" else 4096)
+    B = args.batch or (1024 if args.workload == "wikimel" else 8192)
     sd = synth.make_state_dict(cfg, 7)
-    model = Model(cfg, precision=args.precision).to(dev).eval()
+    model = Model(cfg, precision=args.precision, fused=not args.generic).to(dev).eval()
     model.load_state_dict(sd)
     batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
     N = cfg.num_candidates_model
@@ -163,30 +181,35 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])
         ms, launches = prof[dom]
         per_launch_ms = ms / max(launches, 1)
-        flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic")
+        fused = not args.generic and cfg.num_gcn_layers == 2
+        x3 = args.precision == "bf16x3"
+        flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
         bytes_pair = algorithmic_bytes_per_pair(cfg, batch)
         if dom == "gemm":
-            # mention-side Linears ride in the same kernel: 2 vertex Linears + per layer W_h (2 rows sets) + W_u
-            men_flops = B * (2.0 * D * D + 2.0 * R * D + sum(
-                2.0 * D * D * ((1 if l == cfg.num_gcn_layers - 1 else 2) + (0 if l == cfg.num_gcn_layers - 1 else 2))
-                for l in range(cfg.num_gcn_layers)))
-            work = (flops_pair * pairs_per_step + men_flops) * args.steps / max(launches, 1)   # flops per launch
+            # algorithmic FLOPs of the contraction class per launch / average launch time.  In split-bf16
+            # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
+            work = (flops_pair * pairs_per_step + mention_flops(D, R, fused) * B) * args.steps / max(launches, 1)
             achieved = work / (per_launch_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_gemm_f32", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+            peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS
+            roof = {"bound": "mfma", "kernel": "gemm class (k_gemm_x3_planes + k_gemm_f32)" if x3 else "k_gemm_f32",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                     "launches": int(launches), "avg_launch_ms": per_launch_ms}
+            if x3:
+                roof["executed_bf16_tflops"] = 3 * achieved
+                roof["executed_frac"] = 3 * achieved / peak
         else:
+            # the streaming class: compulsory input bytes of the step (+ nothing else counted) per launch
             work = bytes_pair * pairs_per_step * args.steps / max(launches, 1)
             achieved = work / (per_launch_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": None, "launches": int(launches),
-                    "avg_launch_ms": per_launch_ms}
+            roof = {"bound": "hbm", "kernel": "k_entity_stream (+ mention pooling)" if dom == "pool" else dom,
+                    "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                    "traffic": None, "launches": int(launches), "avg_launch_ms": per_launch_ms}
         value = pairs_per_step * world * args.steps / elapsed
         line = {
             "metric": "mention x candidate pairs scored/sec",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3" if x3 else "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.dataset_name}-shaped scoring forward: {N - 1}-cand (+1 answer slot), D={D}, R={R}, "
                                    f"L={cfg.max_mention_sentence_len}, P={cfg.resnet_num_region}"
                                    + (f", T={cfg.max_entity_attr_token_len} token-level entity text" if cfg.token_level_entities else ""),
@@ -195,7 +218,7 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "hbm_fraction_whole_path": bytes_pair * value / world / (PEAK_HBM_GBS * 1e9),
-            "mfma_f32_fraction_whole_path": flops_pair * value / world / (PEAK_F32_MATRIX_TFLOPS * 1e12),
+            "path": ("fused two-layer" if fused else "layer-by-layer") + ", " + args.precision,
             "algorithmic": {"bytes_per_pair": bytes_pair, "flops_per_pair_executed": flops_pair,
                             "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
         }

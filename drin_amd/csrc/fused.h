@@ -24,7 +24,11 @@ struct StreamArgs {
   const float* k_t;                  // [D]  W_v b_et + b_v
   const float* k_i;                  // [D]  W_v b_ei + b_v
   // outputs
-  float* xt_out;                     // TOKENS: pooled entity text [M, D]
+  float* xt_out;                     // TOKENS: pooled entity text [M, D] (NULL when only the planes are wanted)
+  void* xt_hi;                       // optional bf16 hi / lo planes of the entity text GEMM operand [M, D]
+  void* xt_lo;
+  void* xi_hi;                       // optional bf16 hi / lo planes of the entity image rows [M, R]
+  void* xi_lo;
   float* e0m;                        // [4][M] layer-1 edges (already multiplied by the edge switch)
   float* e1m;                        // [4][M] layer-2 edges (ditto)
   float* s_part;                     // [B][chunks][2 D + 2 R + 4]
@@ -43,7 +47,9 @@ struct PairArgs {
   const float* beta;
   const float* e0m;
   const float* e1m;
-  float* et1;            // [M, D]
+  float* et1;            // [M, D]  (NULL when only the planes are wanted)
+  void* et1_hi;          // optional bf16 hi / lo planes of et1
+  void* et1_lo;
   float* s2_part;        // [B][chunks][2 D]
   int B, N, D4, chunks, ldhm;
   float ln_eps;

@@ -27,6 +27,7 @@ namespace drin {
 
 struct Prepared {  // offsets in floats
   size_t wcat1, bcat1, ecat, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
+  size_t p_ctxt, p_cimg, p_wh2;  // bf16 (hi, lo) planes of the three pair-sized GEMM weights; lo follows hi
   void build(const drin_config& c) {
     const size_t D = c.embed_dim, R = c.image_dim;
     size_t off = 0;
@@ -44,13 +45,16 @@ struct Prepared {  // offsets in floats
     c_img = take(D * R);          // W_h1 W_ei              [D, R]
     cb_t = take(D);               // W_h1 b_et + b_h1
     cb_i = take(D);               // W_h1 b_ei + b_h1
+    p_ctxt = take(D * D);         // hi plane D*D bf16 (= D*D/2 floats) then lo plane
+    p_cimg = take(D * R);
+    p_wh2 = take(D * D);
     total = off;
   }
 };
 
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, agg1, vm1, hm2, h_text, h_image,
-      et1, s2_part, agg2, mt2, total;
+      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, total;
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
@@ -85,6 +89,10 @@ struct FusedLayout {  // workspace offsets in floats
     s2_part = take(B * chunks * 2 * D);
     agg2 = take(B * D);
     mt2 = take(B * D);
+    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL;
+    p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
+    p_xi = take(planes ? M * R : 0);
+    p_et1 = take(planes ? M * D : 0);
     total = off;
   }
 };
@@ -112,6 +120,23 @@ static int fused_supported(const drin_config* c) {
 using namespace drin;
 
 extern "C" {
+
+int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+  if (!x || !hi || !lo) {
+    set_error("drin_split_planes: NULL argument");
+    return DRIN_E_NULL;
+  }
+  return launch_split_planes(x, hi, lo, n, (hipStream_t)stream);
+}
+
+int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                           float* y, int64_t rows, int32_t n_out, int32_t k, void* stream) {
+  if (!x_hi || !x_lo || !w_hi || !w_lo || !y) {
+    set_error("drin_linear_planes_fwd: NULL argument");
+    return DRIN_E_NULL;
+  }
+  return launch_gemm_x3_planes(x_hi, x_lo, k, w_hi, w_lo, k, bias, y, n_out, rows, n_out, k, (hipStream_t)stream);
+}
 
 int drin_fused_supported(const drin_config* cfg) {
   DRIN_TRY(validate_config(cfg));
@@ -174,6 +199,16 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
   DRIN_TRY(launch_gemm_nn(L1.w_h, D, params->w_entity_image, R, pb + P.c_img, R, D, R, D, false, F32, st));
   DRIN_TRY(launch_gemm_nt(params->b_entity_text, D, L1.w_h, D, L1.b_h, pb + P.cb_t, D, 1, D, D, false, F32, st));
   DRIN_TRY(launch_gemm_nt(params->b_entity_image, D, L1.w_h, D, L1.b_h, pb + P.cb_i, D, 1, D, D, false, F32, st));
+  // bf16 hi / lo planes of the pair-sized GEMM weights (split-bf16 precision)
+  {
+    const size_t dd = (size_t)D * D, dr = (size_t)D * R;
+    __bf16* q = reinterpret_cast<__bf16*>(pb + P.p_ctxt);
+    DRIN_TRY(launch_split_planes(pb + P.c_txt, q, q + dd, dd, st));
+    q = reinterpret_cast<__bf16*>(pb + P.p_cimg);
+    DRIN_TRY(launch_split_planes(pb + P.c_img, q, q + dr, dr, st));
+    q = reinterpret_cast<__bf16*>(pb + P.p_wh2);
+    DRIN_TRY(launch_split_planes(params->layer[1].w_h, q, q + dd, dd, st));
+  }
   return DRIN_OK;
 }
 
@@ -204,6 +239,13 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   const int F32 = DRIN_PREC_F32;
   const bool dyn = cfg->dynamic_edges != 0;
   const bool tokens = cfg->entity_tokens > 0;
+  // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
+  // run on the LDS-DMA kernel of gemm_x3_planes.hip
+  const bool planes = (prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL) && (D % 32 == 0) && (R % 32 == 0);
+  __bf16* xt_hi = reinterpret_cast<__bf16*>(ws + L.p_xt);
+  __bf16* xi_hi = reinterpret_cast<__bf16*>(ws + L.p_xi);
+  __bf16* e1_hi = reinterpret_cast<__bf16*>(ws + L.p_et1);
+  const size_t MD = (size_t)M * D, MR = (size_t)M * R;
   const drin_layer_params& L1 = params->layer[0];
   const drin_layer_params& L2 = params->layer[1];
 
@@ -238,7 +280,13 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.ldq = D + R;
   sa.k_t = pb + P.k_t;
   sa.k_i = pb + P.k_i;
-  sa.xt_out = ws + L.xt;
+  sa.xt_out = planes ? nullptr : ws + L.xt;
+  if (planes) {
+    sa.xt_hi = xt_hi;
+    sa.xt_lo = xt_hi + MD;
+    sa.xi_hi = xi_hi;
+    sa.xi_lo = xi_hi + MR;
+  }
   sa.e0m = ws + L.e0m;
   sa.e1m = ws + L.e1m;
   sa.s_part = ws + L.s_part;
@@ -266,9 +314,16 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
   DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, F32, st));
   // (5) the two pair-sized layer-1 contractions on the folded weights
-  const float* x_t = tokens ? ws + L.xt : b->entity_text;
-  DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
-  DRIN_TRY(launch_gemm_nt(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, false, prec, st));
+  if (planes) {
+    const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
+    const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
+    DRIN_TRY(launch_gemm_x3_planes(xt_hi, xt_hi + MD, D, ct, ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st));
+    DRIN_TRY(launch_gemm_x3_planes(xi_hi, xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
+  } else {
+    const float* x_t = tokens ? ws + L.xt : b->entity_text;
+    DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
+    DRIN_TRY(launch_gemm_nt(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, false, prec, st));
+  }
   // (6) layer-1 entity vertices + layer-2 mention aggregates
   PairArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -282,7 +337,11 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   pa.beta = L1.ln_bias;
   pa.e0m = ws + L.e0m;
   pa.e1m = ws + L.e1m;
-  pa.et1 = ws + L.et1;
+  pa.et1 = planes ? nullptr : ws + L.et1;
+  if (planes) {
+    pa.et1_hi = e1_hi;
+    pa.et1_lo = e1_hi + MD;
+  }
   pa.s2_part = ws + L.s2_part;
   pa.B = B;
   pa.N = N;
@@ -296,7 +355,12 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
   // (8) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h_text;
-  DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
+  if (planes) {
+    const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
+    DRIN_TRY(launch_gemm_x3_planes(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, nullptr, h2, D, M, D, D, st));
+  } else {
+    DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
+  }
   FinalArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.h2 = h2;

@@ -35,6 +35,32 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const Row<V>& r
     if (c4 < n4) st4(p + c4 * 4, r.v[j]);
   }
 }
+// v = hi + lo in bf16 (operand planes of the split-bf16 GEMM, gemm_x3_planes.hip)
+template <int V>
+__device__ __forceinline__ void store_row_planes(void* __restrict__ hi, void* __restrict__ lo, int64_t row_off,
+                                                 const Row<V>& r, int lane, int n4) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  __bf16* ph = reinterpret_cast<__bf16*>(hi) + row_off;
+  __bf16* pl = reinterpret_cast<__bf16*>(lo) + row_off;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < n4) {
+      const float4 v = r.v[j];
+      bf16x4 h, l;
+      h[0] = (__bf16)v.x;
+      h[1] = (__bf16)v.y;
+      h[2] = (__bf16)v.z;
+      h[3] = (__bf16)v.w;
+      l[0] = (__bf16)(v.x - (float)h[0]);
+      l[1] = (__bf16)(v.y - (float)h[1]);
+      l[2] = (__bf16)(v.z - (float)h[2]);
+      l[3] = (__bf16)(v.w - (float)h[3]);
+      *reinterpret_cast<bf16x4*>(ph + c4 * 4) = h;
+      *reinterpret_cast<bf16x4*>(pl + c4 * 4) = l;
+    }
+  }
+}
 template <int V>
 __device__ __forceinline__ float dot_rows(const Row<V>& a, const Row<V>& b) {
   float s = 0.f;
@@ -162,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
 #pragma unroll
       for (int j = 0; j < DV; ++j)
         xt.v[j] = make_float4(acc.v[j].x / den, acc.v[j].y / den, acc.v[j].z / den, acc.v[j].w / den);
-      store_row<DV>(a.xt_out + p * D, xt, lane, D4);
+      if (a.xt_out) store_row<DV>(a.xt_out + p * D, xt, lane, D4);
       const float xy = wave_sum(dot_row_lds<DV>(cls, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(cls, cls));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     } else {
@@ -170,6 +196,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       const float xy = wave_sum(dot_row_lds<DV>(xt, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(xt, xt));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     }
+    if (a.xt_hi) store_row_planes<DV>(a.xt_hi, a.xt_lo, p * D, xt, lane, D4);
     // ---- objects: weighted pair similarity (model.py:84-92) ------------------------------------------
     float sim = 0.f, wsum = 0.f;
     for (int j = 0; j < a.Ke; ++j) {
@@ -187,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     const float ii = sim / (wsum + a.miei_eps);
     // ---- image row + edges ----------------------------------------------------------------------------
     const Row<RV> xi = load_row<RV>(a.entity_image + p * R, lane, R4);
+    if (a.xi_hi) store_row_planes<RV>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
     const float e_it = (a.miet[p] / a.clip) * a.mask[2];
@@ -432,7 +460,8 @@ __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
     const float e_tt = a.e0m[p], e_ti = a.e0m[M + p], e_it = a.e0m[2 * M + p], e_ii = a.e0m[3 * M + p];
     const Row<DV> et1 = ln_gelu_row<DV>(combine_rows<DV>(ht, e_tt, hm_t, e_it, hm_i, c_t), a.gamma, a.beta, lane, D4, a.ln_eps);
     const Row<DV> ei1 = ln_gelu_row<DV>(combine_rows<DV>(hi, e_ti, hm_t, e_ii, hm_i, c_i), a.gamma, a.beta, lane, D4, a.ln_eps);
-    store_row<DV>(a.et1 + p * D, et1, lane, D4);
+    if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
+    if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
     axpy_row<DV>(S_t, a.e1m[p], et1);
     axpy_row<DV>(S_i, a.e1m[M + p], ei1);
   }

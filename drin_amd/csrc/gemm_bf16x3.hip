@@ -25,6 +25,25 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace x3 {
 
+#ifdef X3_STAMPS  // diagnostic build: per-segment cycle sums of wave 0 of workgroup 0 (never in the shipped kernel)
+__device__ unsigned long long g_stamps[8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(i)                                   \
+  do {                                             \
+    const unsigned long long _t = stamp();         \
+    seg[i] += _t - tprev;                          \
+    tprev = _t;                                    \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 constexpr int BM = 256, BN = 256, BK = 32;
 constexpr int THREADS = 512;
 constexpr int PLANE_BYTES = 256 * 64;         // one operand plane of one buffer
@@ -154,24 +173,37 @@ __global__ void __launch_bounds__(THREADS, 2)
   // registers (its loads were issued one full iteration ago).  Between the two k16 steps the staged
   // tile is split and written to the other buffer and the loads of tile kb+2 are issued into the same
   // registers, so every global load has a whole iteration of MFMA work to land under.
+#ifdef X3_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = stamp();
+#endif
   for (int kb = 0; kb < nkb; ++kb) {
     const int cur = kb & 1;
     const char* buf = smem + cur * BUF_BYTES;
     k16_step(buf, 0);
+    STAMP(0);
     if (kb + 1 < nkb) {
       char* nb = smem + (cur ^ 1) * BUF_BYTES;
       store_tile(sa, nb, nb + PLANE_BYTES);
       store_tile(sb, nb + 2 * PLANE_BYTES, nb + 3 * PLANE_BYTES);
+      STAMP(1);
 #ifndef ABL_NO_GLOBAL
       if (kb + 2 < nkb) {
         load_tile(sa, pa, (kb + 2) * BK);
         load_tile(sb, pb, (kb + 2) * BK);
       }
 #endif
+      STAMP(2);
     }
     k16_step(buf, 1);
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
   }
+#ifdef X3_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) g_stamps[i] = seg[i];
+#endif
 
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -189,6 +221,12 @@ __global__ void __launch_bounds__(THREADS, 2)
 }
 
 }  // namespace x3
+
+#ifdef X3_STAMPS
+extern "C" __attribute__((visibility("default"))) int drin_debug_x3_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(x3::g_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st) {

@@ -60,6 +60,12 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 // same contraction, operands split into bf16 hi + lo, three bf16 MFMAs, fp32 accumulate (gemm_bf16x3.hip)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st);
+// same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
+int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
+                          int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
+                          hipStream_t st);
+// fp32 -> bf16 hi / lo planes (n % 4 == 0)
+int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream_t st);
 // y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
                    int K, bool accumulate, int precision, hipStream_t st);

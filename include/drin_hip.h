@@ -191,6 +191,14 @@ DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* bat
                                    const void* prepared, void* workspace, size_t workspace_bytes, float* scores,
                                    void* stream);
 
+/* Building blocks of the split-bf16 precision: x = hi + lo with hi, lo bf16 planes (n % 4 == 0), and the
+ * contraction y = x w^T (+ bias) on such planes by LDS-DMA + bf16 MFMA (k % 32 == 0).  Plane pointers are
+ * device pointers to bf16 arrays with the row strides of the fp32 originals. */
+DRIN_API int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
+DRIN_API int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                    const float* bias, float* y, int64_t rows, int32_t n_out, int32_t k,
+                                    void* stream);
+
 /* ---- in-process kernel timing (bench.py's roofline leg) ---------------------------------------- */
 
 /* Kernel classes the launches are attributed to. */

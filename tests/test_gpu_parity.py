@@ -73,6 +73,31 @@ def test_linear_fwd_bf16x3(rows, n_out, k):
     assert rel <= 2e-5
 
 
+@pytest.mark.parametrize("rows,n_out,k", [(7, 64, 64), (300, 768, 768), (1000, 768, 2048), (513, 258, 96)])
+def test_linear_planes_fwd(rows, n_out, k):
+    """drin_split_planes + drin_linear_planes_fwd (LDS-DMA split-bf16 GEMM) against fp64."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows + 3 * k)
+    x = torch.randn(rows, k, generator=g)
+    w = torch.randn(n_out, k, generator=g) / k ** 0.5
+    b = torch.randn(n_out, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    planes = [torch.empty(t.shape, dtype=torch.bfloat16, device=DEV) for t in (x, x, w, w)]
+    _lib.check(lib.drin_split_planes(xd.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), xd.numel(), st))
+    _lib.check(lib.drin_split_planes(wd.data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), wd.numel(), st))
+    # hi + lo reproduces the fp32 value to ~2^-17 relative
+    rec = planes[0].float() + planes[1].float()
+    assert ((rec - xd).abs() <= xd.abs() * 2.0 ** -16 + 1e-30).all()
+    y = torch.full((rows, n_out), float("nan"), device=DEV)
+    _lib.check(lib.drin_linear_planes_fwd(*(p.data_ptr() for p in planes), bd.data_ptr(), y.data_ptr(), rows, n_out, k, st))
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    scale = torch.nn.functional.linear(x.abs().double(), w.abs().double())
+    rel = ((y.cpu().double() - ref).abs() / scale).max().item()
+    print(f"planes {rows}x{n_out}x{k}: max err / sum|x||w| = {rel:.2e}")
+    assert rel <= 2e-5
+
+
 def test_linear_fwd_errors():
     lib = _lib.load()
     x = torch.zeros(4, 6, device=DEV)

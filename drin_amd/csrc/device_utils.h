@@ -7,10 +7,26 @@ namespace drin {
 
 constexpr int kWave = 64;
 
+// Sum over the 64 lanes, result in every lane.  Four DPP adds (quad swaps, half-row and row mirrors: plain
+// VALU, a few cycles each) leave every lane of a 16-lane row with the row sum; the four row sums are
+// then read as scalars.  The usual __shfl_xor butterfly compiles to six dependent ds_bpermute_b32
+// round trips through the LDS crossbar (~100+ cycles each), which is what the per-pair row kernels -
+// ten or more reductions per pair - were actually waiting on.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v = dpp_add<0x141>(v);  // row_half_mirror: lane i <-> 7 - i within 8
+  v = dpp_add<0x140>(v);  // row_mirror: lane i <-> 15 - i within 16
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -31,6 +47,18 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
 
 // exact-erf GELU (torch.nn.functional.gelu default, args.py:35)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Branch-free GELU for the fused inference row kernels: erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 6e-7 in fp32 arithmetic, i.e. <= 5e-7 on gelu - the same order as fp32 rounding of the
+// reference's own erf) with the hardware exp2 / rcp; ~14 VALU instructions against ~60 with branches
+// for the library erff.  The row kernels are VALU-bound on this function.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float poly =
+      t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = 1.0f - poly * __expf(-z * z);  // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -307,7 +307,7 @@ static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(entity_stream)");
     attr_done = true;
   }
-  KernelTimer timer(DRIN_KC_POOL, st);
+  KernelTimer timer(DRIN_KC_STREAM, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), lds, st, a);
   DRIN_CHECK_LAUNCH("k_entity_stream");
   return DRIN_OK;
@@ -415,10 +415,10 @@ __device__ __forceinline__ Row<DV> ln_gelu_row(const Row<DV>& h, const float* __
     const int c4 = lane + 64 * j;
     if (c4 < D4) {
       const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
-      y.v[j].x = gelu_erf((h.v[j].x - mu) * rstd * g.x + bt.x);
-      y.v[j].y = gelu_erf((h.v[j].y - mu) * rstd * g.y + bt.y);
-      y.v[j].z = gelu_erf((h.v[j].z - mu) * rstd * g.z + bt.z);
-      y.v[j].w = gelu_erf((h.v[j].w - mu) * rstd * g.w + bt.w);
+      y.v[j].x = gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
+      y.v[j].y = gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
+      y.v[j].z = gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
+      y.v[j].w = gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
     } else {
       y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }

@@ -207,7 +207,8 @@ typedef enum {
   DRIN_KC_POOL = 1,   /* input pooling: span / region / token means                               */
   DRIN_KC_EDGE = 2,   /* static edge builders: cosine rows, miei, scaling                          */
   DRIN_KC_GCN = 3,    /* aggregation, LayerNorm+GELU, edge update, their backward                  */
-  DRIN_KC_COUNT = 4
+  DRIN_KC_STREAM = 4, /* k_entity_stream: the single pass over the entity-side bytes (fused path)  */
+  DRIN_KC_COUNT = 5
 } drin_kernel_class;
 
 /* While a profile is open on the calling thread, every launch made from that thread is bracketed by

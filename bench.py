@@ -76,6 +76,21 @@ def algorithmic_bytes_per_pair(cfg, batch):
     return ent + men / N + 4
 
 
+def measured_traffic(kernel_prefix, B, precision, fused):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.py),
+    valid only for the configuration they were taken on (default workload); None otherwise."""
+    path = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
+    if not (os.path.exists(path) and B == 1024 and precision == "bf16x3" and fused):
+        return None
+    try:
+        for k, v in json.load(open(path))["kernels"].items():
+            if kernel_prefix in k:
+                return v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def host_cores() -> int:
     """CPU cores this process may actually use (affinity and cgroup quota, not the node's total)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -111,6 +126,61 @@ def cpu_baseline(cfg, sd, seconds=12.0):
                       f"torch {torch.get_num_threads()} threads, {el:.1f} s"}
 
 
+def bench_train(args, cfg, model, dev, world, rank, B, barrier):
+    """One optimisation step of train.py:30-56 per "step": forward (intermediates kept), TripletLoss, backward
+    through the HIP kernels, one RCCL all-reduce of the flat gradient bucket (world > 1), Adam."""
+    from drin_amd.metrics import TripletLoss
+    from drin_amd.train import GradBucket
+
+    model.train()
+    full = synth.make_device_batch(cfg, B, 200 + rank, dev)
+    batch, y = full[:14], full[14]
+    loss_fn = TripletLoss(cfg.triplet_margin)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate)
+    bucket = GradBucket(list(model.parameters()))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(y, model(batch))
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    _lib.profile_begin(1 << 16)
+    for _ in range(args.steps):
+        step()
+    prof = _lib.profile_end()
+    if rank == 0:
+        N = cfg.num_candidates_model
+        print(json.dumps({
+            "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)",
+            "value": B * N * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)",
+                       "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "final_loss": float(loss)}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +192,9 @@ def main():
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
                          "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
     ap.add_argument("--generic", action="store_true", help="use the layer-by-layer path instead of the fused one")
+    ap.add_argument("--mode", default="score", choices=["score", "train"],
+                    help="score: the scoring forward (headline metric); train: forward + TripletLoss + backward + "
+                         "gradient all-reduce + Adam step (BASELINE configs 3-4), reported under the same unit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,7 +212,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
-    B = args.batch or (1024 if args.workload == "wikimel" else 8192)
+    B = args.batch or ((1024 if args.workload == "wikimel" else 8192) if args.mode == "score" else 64)
     sd = synth.make_state_dict(cfg, 7)
     model = Model(cfg, precision=args.precision, fused=not args.generic).to(dev).eval()
     model.load_state_dict(sd)
@@ -152,6 +225,9 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    if args.mode == "train":
+        return bench_train(args, cfg, model, dev, world, rank, B, barrier)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -203,7 +279,8 @@ def main():
             achieved = work / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_entity_stream" if dom == "stream" else dom,
                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": None, "launches": int(launches), "avg_launch_ms": per_launch_ms}
+                    "traffic": measured_traffic("k_entity_stream", B, args.precision, fused) if dom == "stream" else None,
+                    "launches": int(launches), "avg_launch_ms": per_launch_ms}
         value = pairs_per_step * world * args.steps / elapsed
         line = {
             "metric": "mention x candidate pairs scored/sec",

@@ -1,0 +1,31 @@
+"""Turn the rocprofv3 --pmc passes of bench.py into profiles/<tag>_hbm_traffic.json.
+
+Run on the GPU box, FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots, MI355X_MICROARCH.md
+'rocprofv3 PMC slots'):
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    python3 tools/collect_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r1_hbm_traffic.json
+Corrections (MI355X_MICROARCH.md, HBM): the counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
+the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-byte
+streaming stores.
+"""
+import collections, csv, glob, json, sys
+
+def per_kernel(d):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "drin" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    fb = 2.0 * fetch.get(k, 0.0) * 1024.0
+    wb = write.get(k, 0.0) * 1024.0
+    out[k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean per launch",
+           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (defaults: wikimel B=1024 bf16x3 fused)",
+           "kernels": out}, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out.get("void drin::k_entity_stream<3, 8, true>", {}), indent=1))

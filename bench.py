@@ -62,6 +62,10 @@ def mention_flops(D, R, fused):
 def algorithmic_bytes_per_pair(cfg, batch):
     """Compulsory input bytes per pair: entity-side rows that are actually needed
     + the mention-side bytes amortised over the N candidates + the 4-byte score."""
+    if not isinstance(batch, (list, tuple)):          # table form: 8-byte candidate index + the gathered pooled row
+        D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
+        men = 3 * D * 4 + cfg.resnet_num_region * R * 4 + cfg.object_topk_mention * (R + 1) * 4 + 16
+        return 8 + D * 4 + R * 4 + cfg.object_topk_entity * (R + 1) * 4 + 8 + men / N + 4
     B, N = batch[0].shape[0], cfg.num_candidates_model
     D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
     if cfg.token_level_entities:
@@ -186,7 +190,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="wikimel", choices=["wikimel", "wikidiverse"])
+    ap.add_argument("--workload", default="wikimel", choices=["wikimel", "wikidiverse", "table"],
+                    help="wikimel: 100-cand token-level (headline); wikidiverse: 10-cand pooled; table: BASELINE config 5 - "
+                         "1000 candidates per mention gathered on the device from a table of --entities random entities")
+    ap.add_argument("--entities", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 1024 wikimel / 8192 wikidiverse)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
@@ -211,13 +218,29 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
-    B = args.batch or ((1024 if args.workload == "wikimel" else 8192) if args.mode == "score" else 64)
+    if args.workload == "table":
+        cfg = DrinConfig(num_candidates_data=1000)       # pooled-text entity rows: 19.7 KB per entity in fp32
+    else:
+        cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
+    default_b = {"wikimel": 1024, "wikidiverse": 8192, "table": 256}[args.workload]
+    B = args.batch or (default_b if args.mode == "score" else 64)
     sd = synth.make_state_dict(cfg, 7)
     model = Model(cfg, precision=args.precision, fused=not args.generic).to(dev).eval()
     model.load_state_dict(sd)
-    batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
     N = cfg.num_candidates_model
+    if args.workload == "table":
+        from drin_amd.model import EntityTable, IndexedBatch
+        E, D, R = args.entities, cfg.bert_embed_dim, cfg.resnet_embed_dim
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        table = EntityTable(torch.randn(E, D, device=dev, generator=g), None, torch.randn(E, R, device=dev, generator=g),
+                            torch.randn(E, 1, R, device=dev, generator=g), torch.rand(E, 1, device=dev, generator=g))
+        men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 100 + rank, dev)
+        cand = torch.randint(0, E, (B, N), device=dev, generator=g)
+        sims = 20.0 + 5.0 * torch.randn(2, B, N, device=dev, generator=g)
+        batch = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+    else:
+        batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
     pairs_per_step = B * N
 
     def barrier():

@@ -31,7 +31,7 @@ class DrinConfigC(C.Structure):
         ("entity_image_inner", C.c_int32), ("entity_object_inner", C.c_int32), ("num_layers", C.c_int32),
         ("dynamic_edges", C.c_int32), ("edge_enabled", C.c_float * 4), ("layer_norm_eps", C.c_float),
         ("cosine_eps", C.c_float), ("miei_eps", C.c_float), ("clip_scale", C.c_float), ("precision", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("num_entities", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -41,7 +41,7 @@ class DrinBatchC(C.Structure):
         ("mention_image", C.c_void_p), ("mention_object", C.c_void_p), ("mention_object_score", C.c_void_p),
         ("entity_text", C.c_void_p), ("entity_text_mask", C.c_void_p), ("entity_image", C.c_void_p),
         ("entity_object", C.c_void_p), ("entity_object_score", C.c_void_p), ("miet_similarity", C.c_void_p),
-        ("mtei_similarity", C.c_void_p),
+        ("mtei_similarity", C.c_void_p), ("entity_index", C.c_void_p),
     ]
 
 

@@ -346,6 +346,10 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
   DRIN_TRY(validate_params(cfg, params));
+  if (batch->entity_index) {
+    set_error("drin_forward: entity_index (table form) is taken by drin_forward_prepared only; pass gathered tensors");
+    return DRIN_E_UNSUPPORTED;
+  }
   if (!scores) {
     set_error("scores is NULL");
     return DRIN_E_NULL;

@@ -13,6 +13,8 @@ struct StreamArgs {
   const float* entity_image;         // [M, R]
   const float* entity_object;        // [M, Ke, R]
   const float* entity_object_score;  // [M, Ke]
+  const int64_t* entity_index;       // optional [M]: entity_* above are tables, pair p reads row entity_index[p]
+  int64_t num_entities;
   const float* miet;                 // [M]
   const float* mtei;                 // [M]
   // mention side

@@ -242,6 +242,17 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
   // run on the LDS-DMA kernel of gemm_x3_planes.hip
   const bool planes = (prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL) && (D % 32 == 0) && (R % 32 == 0);
+  const bool indexed = b->entity_index != nullptr;
+  if (indexed && cfg->num_entities <= 0) {
+    set_error("drin_forward_prepared: entity_index given but cfg.num_entities = %d", cfg->num_entities);
+    return DRIN_E_SHAPE;
+  }
+  if (indexed && !planes) {
+    // the fp32 contractions read the entity rows in place; with a table they need gathered copies
+    set_error("drin_forward_prepared: entity_index needs the split-bf16 precision (the stream kernel gathers the "
+              "GEMM operands as planes); gather on the caller side for DRIN_PREC_F32");
+    return DRIN_E_UNSUPPORTED;
+  }
   __bf16* xt_hi = reinterpret_cast<__bf16*>(ws + L.p_xt);
   __bf16* xi_hi = reinterpret_cast<__bf16*>(ws + L.p_xi);
   __bf16* e1_hi = reinterpret_cast<__bf16*>(ws + L.p_et1);
@@ -269,6 +280,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.entity_image = b->entity_image;
   sa.entity_object = b->entity_object;
   sa.entity_object_score = b->entity_object_score;
+  sa.entity_index = b->entity_index;
+  sa.num_entities = cfg->num_entities;
   sa.miet = b->miet_similarity;
   sa.mtei = b->mtei_similarity;
   sa.span_mean = ws + L.span_mean;

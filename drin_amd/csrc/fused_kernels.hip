@@ -156,18 +156,24 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
 
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
+    // entity row: the pair itself, or a row of the entity tables (on-device form of data.py:87-93)
+    int64_t e = p;
+    if (a.entity_index) {
+      e = a.entity_index[p];
+      e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
+    }
     // ---- text: CLS / pooler cosine (model.py:71-76) and token mean (ghmfc.py:245-249) ---------------
     Row<DV> xt;
     float tt;
     if (TOKENS) {
       const int T = a.T;
       int cnt = 0;
-      for (int t = lane; t < T; t += 64) cnt += (int)a.entity_mask[p * T + t];
+      for (int t = lane; t < T; t += 64) cnt += (int)a.entity_mask[e * T + t];
       cnt = (int)wave_sum((float)cnt);
       int stop = cnt - 1;
       if (stop < 0) stop += T;
       stop = stop < 0 ? 0 : (stop > T ? T : stop);
-      const float* base = a.entity_text + p * (int64_t)T * D;
+      const float* base = a.entity_text + e * (int64_t)T * D;
       const Row<DV> cls = load_row<DV>(base, lane, D4);
       Row<DV> acc = zero_row<DV>();
       int t = 1;
@@ -192,7 +198,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       const float xy = wave_sum(dot_row_lds<DV>(cls, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(cls, cls));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     } else {
-      xt = load_row<DV>(a.entity_text + p * D, lane, D4);
+      xt = load_row<DV>(a.entity_text + e * D, lane, D4);
       const float xy = wave_sum(dot_row_lds<DV>(xt, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(xt, xt));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     }
@@ -200,9 +206,9 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // ---- objects: weighted pair similarity (model.py:84-92) ------------------------------------------
     float sim = 0.f, wsum = 0.f;
     for (int j = 0; j < a.Ke; ++j) {
-      const Row<RV> eo = load_row<RV>(a.entity_object + (p * a.Ke + j) * R, lane, R4);
+      const Row<RV> eo = load_row<RV>(a.entity_object + (e * a.Ke + j) * R, lane, R4);
       const float ny = fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps);
-      const float es = a.entity_object_score[p * a.Ke + j];
+      const float es = a.entity_object_score[e * a.Ke + j];
       for (int i = 0; i < a.Km; ++i) {
         const float xy = wave_sum(dot_row_lds<RV>(eo, l_mobj + i * R, lane, R4));
         const float w = a.mscore[b * a.Km + i] * es;
@@ -213,7 +219,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // the reference sums i-major, j-minor; with Ke = 1 (both datasets) the orders coincide
     const float ii = sim / (wsum + a.miei_eps);
     // ---- image row + edges ----------------------------------------------------------------------------
-    const Row<RV> xi = load_row<RV>(a.entity_image + p * R, lane, R4);
+    const Row<RV> xi = load_row<RV>(a.entity_image + e * R, lane, R4);
     if (a.xi_hi) store_row_planes<RV>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];

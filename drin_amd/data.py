@@ -128,6 +128,55 @@ def create_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int] = None
     return loaders
 
 
+class IndexedMELData(MELData):
+    """WikiMEL split in table form: `__getitem__` returns the seven mention-side tensors,
+    the candidate rows of the entity tables `[N]` int64 (what `qid2idx` maps the QIDs to, data.py:88), the two
+    similarity rows and the answer - 11 items, ~1 MB per mention instead of 22 MB.  The tables themselves go to
+    the device once (`load_entity_table`) and are gathered inside the HIP stream kernel."""
+
+    def __getitem__(self, idx):
+        t = self._t
+        rows = np.asarray([self.qid2idx[str(q)] for q in self.entity_qid[idx]], dtype=np.int64)
+        return (
+            t(self.mention_text_feature[idx]), t(self.mention_text_mask[idx]),
+            t(self.mention_start_pos[idx]) + 1, t(self.mention_end_pos[idx]) + 1,
+            t(self.mention_image_feature[idx]), t(self.mention_object_feature[idx]), t(self.mention_object_score[idx]),
+            torch.from_numpy(rows), t(self.miet_similarity[idx]), t(self.mtei_similarity[idx]),
+            t(self.onehot[self.answer[idx]]),
+        )
+
+
+def load_entity_table(cfg: DrinConfig, root: str, device="cpu", entity_mmap: Optional[str] = None):
+    """The five WikiMEL entity tables of `drin/data.py:163-175` as a `drin_amd.model.EntityTable` on `device`."""
+    from .model import EntityTable
+
+    p = lambda name: os.path.join(root, name)  # noqa: E731
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    return EntityTable(up(_load(p("entity-attr-feature.npy"), entity_mmap)), up(_load(p("entity-attr-mask.npy"))),
+                       up(_load(p("entity-image-feature_all.npy"), entity_mmap)),
+                       up(_load(p("entity-object-feature_all.npy"), entity_mmap)),
+                       up(_load(p("entity-object-score_all.npy"))))
+
+
+def create_indexed_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int] = None, num_workers: int = 0,
+                            rank: int = 0, world_size: int = 1, mention_mmap: Optional[str] = None) -> List[DataLoader]:
+    """[train, valid, test] loaders of `IndexedMELData` (WikiMEL only)."""
+    if cfg.dataset_name != "wikimel":
+        raise ValueError("the table form exists for the wikimel layout only (drin/data.py:40-46)")
+    N = cfg.num_candidates_model
+    onehot = np.concatenate([np.eye(N - 1, dtype=np.uint8), np.zeros((1, N - 1), dtype=np.uint8)], 0)
+    empty = np.zeros((0,), dtype=np.float32)
+    shared = {"onehot": onehot, "entity_text": empty, "entity_text_mask": empty, "entity_image": empty,
+              "entity_object": empty, "entity_object_score": empty}
+    loaders = []
+    for s in SPLITS:
+        ds = IndexedMELData(cfg, root, s, shared, mention_mmap)
+        shuffle = s == "train" and cfg.shuffle_train_data
+        sampler = ShardSampler(len(ds), rank, world_size, shuffle, cfg.seed) if (world_size > 1 or shuffle) else None
+        loaders.append(DataLoader(ds, batch_size or cfg.batch_size, shuffle=False, sampler=sampler, num_workers=num_workers))
+    return loaders
+
+
 class ShardSampler(torch.utils.data.Sampler):
     """Rank r of w draws indices perm[r::w] of one permutation shared by all ranks (re-seeded per epoch)."""
 

@@ -87,10 +87,49 @@ def _fill_params(struct, tensors: Sequence[Optional[torch.Tensor]]) -> None:
             setattr(struct.layer[l], n, _ptr(tensors[8 + 8 * l + j]))
 
 
+class EntityTable:
+    """The WikiMEL entity tables of `drin/data.py:163-175`, resident on the device: text features
+    `[E, T, D]` (+ mask `[E, T]`) or pooled `[E, D]`, image `[E, (1,) R]`, object `[E, Ke, (1,) R]`, object
+    score `[E, Ke]`.  With it a batch carries candidate INDICES instead of 22 MB of gathered features."""
+
+    def __init__(self, text, mask, image, object, object_score):
+        self.text, self.mask, self.image, self.object, self.object_score = text, mask, image, object, object_score
+
+    @property
+    def num_entities(self) -> int:
+        return self.text.shape[0]
+
+    def to(self, device) -> "EntityTable":
+        mv = lambda t: None if t is None else t.to(device)  # noqa: E731
+        return EntityTable(mv(self.text), mv(self.mask), mv(self.image), mv(self.object), mv(self.object_score))
+
+    def gather(self, index: torch.Tensor):
+        """Per-pair tensors exactly as `MELData.__getitem__` + collate would deliver them (data.py:87-93)."""
+        mask = self.mask[index] if self.mask is not None else torch.zeros(index.shape[0], dtype=torch.int64, device=index.device)
+        return [self.text[index], mask, self.image[index], self.object[index], self.object_score[index]]
+
+
+class IndexedBatch:
+    """A batch in table form: the seven mention-side tensors of the 14-sequence, the device-resident
+    `EntityTable`, `candidates [B, N]` int64 rows of it, the two CLIP similarity matrices `[B, N]`."""
+
+    def __init__(self, mention: Sequence[torch.Tensor], table: EntityTable, candidates: torch.Tensor,
+                 miet_similarity: torch.Tensor, mtei_similarity: torch.Tensor):
+        if len(mention) != 7:
+            raise ValueError("mention part must be the first 7 tensors of the 14-sequence (drin/data.py:110-117)")
+        self.mention, self.table, self.candidates = list(mention), table, candidates
+        self.miet_similarity, self.mtei_similarity = miet_similarity, mtei_similarity
+
+    def gathered(self) -> List[torch.Tensor]:
+        """The equivalent 14-sequence (entity rows materialised with torch indexing)."""
+        return self.mention + self.table.gather(self.candidates) + [self.miet_similarity, self.mtei_similarity]
+
+
 class _Call:
     """One forward's C structs; keeps the tensors they point into alive."""
 
-    def __init__(self, cfg: DrinConfig, batch: Sequence[torch.Tensor], precision: int):
+    def __init__(self, cfg: DrinConfig, batch: Sequence[torch.Tensor], precision: int,
+                 entity_index: Optional[torch.Tensor] = None):
         if len(batch) not in (14, 15):
             raise ValueError(f"batch must be the 14-sequence of drin/data.py:110-126 (got {len(batch)} items)")
         (mtf, _mask, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei) = batch[:14]
@@ -112,11 +151,24 @@ class _Call:
         B, L, D = mtf.shape
         N = cfg.num_candidates_model
         R = mimg.shape[-1]
+        table = entity_index is not None
+        if table:
+            # entity tensors are tables [E, ...]: give them the per-pair ranks by viewing E as (E, 1)
+            E = etf.shape[0]
+            entity_index = i64(entity_index)
+            if tuple(entity_index.shape) != (B, N):
+                raise ValueError(f"candidates has shape {tuple(entity_index.shape)}, expected {(B, N)}")
+            etf, eimg, eobj, escore = (t.unsqueeze(1) for t in (etf, eimg, eobj, escore))
+            if emask is not None and torch.is_tensor(emask) and emask.dim() >= 2:
+                emask = emask.unsqueeze(1)
+            lead = (E, 1)
+        else:
+            lead = (B, N)
         token_level = etf.dim() == 4                                  # model.py:73-75
         if D != cfg.bert_embed_dim or R != cfg.resnet_embed_dim:
             raise ValueError(f"feature dims ({D}, {R}) do not match the config ({cfg.bert_embed_dim}, {cfg.resnet_embed_dim})")
-        if etf.shape[:2] != (B, N):
-            raise ValueError(f"entity_text_feature leads with {tuple(etf.shape[:2])}, expected {(B, N)}")
+        if tuple(etf.shape[:2]) != lead:
+            raise ValueError(f"entity_text_feature leads with {tuple(etf.shape[:2])}, expected {lead}")
         if mobj.dim() not in (3, 4) or eobj.dim() not in (4, 5) or eimg.dim() not in (3, 4):
             raise ValueError("unexpected rank for object / image features (model.py:43-44,78-83)")
         Km = mobj.shape[1]
@@ -124,7 +176,7 @@ class _Call:
         for name, t, shape in (
             ("mention_image_feature", mimg, (B, mimg.shape[1], R)),
             ("mention_object_score", mscore, (B, Km)),
-            ("entity_object_score", escore, (B, N, Ke)),
+            ("entity_object_score", escore, lead + (Ke,)),
             ("miet_similarity", miet, (B, N)),
             ("mtei_similarity", mtei, (B, N)),
             ("mention_start_pos", start, (B,)),
@@ -132,7 +184,7 @@ class _Call:
         ):
             if tuple(t.shape) != shape:
                 raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shape}")
-        if eimg.shape[0:2] != (B, N) or eobj.shape[0:2] != (B, N) or eimg.shape[-1] != R or eobj.shape[-1] != R or mobj.shape[-1] != R:
+        if tuple(eimg.shape[0:2]) != lead or tuple(eobj.shape[0:2]) != lead or eimg.shape[-1] != R or eobj.shape[-1] != R or mobj.shape[-1] != R:
             raise ValueError("entity/mention image or object feature shape mismatch")
         if token_level:
             emask = i64(emask)
@@ -140,7 +192,7 @@ class _Call:
                 raise ValueError(f"entity_text_mask has shape {tuple(emask.shape)}, expected {tuple(etf.shape[:3])}")
         else:
             emask = None
-        self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei]
+        self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei, entity_index]
         self.device = dev
         self.B, self.N, self.D = B, N, D
         c = _lib.DrinConfigC()
@@ -159,11 +211,13 @@ class _Call:
         c.layer_norm_eps, c.cosine_eps, c.miei_eps, c.clip_scale = (
             cfg.layer_norm_eps, cfg.cosine_eps, cfg.miei_eps, cfg.clip_logit_scale)
         c.precision = precision
+        c.num_entities = etf.shape[0] if table else 0
         self.cfg = c
         b = _lib.DrinBatchC()
         for name, t in zip(("mention_text", "mention_start", "mention_end", "mention_image", "mention_object",
                             "mention_object_score", "entity_text", "entity_text_mask", "entity_image",
-                            "entity_object", "entity_object_score", "miet_similarity", "mtei_similarity"), self.keep):
+                            "entity_object", "entity_object_score", "miet_similarity", "mtei_similarity",
+                            "entity_index"), self.keep):
             setattr(b, name, _ptr(t))
         self.batch = b
 
@@ -257,9 +311,23 @@ class Model(nn.Module):
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 
-    def forward(self, batch: Sequence[torch.Tensor]) -> torch.Tensor:
-        call = _Call(self.cfg, batch, self.precision)
+    def forward(self, batch) -> torch.Tensor:
         params = _param_list(self)
+        if isinstance(batch, IndexedBatch):
+            # table form: inference gathers inside the stream kernel; everything else (training,
+            # exact-fp32 precision, geometries off the fused path) gathers with torch indexing first
+            inference = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+            in_kernel = (inference and self._prepared is not None and self.cfg.num_gcn_layers == 2
+                         and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL))
+            if in_kernel:
+                t = batch.table
+                seq = batch.mention + [t.text, t.mask, t.image, t.object, t.object_score,
+                                       batch.miet_similarity, batch.mtei_similarity]
+                call = _Call(self.cfg, seq, self.precision, entity_index=batch.candidates)
+                if _lib.load().drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
+                    return _DrinScore.apply(call, self._prepared, False, *params)
+            batch = batch.gathered()
+        call = _Call(self.cfg, batch, self.precision)
         # grad mode is already off inside Function.forward (and needs_input_grad ignores no_grad), so the
         # caller's mode is read here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)

@@ -100,8 +100,11 @@ class MELRunner:
     """`MELModel` of `train.py:20-56` without Lightning."""
 
     def __init__(self, cfg: DrinConfig, model: nn.Module, device, global_batch_loss: bool = False,
-                 log: Optional[Callable[[str], None]] = None):
+                 log: Optional[Callable[[str], None]] = None, entity_table=None):
+        """`entity_table`: a device-resident `drin_amd.model.EntityTable`; the loaders then yield the 11-item
+        table-form batches of `drin_amd.data.IndexedMELData` (candidate indices instead of gathered features)."""
         self.cfg, self.model, self.device = cfg, model, torch.device(device)
+        self.entity_table = entity_table
         self.loss = TripletLoss(cfg.triplet_margin)
         self.metrics = [TopkAccuracy(k, self.device) for k in cfg.metrics_topk]
         self.bucket = GradBucket(list(model.parameters()))
@@ -115,7 +118,11 @@ class MELRunner:
         """`_forward_step` (`train.py:30-44`)."""
         batch = self._to_device(batch)
         y = batch[-1]
-        y_hat = self.model(batch[:-1])
+        if self.entity_table is not None:
+            from .model import IndexedBatch
+            y_hat = self.model(IndexedBatch(batch[:7], self.entity_table, batch[7], batch[8], batch[9]))
+        else:
+            y_hat = self.model(batch[:-1])
         if self.global_batch_loss and _world() > 1:
             world = _world()
             ys = [torch.empty_like(y) for _ in range(world)]

@@ -74,7 +74,8 @@ typedef struct {
   float miei_eps;           /* 1e-9  (model.py:92)                                                */
   float clip_scale;         /* 100   (model.py:203)                                               */
   int32_t precision;        /* drin_precision                                                     */
-  int32_t reserved[3];
+  int32_t num_entities;     /* rows of the entity TABLES when drin_batch.entity_index is set, else 0    */
+  int32_t reserved[2];
 } drin_config;
 
 /* The 14 tensors `Model.forward` unpacks (drin/model.py:165-180), device pointers.
@@ -93,6 +94,12 @@ typedef struct {
   const float* entity_object_score;   /* [B, N, Ke]                                              */
   const float* miet_similarity;       /* [B, N]  CLIP logits (model.py:178,203)                  */
   const float* mtei_similarity;       /* [B, N]                                                  */
+  /* Optional on-device form of the WikiMEL entity-table gather (drin/data.py:87-93).  When non-NULL,
+   * entity_text / entity_text_mask / entity_image / entity_object / entity_object_score are TABLES with
+   * cfg.num_entities rows ([E, T, D], [E, T], [E, (inner,) R], ...) and candidate (b, n) reads row
+   * entity_index[b, n] (clamped to [0, E-1]) instead of row b*N + n.  Taken by drin_forward_prepared;
+   * drin_forward / drin_backward need the gathered per-pair tensors. */
+  const int64_t* entity_index;        /* [B, N] or NULL                                          */
 } drin_batch;
 
 /* One GCNLayer's parameters (drin/model.py:109-119); nn.Linear layout weight[out][in]. */

@@ -444,3 +444,62 @@ def test_training_loop_on_device_tracks_cpu_oracle_loop(tmp_path):
         assert abs(a.loss - b.loss) <= 5e-4, (a, b)
         assert a.topk == pytest.approx(b.topk, abs=1e-9)
     assert hist["hip"].train[-1].loss < hist["hip"].train[0].loss
+
+
+# ---- table form: on-device entity gather (drin/data.py:87-93) -----------------------------------
+@pytest.mark.parametrize("token_level", [True, False], ids=["wikimel_tokens", "pooled_text"])
+def test_indexed_batch_matches_gathered_batch(token_level):
+    """Candidate indices into device-resident entity tables score exactly like the gathered 14-sequence: the
+    fused bf16x3 path gathers inside the stream kernel (bit-identical), every other mode gathers with torch."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = DrinConfig(dataset_name="wikimel" if token_level else "wikidiverse", num_candidates_data=20,
+                     max_entity_attr_token_len=10, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    E, B, N = 57, 6, cfg.num_candidates_model
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 71)
+    table = EntityTable(tab[7][0], tab[8][0] if token_level else None, tab[9][0], tab[10][0], tab[11][0]).to(DEV)
+    men = _to_dev(synth.make_batch(cfg, B, 72))
+    g = torch.Generator().manual_seed(3)
+    cand = torch.randint(0, E, (B, N), generator=g).to(DEV)
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    gathered = ib.gathered()
+    ref = O.forward(sd, [t.cpu() for t in gathered])
+    for precision in ("bf16x3_all", "f32"):
+        model = Model(cfg, precision=precision).to(DEV).eval()
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            a = model(ib)
+            b = model(gathered)
+        assert torch.equal(a, b), precision
+        assert (a.cpu() - ref).abs().max().item() <= 1e-5
+    # training through the table form: same gradients as through the gathered tensors
+    model = Model(cfg).to(DEV)
+    model.load_state_dict(sd)
+    model(ib).sum().backward()
+    g1 = [p.grad.clone() if p.grad is not None else None for p in model.parameters()]
+    model.zero_grad()
+    model(gathered).sum().backward()
+    for x, p in zip(g1, model.parameters()):
+        assert (x is None) == (p.grad is None)
+        if x is not None:
+            assert torch.allclose(x, p.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_indexed_loader_and_runner(tmp_path):
+    """.npy tables -> device EntityTable + index batches -> MELRunner: same losses as the gathered loader."""
+    from drin_amd.data import create_datasets, create_indexed_datasets, load_entity_table, write_synthetic_dataset
+    from drin_amd.train import MELRunner, seed_everything
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6, batch_size=4, num_epoch=1,
+                     test_epoch_interval=1, shuffle_train_data=False, metrics_topk=(1, 3), acc_correction=(0.0, 0.0, 0.0), **TINY)
+    write_synthetic_dataset(cfg, str(tmp_path), sizes=(12, 4, 4), seed=4, num_entities=30)
+    hist = {}
+    for kind in ("gathered", "indexed"):
+        seed_everything(cfg.seed)
+        model = Model(cfg).to(DEV)
+        if kind == "indexed":
+            table = load_entity_table(cfg, str(tmp_path), DEV)
+            hist[kind] = MELRunner(cfg, model, DEV, entity_table=table).fit(create_indexed_datasets(cfg, str(tmp_path)))
+        else:
+            hist[kind] = MELRunner(cfg, model, DEV).fit(create_datasets(cfg, str(tmp_path)))
+    for a, b in zip(hist["gathered"].train + hist["gathered"].test, hist["indexed"].train + hist["indexed"].test):
+        assert abs(a.loss - b.loss) <= 1e-4 and a.topk == pytest.approx(b.topk, abs=1e-9)

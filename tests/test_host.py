@@ -152,3 +152,19 @@ def test_training_loop_semantics(tmp_path):
     assert abs(l2.item() - loss.item()) < 1e-7
     for (k, a), (_, b) in zip(ref.state_dict().items(), mine.state_dict().items()):
         assert torch.allclose(a, b, atol=1e-7), k
+
+
+def test_indexed_loader_matches_gathered_loader(tmp_path):
+    """Table form: candidate rows + tables reproduce the gathered 15-tuple exactly."""
+    from drin_amd.data import create_indexed_datasets, load_entity_table
+    from drin_amd.model import IndexedBatch
+    cfg = TINY_WM.with_(shuffle_train_data=False)
+    write_synthetic_dataset(cfg, str(tmp_path), sizes=(8, 4, 4), seed=6, num_entities=25)
+    full = next(iter(create_datasets(cfg, str(tmp_path))[0]))
+    idx = next(iter(create_indexed_datasets(cfg, str(tmp_path))[0]))
+    assert len(idx) == 11 and idx[7].dtype == torch.int64 and tuple(idx[7].shape) == (4, cfg.num_candidates_model)
+    table = load_entity_table(cfg, str(tmp_path))
+    rebuilt = IndexedBatch(idx[:7], table, idx[7], idx[8], idx[9]).gathered() + [idx[10]]
+    assert len(rebuilt) == 15
+    for a, b in zip(full, rebuilt):
+        assert torch.equal(a, b)

@@ -26,7 +26,7 @@
 namespace drin {
 
 struct Prepared {  // offsets in floats
-  size_t wcat1, bcat1, ecat, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
+  size_t wcat1, bcat1, ecat, etmp, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
   size_t p_ctxt, p_cimg, p_wh2;  // bf16 (hi, lo) planes of the three pair-sized GEMM weights; lo follows hi
   void build(const drin_config& c) {
     const size_t D = c.embed_dim, R = c.image_dim;
@@ -38,7 +38,8 @@ struct Prepared {  // offsets in floats
     };
     wcat1 = take(2 * D * D);      // [W_h1; W_u1]           [2D, D]
     bcat1 = take(2 * D);          // [0; b_u1]
-    ecat = take(D * (D + R));     // [W_v1 W_et | W_v1 W_ei] [D, D + R]
+    ecat = take(D * (D + R));     // ([W_v1 W_et | W_v1 W_ei])^T  [D + R, D]  (nn.Linear layout: q = fu ecat^T)
+    etmp = take(D * (D + R));     // scratch of drin_prepare: the un-transposed product
     k_t = take(D);                // W_v1 b_et + b_v1
     k_i = take(D);                // W_v1 b_ei + b_v1
     c_txt = take(D * D);          // W_h1 W_et              [D, D]
@@ -53,7 +54,7 @@ struct Prepared {  // offsets in floats
 };
 
 struct FusedLayout {  // workspace offsets in floats
-  size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, agg1, vm1, hm2, h_text, h_image,
+  size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
       et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, total;
   int chunks;
   void build(const drin_config& c) {
@@ -80,6 +81,7 @@ struct FusedLayout {  // workspace offsets in floats
     s_img = take(2 * B * R);
     sig = take(4 * B);
     tm = take(2 * B * D);
+    tm2 = take(2 * B * D);
     agg1 = take(2 * B * D);
     vm1 = take(2 * B * D);
     hm2 = take(2 * B * D);
@@ -189,8 +191,9 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
   }
   DRIN_TRY(copy(pb + P.bcat1 + D, L1.b_u, D));
   // E = W_v1 [W_et | W_ei]   (y[m, n] = sum_k x[m, k] w[k, n])
-  DRIN_TRY(launch_gemm_nn(L1.w_v, D, params->w_entity_text, D, pb + P.ecat, D + R, D, D, D, false, F32, st));
-  DRIN_TRY(launch_gemm_nn(L1.w_v, D, params->w_entity_image, R, pb + P.ecat + D, D + R, D, R, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nn(L1.w_v, D, params->w_entity_text, D, pb + P.etmp, D + R, D, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nn(L1.w_v, D, params->w_entity_image, R, pb + P.etmp + D, D + R, D, R, D, false, F32, st));
+  DRIN_TRY(launch_transpose(pb + P.etmp, pb + P.ecat, D, D + R, st));
   // k = b_e W_v1^T + b_v1 as row vectors
   DRIN_TRY(launch_gemm_nt(params->b_entity_text, D, L1.w_v, D, L1.b_v, pb + P.k_t, D, 1, D, D, false, F32, st));
   DRIN_TRY(launch_gemm_nt(params->b_entity_image, D, L1.w_v, D, L1.b_v, pb + P.k_i, D, 1, D, D, false, F32, st));
@@ -236,7 +239,6 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   const int64_t M = (int64_t)B * N;
   if (B == 0) return DRIN_OK;
   const int prec = cfg->precision;
-  const int F32 = DRIN_PREC_F32;
   const bool dyn = cfg->dynamic_edges != 0;
   const bool tokens = cfg->entity_tokens > 0;
   // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
@@ -265,13 +267,15 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
                             cfg->mention_tokens, D, st));
   DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
   float* vm0 = ws + L.vm0;
-  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, F32, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, F32, st));
+  // mention-sized contractions take the configured precision too: launch_gemm_nt keeps problems of fewer
+  // than 1024 rows on the fp32 kernel (latency-bound), larger ones (WikiDiverse batches) go split-bf16
+  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, prec, st));
   // (2) [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1], then q = fu [W_v1 W_et | W_v1 W_ei]
   float* hmfu = ws + L.hmfu;
-  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st));
   if (dyn)
-    DRIN_TRY(launch_gemm_nn(hmfu + D, 2 * D, pb + P.ecat, D + R, ws + L.q, D + R, 2 * (int64_t)B, D + R, D, false, F32, st));
+    DRIN_TRY(launch_gemm_nt(hmfu + D, 2 * D, pb + P.ecat, D, nullptr, ws + L.q, D + R, 2 * (int64_t)B, D + R, D, false, prec, st));
   // (3) one pass over the entity-side bytes
   StreamArgs sa;
   memset(&sa, 0, sizeof(sa));
@@ -290,7 +294,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.fu = hmfu + D;
   sa.ldfu = 2 * D;
   sa.q = ws + L.q;
-  sa.ldq = D + R;
+  sa.ldq = D + R;  // q row = [q_text (D) | q_image (R)]
   sa.k_t = pb + P.k_t;
   sa.k_i = pb + P.k_i;
   sa.xt_out = planes ? nullptr : ws + L.xt;
@@ -319,13 +323,13 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_entity_stream(sa, st));
   DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
   // (4) layer-1 mention vertices: T = S_text W_et^T + S_img W_ei^T, then the W_h input, W_h, LN, GELU
-  DRIN_TRY(launch_gemm_nt(ws + L.s_text, D, params->w_entity_text, D, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D, false, F32, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.s_img, R, params->w_entity_image, R, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, R, true, F32, st));
-  DRIN_TRY(launch_mention_input1(ws + L.tm, ws + L.sig, params->b_entity_text, params->b_entity_image, vm0, ws + L.agg1, B, D, N, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.s_text, D, params->w_entity_text, D, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.s_img, R, params->w_entity_image, R, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R, false, prec, st));
+  DRIN_TRY(launch_mention_input1(ws + L.tm, ws + L.tm2, ws + L.sig, params->b_entity_text, params->b_entity_image, vm0, ws + L.agg1, B, D, N, st));
   float* vm1 = ws + L.vm1;
-  DRIN_TRY(launch_gemm_nt(ws + L.agg1, D, L1.w_h, D, L1.b_h, vm1, D, 2 * (int64_t)B, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.agg1, D, L1.w_h, D, L1.b_h, vm1, D, 2 * (int64_t)B, D, D, false, prec, st));
   DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
-  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, prec, st));
   // (5) the two pair-sized layer-1 contractions on the folded weights
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
@@ -364,7 +368,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_pair_layer1(pa, st));
   // (7) layer-2 mention-text vertex
   DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, F32, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, prec, st));
   DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
   // (8) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h_text;

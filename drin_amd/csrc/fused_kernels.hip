@@ -369,9 +369,11 @@ int launch_reduce_stream_partials(const float* part, float* s_text, float* s_img
 
 // ------------------------------------------------------------------------------------------------
 // W_h input of the two mention vertices of layer 1 (model.py:143-144 + :128 self term), from the
-// contracted sums:  out[t][b] = (T[t][b] + sig_a[t][b] b_et + sig_b[t][b] b_ei) / N + v0[t][b]
+// contracted sums (T = S_text W_et^T, T2 = S_img W_ei^T):
+//   out[t][b] = (T[t][b] + T2[t][b] + sig_a[t][b] b_et + sig_b[t][b] b_ei) / N + v0[t][b]
 // with (sig_a, sig_b) = (tt, ti) for t = 0 (mention text) and (it, ii) for t = 1 (mention image).
-__global__ void __launch_bounds__(256) k_mention_input1(const float* __restrict__ T, const float* __restrict__ sig,
+__global__ void __launch_bounds__(256) k_mention_input1(const float* __restrict__ T, const float* __restrict__ T2,
+                                                        const float* __restrict__ sig,
                                                         const float* __restrict__ b_et, const float* __restrict__ b_ei,
                                                         const float* __restrict__ v0, float* __restrict__ out, int B,
                                                         int D, float inv_n) {
@@ -382,16 +384,39 @@ __global__ void __launch_bounds__(256) k_mention_input1(const float* __restrict_
   const int t = (int)(row / B);
   const int64_t b = row - (int64_t)t * B;
   const float sa = sig[(int64_t)(t == 0 ? 0 : 2) * B + b], sb = sig[(int64_t)(t == 0 ? 1 : 3) * B + b];
-  out[i] = (T[i] + sa * b_et[d] + sb * b_ei[d]) * inv_n + v0[i];
+  out[i] = ((T[i] + T2[i]) + sa * b_et[d] + sb * b_ei[d]) * inv_n + v0[i];
 }
 
-int launch_mention_input1(const float* T, const float* sig, const float* b_et, const float* b_ei, const float* v0,
-                          float* out, int B, int D, int N, hipStream_t st) {
+int launch_mention_input1(const float* T, const float* T2, const float* sig, const float* b_et, const float* b_ei,
+                          const float* v0, float* out, int B, int D, int N, hipStream_t st) {
   if (B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_mention_input1, dim3((unsigned)cdiv(2 * (int64_t)B * D, 256)), dim3(256), 0, st, T, sig, b_et,
-                     b_ei, v0, out, B, D, 1.0f / (float)N);
+  hipLaunchKernelGGL(k_mention_input1, dim3((unsigned)cdiv(2 * (int64_t)B * D, 256)), dim3(256), 0, st, T, T2, sig,
+                     b_et, b_ei, v0, out, B, D, 1.0f / (float)N);
   DRIN_CHECK_LAUNCH("k_mention_input1");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[c][r] = in[r][c]   (one-off, drin_prepare: turns W_v1 [W_et | W_ei] into the nn.Linear layout)
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                   int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_transpose, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), dim3(256), 0, st, in, out,
+                     rows, cols);
+  DRIN_CHECK_LAUNCH("k_transpose");
   return DRIN_OK;
 }
 

@@ -212,7 +212,7 @@ def test_forward_bf16x3_matches_reference_golden(golden_dir, name):
 def test_bf16x3_reference_batch_vs_oracle():
     cfg = wikimel_config()
     sd = synth.make_state_dict(cfg, 7)
-    batch = synth.make_batch(cfg, 16, 45)      # 1616 pairs: the pair-sized GEMMs take the bf16x3 kernel
+    batch = synth.make_batch(cfg, 16, 45)
     ref = O.forward(sd, batch)
     model = Model(cfg, precision="bf16x3").to(DEV).eval()
     model.load_state_dict(sd)

@@ -91,7 +91,7 @@ EXPORTS = {
     "drin_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "drin_kernel_class_name": (C.c_char_p, [C.c_int]),
 }
-KERNEL_CLASSES = 5
+KERNEL_CLASSES = 7
 
 
 class DrinError(RuntimeError):

@@ -93,7 +93,7 @@ struct FusedLayout {  // workspace offsets in floats
     mt2 = take(B * D);
     const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL;
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
-    p_xi = take(planes ? M * R : 0);
+    p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
     total = off;
   }
@@ -245,6 +245,10 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   // run on the LDS-DMA kernel of gemm_x3_planes.hip
   const bool planes = (prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL) && (D % 32 == 0) && (R % 32 == 0);
   const bool indexed = b->entity_index != nullptr;
+  // The image rows are read in place by their contraction (fp32, split on the fly): writing 8 KB/pair of
+  // planes from the stream kernel costs it more (measured +0.3 ms at B = 1024) than the LDS-DMA kernel
+  // gains on that GEMM (-0.15 ms).  Only the table form, which has to gather the rows anyway, writes them.
+  const bool xi_planes = planes && indexed;
   if (indexed && cfg->num_entities <= 0) {
     set_error("drin_forward_prepared: entity_index given but cfg.num_entities = %d", cfg->num_entities);
     return DRIN_E_SHAPE;
@@ -301,8 +305,10 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   if (planes) {
     sa.xt_hi = xt_hi;
     sa.xt_lo = xt_hi + MD;
-    sa.xi_hi = xi_hi;
-    sa.xi_lo = xi_hi + MR;
+    if (xi_planes) {
+      sa.xi_hi = xi_hi;
+      sa.xi_lo = xi_hi + MR;
+    }
   }
   sa.e0m = ws + L.e0m;
   sa.e1m = ws + L.e1m;
@@ -335,7 +341,10 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
     DRIN_TRY(launch_gemm_x3_planes(xt_hi, xt_hi + MD, D, ct, ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st));
-    DRIN_TRY(launch_gemm_x3_planes(xi_hi, xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
+    if (xi_planes)
+      DRIN_TRY(launch_gemm_x3_planes(xi_hi, xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
+    else
+      DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));

@@ -250,7 +250,7 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
     attr_done = true;
   }
   dim3 grid((unsigned)cdiv(N, x3::BN), (unsigned)mt);
-  KernelTimer timer(DRIN_KC_GEMM, st);
+  KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(x3::k_gemm_bf16x3, grid, dim3(x3::THREADS), x3::LDS_BYTES, st, x, ldx, w, ldw, bias, y, ldy, M, N,
                      K);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");

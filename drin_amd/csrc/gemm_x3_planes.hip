@@ -276,7 +276,7 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
     attr_done = true;
   }
   dim3 grid((unsigned)cdiv(N, x3p::BN), (unsigned)mt);
-  KernelTimer timer(DRIN_KC_GEMM, st);
+  KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
   hipLaunchKernelGGL(x3p::k_gemm_x3_planes, grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, (const __bf16*)a_hi,
                      (const __bf16*)a_lo, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K);
   DRIN_CHECK_LAUNCH("k_gemm_x3_planes");

@@ -210,12 +210,14 @@ DRIN_API int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const vo
 
 /* Kernel classes the launches are attributed to. */
 typedef enum {
-  DRIN_KC_GEMM = 0,   /* MFMA contractions (gemm_f32.hip and the fused row kernels)               */
+  DRIN_KC_GEMM = 0,   /* k_gemm_f32: exact fp32 MFMA contractions (all backward products too)     */
   DRIN_KC_POOL = 1,   /* input pooling: span / region / token means                               */
   DRIN_KC_EDGE = 2,   /* static edge builders: cosine rows, miei, scaling                          */
   DRIN_KC_GCN = 3,    /* aggregation, LayerNorm+GELU, edge update, their backward                  */
   DRIN_KC_STREAM = 4, /* k_entity_stream: the single pass over the entity-side bytes (fused path)  */
-  DRIN_KC_COUNT = 5
+  DRIN_KC_GEMM_X3 = 5,     /* k_gemm_bf16x3: split-bf16 contraction, fp32 operands split on the fly */
+  DRIN_KC_GEMM_PLANES = 6, /* k_gemm_x3_planes: split-bf16 contraction on pre-split planes (LDS-DMA) */
+  DRIN_KC_COUNT = 7
 } drin_kernel_class;
 
 /* While a profile is open on the calling thread, every launch made from that thread is bracketed by

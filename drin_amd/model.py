@@ -328,6 +328,8 @@ class Model(nn.Module):
                     return _DrinScore.apply(call, self._prepared, False, *params)
             batch = batch.gathered()
         call = _Call(self.cfg, batch, self.precision)
+        if call.B == 0:
+            return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         # grad mode is already off inside Function.forward (and needs_input_grad ignores no_grad), so the
         # caller's mode is read here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)

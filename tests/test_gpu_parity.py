@@ -503,3 +503,56 @@ def test_indexed_loader_and_runner(tmp_path):
             hist[kind] = MELRunner(cfg, model, DEV).fit(create_datasets(cfg, str(tmp_path)))
     for a, b in zip(hist["gathered"].train + hist["gathered"].test, hist["indexed"].train + hist["indexed"].test):
         assert abs(a.loss - b.loss) <= 1e-4 and a.topk == pytest.approx(b.topk, abs=1e-9)
+
+
+# ---- ragged / unusual geometries against the oracle ---------------------------------------------------------
+@pytest.mark.parametrize("kw,B", [
+    (dict(object_topk_mention=2, object_topk_entity=2), 3),            # Km, Ke other than (3, 1): i-major / j-minor sum
+    (dict(num_candidates_data=0), 4),                                   # N = 1: only the answer slot
+    (dict(num_candidates_data=1000), 2),                                # BASELINE config 5 candidate count
+    (dict(dataset_name="wikimel", num_candidates_data=5, max_entity_attr_token_len=1), 3),   # T = 1: every slice empty -> NaN
+    (dict(dataset_name="wikimel", num_candidates_data=17, max_entity_attr_token_len=70), 2),  # T > 64: mask count over 2 wave passes
+    (dict(max_mention_sentence_len=4, resnet_num_region=1), 5),
+])
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layerwise"])
+def test_unusual_geometries_vs_oracle(kw, B, fused):
+    base = dict(TINY)
+    base.update(kw)
+    cfg = DrinConfig(**base)
+    sd = synth.make_state_dict(cfg, 8)
+    batch = synth.make_batch(cfg, B, 61, min_tokens=1)
+    ref = O.forward(sd, batch)
+    model = Model(cfg, fused=fused).to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        got = model(_to_dev(batch)).cpu()
+    assert got.shape == ref.shape
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert (torch.nan_to_num(got) - torch.nan_to_num(ref)).abs().max().item() <= 2e-5
+
+
+def test_empty_batch():
+    cfg = DrinConfig(**TINY)
+    model = Model(cfg).to(DEV).eval()
+    batch = [t[:0] for t in _to_dev(synth.make_batch(cfg, 2, 1))]
+    with torch.no_grad():
+        out = model(batch)
+    assert tuple(out.shape) == (0, cfg.num_candidates_model)
+
+
+def test_inner_feature_dims_take_the_pooled_path():
+    """mention objects [B, Km, 2, R] / entity image [B, N, 3, R] / entity objects [B, N, Ke, 2, R]: the means of
+    model.py:43-44,78-83 are real reductions here (both datasets store a singleton there)."""
+    cfg = DrinConfig(**TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    batch = synth.make_batch(cfg, 3, 62)
+    g = torch.Generator().manual_seed(5)
+    batch[5] = torch.randn(3, 3, 2, cfg.resnet_embed_dim, generator=g)
+    batch[9] = torch.randn(3, cfg.num_candidates_model, 3, cfg.resnet_embed_dim, generator=g)
+    batch[10] = torch.randn(3, cfg.num_candidates_model, 1, 2, cfg.resnet_embed_dim, generator=g)
+    ref = O.forward(sd, batch)
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        got = model(_to_dev(batch)).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5

@@ -344,7 +344,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
     if (xi_planes)
       DRIN_TRY(launch_gemm_x3_planes(xi_hi, xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
     else
-      DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st));
+      DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
+                                     ci + (size_t)D * R));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));

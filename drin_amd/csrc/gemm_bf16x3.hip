@@ -1,19 +1,23 @@
 // fp32-equivalent GEMM on the bf16 matrix cores ("bf16x3"): y[m, n] = sum_k x[m, k] w[n, k] + bias[n].
 //
-// Every fp32 operand is split on the fly into two bf16 numbers, v = hi + lo (+ <= 2^-17 |v|), and
-// the product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on
-// v_mfma_f32_32x32x16_bf16: three MFMAs at the bf16 rate (16x the fp32 MFMA rate) instead of eight
-// fp32 MFMAs, i.e. 5.3x fewer matrix-core cycles per contraction.  bf16 x bf16 products are exact in
-// fp32, so the only error is the dropped lo*lo term and the split residue: ~1e-5 relative per
-// product with random sign, which measures as ~1e-6 on the final scores (75x inside the 1e-4
-// parity bar; tests/test_gpu_parity.py pins it).
+// Every fp32 operand is split into two bf16 numbers, v = hi + lo (+ <= 2^-17 |v|), and the product is
+// evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x16_bf16: three MFMAs at
+// the bf16 rate (16x the fp32 MFMA rate) instead of eight fp32 MFMAs.  bf16 x bf16 products are exact in
+// fp32, so the only error is the dropped lo*lo term and the split residue: <= 7e-6 of sum |x||w| per
+// output, ~1e-6 on the final scores (75x inside the 1e-4 parity bar; tests/test_gpu_parity.py pins it).
 //
-// Tile 256 x 256 x 32, 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns 128 x 64 = 4 x 2 MFMA
-// tiles (128 accumulator VGPRs).  At the bf16 rate a 128 x 128 tile would need > 30 TB/s from L2;
-// 256 x 256 needs ~13 TB/s.  LDS: per buffer four planes (A hi, A lo, B hi, B lo) of 256 rows x 64 B
-// = 64 KiB, two buffers = 128 KiB -> one workgroup per CU, two waves per SIMD.  Rows are 64 B
-// (32 bf16); the 16-byte chunk index is XOR-swizzled with (row >> 2) & 3 so that every ds_read_b128
-// lane group (rows r .. at one chunk) lands on 16 distinct bank quads.
+// This file: the activation operand x arrives as fp32 and is split ON THE FLY while it is staged
+// (global -> VGPR -> split -> LDS); the weight operand is either split the same way or, when drin_prepare
+// has already written its bf16 planes, streamed by LDS-DMA (W_PLANES).  gemm_x3_planes.hip is the
+// variant for activations that their producer already wrote as planes.
+//
+// Two tile shapes of one template:
+//   256 x 256 x 32, 8 waves (2 x 4, wave tile 128 x 64): pair-sized problems.  At the bf16 rate a 128 x 128
+//     tile would need > 30 TB/s from L2; 256 x 256 needs ~13 TB/s.  128 KiB LDS, one workgroup per CU.
+//   64 x 128 x 32, 4 waves (2 x 2, wave tile 32 x 64): mention-sized problems (a few thousand rows), where
+//     the number of workgroups, not the tile efficiency, decides the time.
+// LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with (row >> 2) & 3 so that every
+// ds_read_b128 lane group lands on 16 distinct bank quads (for LDS-DMA the swizzle goes on the source).
 #include "device_utils.h"
 #include "internal.h"
 
@@ -25,67 +29,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace x3 {
 
-#ifdef X3_STAMPS  // diagnostic build: per-segment cycle sums of wave 0 of workgroup 0 (never in the shipped kernel)
-__device__ unsigned long long g_stamps[8];
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define STAMP(i)                                   \
-  do {                                             \
-    const unsigned long long _t = stamp();         \
-    seg[i] += _t - tprev;                          \
-    tprev = _t;                                    \
-  } while (0)
-#else
-#define STAMP(i)
-#endif
+constexpr int BK = 32;
 
-constexpr int BM = 256, BN = 256, BK = 32;
-constexpr int THREADS = 512;
-constexpr int PLANE_BYTES = 256 * 64;         // one operand plane of one buffer
-constexpr int BUF_BYTES = 4 * PLANE_BYTES;    // A hi, A lo, B hi, B lo
-constexpr int LDS_BYTES = 2 * BUF_BYTES;      // 131072
-
-// byte offset of (row, 16-byte chunk c) inside a plane
 __device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
-struct Staged {
-  float4 v[4];
-};
-
-// 256 rows x 32 floats: thread t loads float4 #(t & 7) of rows (t >> 3) + 64 i.  Loads are
-// unconditional (no exec-masked branches in the K loop): rows past the end are clamped to the last
-// row - their products land in output rows / columns that are never stored - and K % 32 == 0.
-struct RowPtrs {
-  const float* p[4];
-};
-__device__ __forceinline__ RowPtrs row_ptrs(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows) {
-  const int t = threadIdx.x;
-  const int c4 = t & 7, r = t >> 3;
-  RowPtrs q;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t row = row0 + r + 64 * i;
-    row = row < rows ? row : rows - 1;
-    q.p[i] = src + row * ld + c4 * 4;
-  }
-  return q;
-}
-__device__ __forceinline__ void load_tile(Staged& s, const RowPtrs& q, int k0) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) s.v[i] = ld4(q.p[i] + k0);
-}
-
 __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
-#ifdef ABL_NO_SPLIT  // ablation build: wrong numbers, timing only
-  hi = *reinterpret_cast<bf16x4*>(&v.x);
-  lo = *reinterpret_cast<bf16x4*>(&v.z);
-  return;
-#endif
   hi[0] = (__bf16)v.x;
   hi[1] = (__bf16)v.y;
   hi[2] = (__bf16)v.z;
@@ -96,165 +44,241 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
   lo[3] = (__bf16)(v.w - (float)hi[3]);
 }
 
-// registers -> (hi plane, lo plane): float4 #c4 of a row is the 8-byte half (c4 & 1) of chunk c4 >> 1
-__device__ __forceinline__ void store_tile(const Staged& s, char* __restrict__ hi_plane, char* __restrict__ lo_plane) {
-  const int t = threadIdx.x;
-  const int c4 = t & 7, r = t >> 3;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bf16x4 hi, lo;
-    split4(s.v[i], hi, lo);
-    const int off = swz(r + 64 * i, c4 >> 1) + ((c4 & 1) << 3);
-    *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
-    *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
-  }
-}
+// ROWS x 32 floats staged by THREADS threads: thread t loads float4 #(t & 7) of rows (t >> 3) + (THREADS/8) i.
+// Loads are unconditional (no exec-masked branches in the K loop): rows past the end are clamped to the
+// last row - their products land in output rows / columns that are never stored - and K % 32 == 0.
+template <int ROWS, int THREADS>
+struct Stager {
+  static constexpr int RPP = THREADS / 8;  // rows per pass
+  static constexpr int PASSES = ROWS / RPP;
+  const float* p[PASSES];
+  float4 v[PASSES];
 
-__global__ void __launch_bounds__(THREADS, 2)
-    k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
-                  const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows) {
+    const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      int64_t row = row0 + r + RPP * i;
+      row = row < rows ? row : rows - 1;
+      p[i] = src + row * ld + c4 * 4;
+    }
+  }
+  __device__ __forceinline__ void load(int k0) {
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) v[i] = ld4(p[i] + k0);
+  }
+  // registers -> (hi plane, lo plane): float4 #c4 of a row is the 8-byte half (c4 & 1) of chunk c4 >> 1
+  __device__ __forceinline__ void store(char* __restrict__ hi_plane, char* __restrict__ lo_plane) const {
+    const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      bf16x4 hi, lo;
+      split4(v[i], hi, lo);
+      const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
+      *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
+      *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+    }
+  }
+};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA of the weight planes: 2 planes x ROWS rows x 64 B = ROWS / 8 pieces of 1 KiB, dealt over the waves.
+template <int ROWS, int WAVES>
+struct PlaneDma {
+  static constexpr int PIECES = ROWS / 8 / WAVES;  // per wave
+  const char* src[PIECES];
+  int lds_off[PIECES];
+
+  __device__ __forceinline__ void init(const __bf16* hi, const __bf16* lo, int64_t ld, int64_t row0, int64_t rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int piece = wave * PIECES + i;  // 0 .. ROWS/8 - 1; first half hi plane, second half lo plane
+      const int plane = piece / (ROWS / 16), pr = piece % (ROWS / 16);
+      const int row = pr * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      int64_t g = row0 + row;
+      g = g < rows ? g : rows - 1;
+      src[i] = reinterpret_cast<const char*>((plane ? lo : hi) + g * ld) + chunk * 16;
+      lds_off[i] = plane * ROWS * 64 + pr * 1024;
+    }
+  }
+  __device__ __forceinline__ void issue(char* planes_base, int kb) const {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)kb * (BK * 2)), (lptr_t)(planes_base + lds_off[i]), 16,
+                                       0, 0);
+  }
+};
+
+template <int BM, int BN, int WM, int WN>
+struct Cfg {
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
+  static constexpr int BUF_BYTES = 2 * A_PLANE + 2 * B_PLANE;  // A hi, A lo, B hi, B lo
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+  static constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+};
+
+template <int BM, int BN, int WM, int WN, bool W_PLANES>
+__global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
+    k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
+                  const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
+                  int64_t ldc, int64_t M, int N, int K) {
+  using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t m0 = (int64_t)blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const int nkb = K / BK;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves; wave tile 128 x 64
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
-  f32x16 acc[4][2];
+  f32x16 acc[G::MI][G::NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < G::MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < G::NI; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  Staged sa, sb;
-  const RowPtrs pa = row_ptrs(A, lda, m0, M);
-  const RowPtrs pb = row_ptrs(W, ldw, n0, N);
-  load_tile(sa, pa, 0);
-  load_tile(sb, pb, 0);
-  store_tile(sa, smem, smem + PLANE_BYTES);
-  store_tile(sb, smem + 2 * PLANE_BYTES, smem + 3 * PLANE_BYTES);
+  Stager<BM, G::THREADS> sa;
+  Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;  // one dummy pass when the weights come by DMA
+  PlaneDma<BN, WM * WN> dma;
+  sa.init(A, lda, m0, M);
+  if (W_PLANES)
+    dma.init(w_hi, w_lo, ldw, n0, N);
+  else
+    sb.init(W, ldw, n0, N);
+
+  sa.load(0);
+  if (W_PLANES)
+    dma.issue(smem + 2 * G::A_PLANE, 0);
+  else
+    sb.load(0);
+  sa.store(smem, smem + G::A_PLANE);
+  if (!W_PLANES) sb.store(smem + 2 * G::A_PLANE, smem + 2 * G::A_PLANE + G::B_PLANE);
   if (nkb > 1) {  // tile 1 is in flight while tile 0 is computed
-    load_tile(sa, pa, BK);
-    load_tile(sb, pb, BK);
+    sa.load(BK);
+    if (!W_PLANES) sb.load(BK);
   }
   __syncthreads();
 
-  // One k16 step (24 MFMAs per wave) of the current buffer.
+  // One k16 step of the current buffer: (MI x NI) tiles x 3 MFMAs per wave.
   auto k16_step = [&](const char* buf, int s) {
-    bf16x8 bh[2], bl[2];
+    bf16x8 bh[G::NI], bl[G::NI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int off = swz(wn * 64 + j * 32 + r, 2 * s + h);
-      bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * PLANE_BYTES + off);
-      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE_BYTES + off);
+    for (int j = 0; j < G::NI; ++j) {
+      const int off = swz(wn * (BN / WN) + j * 32 + r, 2 * s + h);
+      bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + off);
+      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int off = swz(wm * 128 + i * 32 + r, 2 * s + h);
+    for (int i = 0; i < G::MI; ++i) {
+      const int off = swz(wm * (BM / WM) + i * 32 + r, 2 * s + h);
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#ifdef ABL_NO_MFMA  // ablation build: keep the fragment reads alive, skip the matrix work
-        asm volatile("" ::"v"(al), "v"(ah), "v"(bh[j]), "v"(bl[j]));
-#else
+      for (int j = 0; j < G::NI; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-#endif
       }
     }
   };
 
-  // Steady state of iteration kb: tile kb is in LDS buffer kb & 1, tile kb+1 is in the staging
-  // registers (its loads were issued one full iteration ago).  Between the two k16 steps the staged
-  // tile is split and written to the other buffer and the loads of tile kb+2 are issued into the same
-  // registers, so every global load has a whole iteration of MFMA work to land under.
-#ifdef X3_STAMPS
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = stamp();
-#endif
+  // Steady state of iteration kb: tile kb is in LDS buffer kb & 1, tile kb+1 is in the staging registers
+  // (its loads were issued one full iteration ago).  Between the two k16 steps the staged tile is split
+  // and written to the other buffer and the loads of tile kb+2 are issued into the same registers, so
+  // every global load has a whole iteration of MFMA work to land under.  Weight planes (W_PLANES) go
+  // straight to the other buffer by LDS-DMA at the top of the iteration.
   for (int kb = 0; kb < nkb; ++kb) {
     const int cur = kb & 1;
-    const char* buf = smem + cur * BUF_BYTES;
+    const char* buf = smem + cur * G::BUF_BYTES;
+    char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
+    const bool more = kb + 1 < nkb;
+    if (W_PLANES && more) dma.issue(nb + 2 * G::A_PLANE, kb + 1);
     k16_step(buf, 0);
-    STAMP(0);
-    if (kb + 1 < nkb) {
-      char* nb = smem + (cur ^ 1) * BUF_BYTES;
-      store_tile(sa, nb, nb + PLANE_BYTES);
-      store_tile(sb, nb + 2 * PLANE_BYTES, nb + 3 * PLANE_BYTES);
-      STAMP(1);
-#ifndef ABL_NO_GLOBAL
+    if (more) {
+      sa.store(nb, nb + G::A_PLANE);
+      if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
       if (kb + 2 < nkb) {
-        load_tile(sa, pa, (kb + 2) * BK);
-        load_tile(sb, pb, (kb + 2) * BK);
+        sa.load((kb + 2) * BK);
+        if (!W_PLANES) sb.load((kb + 2) * BK);
       }
-#endif
-      STAMP(2);
     }
     k16_step(buf, 1);
-    STAMP(3);
-    __syncthreads();
-    STAMP(4);
+    __syncthreads();  // also drains the LDS-DMA of this iteration (vmcnt(0))
   }
-#ifdef X3_STAMPS
-  if (blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0)
-    for (int i = 0; i < 8; ++i) g_stamps[i] = seg[i];
-#endif
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < G::MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < G::NI; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + r;
       if (col >= N) continue;
       const float bv = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int64_t row = m0 + wm * 128 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const int64_t row = m0 + wm * (BM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
         if (row < M) C[row * ldc + col] = acc[i][j][v] + bv;
       }
     }
 }
 
-}  // namespace x3
-
-#ifdef X3_STAMPS
-extern "C" __attribute__((visibility("default"))) int drin_debug_x3_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(x3::g_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
-}
-#endif
-
-int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
-                          int64_t ldy, int64_t M, int N, int K, hipStream_t st) {
-  if (M <= 0 || N <= 0) return DRIN_OK;
-  if ((K % x3::BK) || K <= 0)  // odd reduction lengths take the exact fp32 kernel (guarded loads)
-    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, M, N, K, false, DRIN_PREC_F32, st);
-  if ((ldx % 4) || (ldw % 4) || !aligned16(x) || !aligned16(w)) {
-    set_error("gemm_nt_bf16x3: leading dimensions must be multiples of 4, operands 16-byte aligned");
-    return DRIN_E_ALIGN;
-  }
-  const int64_t mt = cdiv(M, x3::BM);
+template <int BM, int BN, int WM, int WN, bool W_PLANES>
+static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
+                  const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st) {
+  using G = Cfg<BM, BN, WM, WN>;
+  const int64_t mt = cdiv(M, BM);
   if (mt > 65535) {
-    set_error("gemm_nt_bf16x3: %lld row tiles exceed the grid limit; split the batch", (long long)mt);
+    set_error("gemm_bf16x3: %lld row tiles exceed the grid limit; split the batch", (long long)mt);
     return DRIN_E_SHAPE;
   }
+  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3::k_gemm_bf16x3),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_BYTES);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16x3)");
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(N, x3::BN), (unsigned)mt);
+  dim3 grid((unsigned)cdiv(N, BN), (unsigned)mt);
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
-  hipLaunchKernelGGL(x3::k_gemm_bf16x3, grid, dim3(x3::THREADS), x3::LDS_BYTES, st, x, ldx, w, ldw, bias, y, ldy, M, N,
-                     K);
+  hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi, (const __bf16*)w_lo,
+                     ldw, bias, y, ldy, M, N, K);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
   return DRIN_OK;
+}
+
+}  // namespace x3
+
+// w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
+int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+                          int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo) {
+  if (M <= 0 || N <= 0) return DRIN_OK;
+  if ((K % x3::BK) || K <= 0) {  // odd reduction lengths take the exact fp32 kernel (guarded loads)
+    if (!w) {
+      set_error("gemm_bf16x3: K=%d is not a multiple of 32 and no fp32 weights were given", K);
+      return DRIN_E_SHAPE;
+    }
+    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, M, N, K, false, DRIN_PREC_F32, st);
+  }
+  const bool planes = w_hi != nullptr && w_lo != nullptr;
+  if ((ldx % 4) || !aligned16(x) ||
+      (planes ? ((ldw % 8) || !aligned16(w_hi) || !aligned16(w_lo)) : ((ldw % 4) || !aligned16(w)))) {
+    set_error("gemm_bf16x3: operands must be 16-byte aligned with leading dimensions multiples of 4 (fp32) / 8 (bf16)");
+    return DRIN_E_ALIGN;
+  }
+  // pair-sized problems: 256 x 256 tiles; anything that would not fill the chip with them: 64 x 128 tiles
+  const bool big = cdiv(M, 256) * cdiv(N, 256) >= 192;
+  if (big)
+    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st)
+                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st);
+  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st)
+                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st);
 }
 
 }  // namespace drin

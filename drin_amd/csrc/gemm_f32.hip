@@ -245,9 +245,7 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
                    int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st) {
   // split-bf16 contraction for the pair-sized GEMMs; the mention-sized ones (a few hundred rows) stay on
   // the exact fp32 kernel: they are latency-bound, not rate-bound
-  // (its 256 x 256 tiles need >= 128 of them to fill the chip; below that the 64 x 64 fp32 tiles win)
-  const bool enough_tiles = cdiv(M, 256) * cdiv(N, 256) >= 128;
-  if (!accumulate && ((precision == DRIN_PREC_BF16X3 && enough_tiles) || precision == DRIN_PREC_BF16X3_ALL))
+  if (!accumulate && ((precision == DRIN_PREC_BF16X3 && M >= 256) || precision == DRIN_PREC_BF16X3_ALL))
     return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, M, N, K, st);
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) precision = DRIN_PREC_F32;
   DRIN_TRY(check_precision(precision, "gemm_nt"));

@@ -58,8 +58,10 @@ int launch_scale_div(const float* in, float* out, int64_t n, float mul, float di
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                    int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st);
 // same contraction, operands split into bf16 hi + lo, three bf16 MFMAs, fp32 accumulate (gemm_bf16x3.hip)
+// (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
-                          int64_t ldy, int64_t M, int N, int K, hipStream_t st);
+                          int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi = nullptr,
+                          const void* w_lo = nullptr);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,

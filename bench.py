@@ -84,7 +84,7 @@ def measured_traffic(kernel_prefix, B, precision, fused):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.py),
     valid only for the configuration they were taken on (default workload); None otherwise."""
     path = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
-    if not (os.path.exists(path) and B == 1024 and precision == "bf16x3" and fused):
+    if not (os.path.exists(path) and B == 4096 and precision == "bf16x3" and fused):
         return None
     try:
         for k, v in json.load(open(path))["kernels"].items():
@@ -213,7 +213,7 @@ def main():
                     help="wikimel: 100-cand token-level (headline); wikidiverse: 10-cand pooled; table: BASELINE config 5 - "
                          "1000 candidates per mention gathered on the device from a table of --entities random entities")
     ap.add_argument("--entities", type=int, default=1_000_000)
-    ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 1024 wikimel / 8192 wikidiverse)")
+    ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 4096 wikimel / 16384 wikidiverse / 512 table)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
                          "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
@@ -243,7 +243,10 @@ def main():
         cfg = DrinConfig(num_candidates_data=1000)       # pooled-text entity rows: 19.7 KB per entity in fp32
     else:
         cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
-    default_b = {"wikimel": 1024, "wikidiverse": 8192, "table": 256}[args.workload]
+    # WikiMEL: 4096 mentions = 413 696 pairs and 92 GB of resident inputs per step (of 288 GB): large steps
+    # amortise the latency-bound mention-side kernels and the GEMM tile quantisation (22.6 vs 20.0 M pairs/s
+    # at 1024 mentions)
+    default_b = {"wikimel": 4096, "wikidiverse": 16384, "table": 512}[args.workload]
     B = args.batch or (default_b if args.mode == "score" else 64)
     sd = synth.make_state_dict(cfg, 7)
     model = Model(cfg, precision=args.precision, fused=not args.generic).to(dev).eval()
@@ -351,7 +354,7 @@ def main():
             "algorithmic": {"bytes_per_pair": bytes_pair, "flops_per_pair_executed": flops_pair,
                             "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(line))
     if world > 1:

@@ -26,6 +26,6 @@ for k in sorted(set(fetch) | set(write)):
     wb = write.get(k, 0.0) * 1024.0
     out[k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
 json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean per launch",
-           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (defaults: wikimel B=1024 bf16x3 fused)",
+           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (defaults: wikimel B=4096 bf16x3 fused)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out.get("void drin::k_entity_stream<3, 8, true>", {}), indent=1))

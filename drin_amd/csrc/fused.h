@@ -66,7 +66,7 @@ struct FinalArgs {
   const float* e1m;
   const float* mt2;      // [B, D]
   float* scores;         // [M]
-  int B, N, D4;
+  int B, N, D4, chunks;
   float ln_eps, cos_eps;
 };
 

@@ -401,6 +401,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   fa.B = B;
   fa.N = N;
   fa.D4 = D / 4;
+  fa.chunks = L.chunks;
   fa.ln_eps = cfg->layer_norm_eps;
   fa.cos_eps = cfg->cosine_eps;
   return launch_pair_final(fa, st);

@@ -457,6 +457,58 @@ __device__ __forceinline__ Row<DV> ln_gelu_row(const Row<DV>& h, const float* __
   return y;
 }
 
+// The same with gamma / beta held in LDS (per-workgroup constants of the pair kernels)
+template <int DV>
+__device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float* gamma, const float* beta, int lane,
+                                                   int D4, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
+  const float inv_d = 1.0f / (float)(D4 * 4);
+  const float mu = wave_sum(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      const float dx = h.v[j].x - mu, dy = h.v[j].y - mu, dz = h.v[j].z - mu, dw = h.v[j].w - mu;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+  Row<DV> y;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
+      y.v[j].x = gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
+      y.v[j].y = gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
+      y.v[j].z = gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
+      y.v[j].w = gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
+    } else {
+      y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  return y;
+}
+
+// out = base + w1 u1 + w2 u2 + c with u1, u2, c in LDS
+template <int DV>
+__device__ __forceinline__ Row<DV> combine_rows_lds(const Row<DV>& base, float w1, const float* u1, float w2,
+                                                    const float* u2, const float* c, int lane, int D4) {
+  Row<DV> r;
+#pragma unroll
+  for (int j = 0; j < DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4)
+      r.v[j] = fma4(w1, ld4(u1 + c4 * 4), fma4(w2, ld4(u2 + c4 * 4), base.v[j] + ld4(c + c4 * 4)));
+    else
+      r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  return r;
+}
+
 // out = base + w1 u1 + w2 u2 + c
 template <int DV>
 __device__ __forceinline__ Row<DV> combine_rows(const Row<DV>& base, float w1, const Row<DV>& u1, float w2,
@@ -473,27 +525,37 @@ __device__ __forceinline__ Row<DV> combine_rows(const Row<DV>& base, float w1, c
 // and the layer-2 mention aggregates  S2_t[b] = sum_n e1_tt et1,  S2_i[b] = sum_n e1_ti ei1  per chunk.
 template <int DV>
 __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
-  __shared__ float l_red[2 * DV * 256];
+  __shared__ __attribute__((aligned(16))) float l_red[2 * DV * 256];
+  __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm_t, hm_i, c_t, c_i, gamma, beta
   const int D4 = a.D4, D = D4 * 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t b = blockIdx.y;
   const int64_t M = (int64_t)a.B * a.N;
   const int per = (a.N + a.chunks - 1) / a.chunks;
   const int n_begin = blockIdx.x * per, n_end = min(a.N, n_begin + per);
-  const Row<DV> hm_t = load_row<DV>(a.hm + b * a.ldhm, lane, D4);
-  const Row<DV> hm_i = load_row<DV>(a.hm + ((int64_t)a.B + b) * a.ldhm, lane, D4);
-  const Row<DV> c_t = load_row<DV>(a.c_t, lane, D4), c_i = load_row<DV>(a.c_i, lane, D4);
+  constexpr int LD = DV * 256;
+  {
+    const float* src[6] = {a.hm + b * a.ldhm, a.hm + ((int64_t)a.B + b) * a.ldhm, a.c_t, a.c_i, a.gamma, a.beta};
+#pragma unroll
+    for (int v = 0; v < 6; ++v)
+      for (int i = threadIdx.x; i < D4; i += 256) st4(l_const + v * LD + i * 4, ld4(src[v] + i * 4));
+  }
+  __syncthreads();
+  const float *l_hm_t = l_const, *l_hm_i = l_const + LD, *l_ct = l_const + 2 * LD, *l_ci = l_const + 3 * LD;
+  const float *l_gamma = l_const + 4 * LD, *l_beta = l_const + 5 * LD;
   Row<DV> S_t = zero_row<DV>(), S_i = zero_row<DV>();
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
     const Row<DV> ht = load_row<DV>(a.h_text + p * D, lane, D4);
     const Row<DV> hi = load_row<DV>(a.h_image + p * D, lane, D4);
     const float e_tt = a.e0m[p], e_ti = a.e0m[M + p], e_it = a.e0m[2 * M + p], e_ii = a.e0m[3 * M + p];
-    const Row<DV> et1 = ln_gelu_row<DV>(combine_rows<DV>(ht, e_tt, hm_t, e_it, hm_i, c_t), a.gamma, a.beta, lane, D4, a.ln_eps);
-    const Row<DV> ei1 = ln_gelu_row<DV>(combine_rows<DV>(hi, e_ti, hm_t, e_ii, hm_i, c_i), a.gamma, a.beta, lane, D4, a.ln_eps);
+    const Row<DV> et1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4), l_gamma,
+                                            l_beta, lane, D4, a.ln_eps);
     if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
     if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
     axpy_row<DV>(S_t, a.e1m[p], et1);
+    const Row<DV> ei1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4), l_gamma,
+                                            l_beta, lane, D4, a.ln_eps);
     axpy_row<DV>(S_i, a.e1m[M + p], ei1);
   }
   for (int w = 0; w < 4; ++w) {
@@ -558,36 +620,47 @@ int launch_mention_input2(const float* part, const float* mt1, float* out, int B
 }
 
 // ------------------------------------------------------------------------------------------------
-// Layer-2 entity-text vertex and the score, one wave per pair (model.py:128 for et'', :207-209):
+// Layer-2 entity-text vertex and the score (model.py:128 for et'', :207-209), grid (chunks, B), 256 threads:
 //   et2 = gelu(LN(H2raw[p] + e1_tt hm2_t[b] + e1_it hm2_i[b] + b_h2)),  score[p] = cos(mt2[b], et2)
+// The five per-mention / constant vectors live in LDS; each wave walks candidates of its chunk.
 template <int DV>
 __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
+  __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm2_t, hm2_i, b_h2, gamma, beta, mt2
+  const int D4 = a.D4, D = D4 * 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.y;
   const int64_t M = (int64_t)a.B * a.N;
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= M) return;
-  const int lane = threadIdx.x & 63, D4 = a.D4, D = D4 * 4;
-  const int64_t b = p / a.N;
-  const Row<DV> h = load_row<DV>(a.h2 + p * D, lane, D4);
-  const Row<DV> hm_t = load_row<DV>(a.hm2 + b * D, lane, D4);
-  const Row<DV> hm_i = load_row<DV>(a.hm2 + ((int64_t)a.B + b) * D, lane, D4);
-  const Row<DV> bias = load_row<DV>(a.b_h2, lane, D4);
-  const Row<DV> et2 = ln_gelu_row<DV>(combine_rows<DV>(h, a.e1m[p], hm_t, a.e1m[2 * M + p], hm_i, bias), a.gamma, a.beta,
-                                      lane, D4, a.ln_eps);
-  const Row<DV> mt2 = load_row<DV>(a.mt2 + b * D, lane, D4);
-  const float xy = wave_sum(dot_rows<DV>(mt2, et2));
+  const int per = (a.N + a.chunks - 1) / a.chunks;
+  const int n_begin = blockIdx.x * per, n_end = min(a.N, n_begin + per);
+  constexpr int LD = DV * 256;
+  {
+    const float* src[6] = {a.hm2 + b * D, a.hm2 + ((int64_t)a.B + b) * D, a.b_h2, a.gamma, a.beta, a.mt2 + b * D};
+#pragma unroll
+    for (int v = 0; v < 6; ++v)
+      for (int i = threadIdx.x; i < D4; i += 256) st4(l_const + v * LD + i * 4, ld4(src[v] + i * 4));
+  }
+  __syncthreads();
+  const Row<DV> mt2 = load_row<DV>(l_const + 5 * LD, lane, D4);
   const float xx = wave_sum(dot_rows<DV>(mt2, mt2));
-  const float yy = wave_sum(dot_rows<DV>(et2, et2));
-  if (lane == 0) a.scores[p] = cosine_from_sums(xy, xx, yy, a.cos_eps);
+  for (int n = n_begin + wave; n < n_end; n += 4) {
+    const int64_t p = b * a.N + n;
+    const Row<DV> h = load_row<DV>(a.h2 + p * D, lane, D4);
+    const Row<DV> et2 = ln_gelu_row_lds<DV>(
+        combine_rows_lds<DV>(h, a.e1m[p], l_const, a.e1m[2 * M + p], l_const + LD, l_const + 2 * LD, lane, D4),
+        l_const + 3 * LD, l_const + 4 * LD, lane, D4, a.ln_eps);
+    const float xy = wave_sum(dot_rows<DV>(mt2, et2));
+    const float yy = wave_sum(dot_rows<DV>(et2, et2));
+    if (lane == 0) a.scores[p] = cosine_from_sums(xy, xx, yy, a.cos_eps);
+  }
 }
 
 int launch_pair_final(const FinalArgs& a, hipStream_t st) {
-  const int64_t M = (int64_t)a.B * a.N;
-  if (M <= 0) return DRIN_OK;
+  if (a.B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
   if (a.D4 <= 64)
-    hipLaunchKernelGGL(k_pair_final<1>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pair_final<1>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
   else if (a.D4 <= 192)
-    hipLaunchKernelGGL(k_pair_final<3>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pair_final<3>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
   else {
     set_error("pair_final: D=%d outside the built instantiations", a.D4 * 4);
     return DRIN_E_UNSUPPORTED;

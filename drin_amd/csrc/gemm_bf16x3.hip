@@ -1,7 +1,7 @@
 // fp32-equivalent GEMM on the bf16 matrix cores ("bf16x3"): y[m, n] = sum_k x[m, k] w[n, k] + bias[n].
 //
 // Every fp32 operand is split into two bf16 numbers, v = hi + lo (+ <= 2^-17 |v|), and the product is
-// evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x16_bf16: three MFMAs at
+// evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_16x16x32_bf16: three MFMAs at
 // the bf16 rate (16x the fp32 MFMA rate) instead of eight fp32 MFMAs.  bf16 x bf16 products are exact in
 // fp32, so the only error is the dropped lo*lo term and the split residue: <= 7e-6 of sum |x||w| per
 // output, ~1e-6 on the final scores (75x inside the 1e-4 parity bar; tests/test_gpu_parity.py pins it).
@@ -12,18 +12,18 @@
 // variant for activations that their producer already wrote as planes.
 //
 // Two tile shapes of one template:
-//   256 x 256 x 32, 8 waves (2 x 4, wave tile 128 x 64): pair-sized problems.  At the bf16 rate a 128 x 128
+//   256 x 256 x 32, 8 waves (2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles of 16 x 16): pair-sized problems.  At the bf16 rate a 128 x 128
 //     tile would need > 30 TB/s from L2; 256 x 256 needs ~13 TB/s.  128 KiB LDS, one workgroup per CU.
 //   64 x 128 x 32, 4 waves (2 x 2, wave tile 32 x 64): mention-sized problems (a few thousand rows), where
 //     the number of workgroups, not the tile efficiency, decides the time.
-// LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with (row >> 2) & 3 so that every
+// LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled per row quad so that every
 // ds_read_b128 lane group lands on 16 distinct bank quads (for LDS-DMA the swizzle goes on the source).
 #include "device_utils.h"
 #include "internal.h"
 
 namespace drin {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -31,7 +31,11 @@ namespace x3 {
 
 constexpr int BK = 32;
 
-__device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// MFMA shape v_mfma_f32_16x16x32_bf16 (one k-step per K-block; +5 % over 32x32x16 at the clock the chip
+// holds, see gemm_x3_planes.hip).  A lane's fragment is row (lane & 15), chunk (lane >> 4); the bank-conflict-
+// free chunk swizzle for that access pattern is the row-quad permutation f = (0, 2, 3, 1).
+__device__ __forceinline__ int swz_f(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+__device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ swz_f(row)) << 4); }
 
 __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
   hi[0] = (__bf16)v.x;
@@ -98,7 +102,7 @@ struct PlaneDma {
       const int piece = wave * PIECES + i;  // 0 .. ROWS/8 - 1; first half hi plane, second half lo plane
       const int plane = piece / (ROWS / 16), pr = piece % (ROWS / 16);
       const int row = pr * 16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      const int chunk = (lane & 3) ^ swz_f(row);
       int64_t g = row0 + row;
       g = g < rows ? g : rows - 1;
       src[i] = reinterpret_cast<const char*>((plane ? lo : hi) + g * ld) + chunk * 16;
@@ -119,7 +123,7 @@ struct Cfg {
   static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
   static constexpr int BUF_BYTES = 2 * A_PLANE + 2 * B_PLANE;  // A hi, A lo, B hi, B lo
   static constexpr int LDS_BYTES = 2 * BUF_BYTES;
-  static constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  static constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 16 x 16 MFMA tiles per wave
 };
 
 template <int BM, int BN, int WM, int WN, bool W_PLANES>
@@ -134,15 +138,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   const int nkb = K / BK;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 31, h = lane >> 5;
+  const int r = lane & 15, c = lane >> 4;
 
-  f32x16 acc[G::MI][G::NI];
+  f32x4 acc[G::MI][G::NI];
 #pragma unroll
   for (int i = 0; i < G::MI; ++i)
 #pragma unroll
     for (int j = 0; j < G::NI; ++j)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+      for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
   Stager<BM, G::THREADS> sa;
   Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;  // one dummy pass when the weights come by DMA
@@ -166,41 +170,45 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   }
   __syncthreads();
 
-  // One k16 step of the current buffer: (MI x NI) tiles x 3 MFMAs per wave.
-  auto k16_step = [&](const char* buf, int s) {
-    bf16x8 bh[G::NI], bl[G::NI];
+  // Row tiles [i0, i1) of the current buffer: 3 MFMAs per 16 x 16 tile, the whole K-block in one k-step.
+  bf16x8 bh[G::NI], bl[G::NI];
+  auto load_b = [&](const char* buf) {
 #pragma unroll
     for (int j = 0; j < G::NI; ++j) {
-      const int off = swz(wn * (BN / WN) + j * 32 + r, 2 * s + h);
+      const int off = swz(wn * (BN / WN) + j * 16 + r, c);
       bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + off);
       bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
     }
+  };
+  auto row_tiles = [&](const char* buf, int i0, int i1) {
 #pragma unroll
     for (int i = 0; i < G::MI; ++i) {
-      const int off = swz(wm * (BM / WM) + i * 32 + r, 2 * s + h);
+      if (i < i0 || i >= i1) continue;
+      const int off = swz(wm * (BM / WM) + i * 16 + r, c);
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
       const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
 #pragma unroll
       for (int j = 0; j < G::NI; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
       }
     }
   };
 
   // Steady state of iteration kb: tile kb is in LDS buffer kb & 1, tile kb+1 is in the staging registers
-  // (its loads were issued one full iteration ago).  Between the two k16 steps the staged tile is split
-  // and written to the other buffer and the loads of tile kb+2 are issued into the same registers, so
-  // every global load has a whole iteration of MFMA work to land under.  Weight planes (W_PLANES) go
-  // straight to the other buffer by LDS-DMA at the top of the iteration.
+  // (its loads were issued one full iteration ago).  Between the two halves of the row tiles the staged
+  // tile is split and written to the other buffer and the loads of tile kb+2 are issued into the same
+  // registers, so every global load has a whole iteration of MFMA work to land under.  Weight planes
+  // (W_PLANES) go straight to the other buffer by LDS-DMA at the top of the iteration.
   for (int kb = 0; kb < nkb; ++kb) {
     const int cur = kb & 1;
     const char* buf = smem + cur * G::BUF_BYTES;
     char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
     const bool more = kb + 1 < nkb;
     if (W_PLANES && more) dma.issue(nb + 2 * G::A_PLANE, kb + 1);
-    k16_step(buf, 0);
+    load_b(buf);
+    row_tiles(buf, 0, G::MI / 2);
     if (more) {
       sa.store(nb, nb + G::A_PLANE);
       if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
@@ -209,7 +217,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
         if (!W_PLANES) sb.load((kb + 2) * BK);
       }
     }
-    k16_step(buf, 1);
+    row_tiles(buf, G::MI / 2, G::MI);
     __syncthreads();  // also drains the LDS-DMA of this iteration (vmcnt(0))
   }
 
@@ -217,12 +225,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   for (int i = 0; i < G::MI; ++i)
 #pragma unroll
     for (int j = 0; j < G::NI; ++j) {
-      const int col = n0 + wn * (BN / WN) + j * 32 + r;
+      const int col = n0 + wn * (BN / WN) + j * 16 + r;  // C/D of a 16 x 16 tile: column lane & 15, row 4 (lane >> 4) + v
       if (col >= N) continue;
       const float bv = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int64_t row = m0 + wm * (BM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      for (int v = 0; v < 4; ++v) {
+        const int64_t row = m0 + wm * (BM / WM) + i * 16 + c * 4 + v;
         if (row < M) C[row * ldc + col] = acc[i][j][v] + bv;
       }
     }

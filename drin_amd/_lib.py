@@ -31,7 +31,7 @@ class DrinConfigC(C.Structure):
         ("entity_image_inner", C.c_int32), ("entity_object_inner", C.c_int32), ("num_layers", C.c_int32),
         ("dynamic_edges", C.c_int32), ("edge_enabled", C.c_float * 4), ("layer_norm_eps", C.c_float),
         ("cosine_eps", C.c_float), ("miei_eps", C.c_float), ("clip_scale", C.c_float), ("precision", C.c_int32),
-        ("num_entities", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("num_entities", C.c_int32), ("vector_edges", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -46,7 +46,7 @@ class DrinBatchC(C.Structure):
 
 
 class DrinLayerParamsC(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w_h", "b_h", "w_u", "b_u", "w_v", "b_v", "ln_weight", "ln_bias")]
+    _fields_ = [(n, C.c_void_p) for n in ("w_h", "b_h", "w_u", "b_u", "w_v", "b_v", "ln_weight", "ln_bias", "w_m", "b_m")]
 
 
 class DrinParamsC(C.Structure):

@@ -28,7 +28,7 @@ class DrinConfig:
     gcn_embed_dim: int = 768
     num_gcn_layers: int = 2
     gcn_edge_type: str = "dynamic"             # "static" | "dynamic"
-    gcn_edge_feature: str = "scaler"           # reference spelling; "vector" is not on the HIP path
+    gcn_edge_feature: str = "scaler"           # reference spelling; "vector": edges are [B, N, D] (model.py:112-116)
     gcn_edge_enabled: Tuple[float, float, float, float] = (1, 1, 1, 1)
     gcn_vertex_activation: str = "gelu"
     gcn_edge_activation: str = "sigmoid"
@@ -65,11 +65,10 @@ class DrinConfig:
             raise ValueError(f"unknown dataset_name {self.dataset_name!r}")
         if self.gcn_edge_type not in ("static", "dynamic"):
             raise ValueError(f"unknown gcn_edge_type {self.gcn_edge_type!r}")
-        if self.gcn_edge_feature != "scaler":
-            raise NotImplementedError(
-                "gcn_edge_feature='vector' (drin/model.py:112-116,151-152) is a paper ablation that is "
-                "not on the HIP path; only the default 'scaler' mode is built"
-            )
+        if self.gcn_edge_feature not in ("scaler", "vector"):
+            raise ValueError(f"unknown gcn_edge_feature {self.gcn_edge_feature!r} (reference spelling: 'scaler' | 'vector')")
+        if self.gcn_edge_feature == "vector" and self.gcn_embed_dim % 8:
+            raise ValueError("vector edges split gcn_embed_dim in two halves of 16-byte rows: it must be a multiple of 8")
         if self.gcn_vertex_activation != "gelu" or self.gcn_edge_activation != "sigmoid":
             raise NotImplementedError("only gelu vertex / sigmoid edge activations (args.py:35-36) are built")
         if self.gcn_embed_dim != self.bert_embed_dim:

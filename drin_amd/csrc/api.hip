@@ -76,6 +76,10 @@ int validate_config(const drin_config* c) {
     set_error("config: embed_dim=%d > 1024 is not built (LayerNorm row kept in registers)", c->embed_dim);
     return DRIN_E_UNSUPPORTED;
   }
+  if (c->vector_edges && (c->embed_dim % 8)) {
+    set_error("config: vector edges need embed_dim %% 8 == 0 (got %d)", c->embed_dim);
+    return DRIN_E_SHAPE;
+  }
   if (c->num_layers < 0 || c->num_layers > DRIN_MAX_LAYERS) {
     set_error("config: num_layers=%d outside [0, %d]", c->num_layers, DRIN_MAX_LAYERS);
     return DRIN_E_SHAPE;
@@ -142,6 +146,10 @@ static int validate_params(const drin_config* c, const drin_params* p) {
         set_error("params: layer %d tensor NULL or not 16-byte aligned", l);
         return q ? DRIN_E_ALIGN : DRIN_E_NULL;
       }
+    if (c->vector_edges && (!L.w_m || !L.b_m || !aligned16(L.w_m) || !aligned16(L.b_m))) {
+      set_error("params: layer %d w_m / b_m (vector edges, model.py:112) NULL or not 16-byte aligned", l);
+      return DRIN_E_NULL;
+    }
   }
   return DRIN_OK;
 }
@@ -219,13 +227,14 @@ static int copy_out(float* dst, const float* src, size_t n, hipStream_t st) {
   return DRIN_OK;
 }
 
-static int tap(const drin_trace* t, int l, const Layout& L, const float* ws, int B, int64_t M, int D, hipStream_t st) {
+static int tap(const drin_trace* t, int l, const Layout& L, const float* ws, int B, int64_t M, int D, hipStream_t st,
+               size_t edge_width = 1) {
   if (!t) return DRIN_OK;
   DRIN_TRY(copy_out(t->mention_text_vertex[l], ws + L.vm[l], (size_t)B * D, st));
   DRIN_TRY(copy_out(t->mention_image_vertex[l], ws + L.vm[l] + (size_t)B * D, (size_t)B * D, st));
   DRIN_TRY(copy_out(t->entity_text_vertex[l], ws + L.ve[l], (size_t)M * D, st));
   DRIN_TRY(copy_out(t->entity_image_vertex[l], ws + L.ve[l] + (size_t)M * D, (size_t)M * D, st));
-  DRIN_TRY(copy_out(t->edges[l], ws + L.edges[l], (size_t)4 * M, st));
+  DRIN_TRY(copy_out(t->edges[l], ws + L.edges[l], (size_t)4 * M * edge_width, st));
   return DRIN_OK;
 }
 
@@ -377,7 +386,15 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
 
   Pooled P;
   DRIN_TRY(run_pooling(cfg, batch, L, ws, &P, st));
-  DRIN_TRY(run_static_edges(cfg, batch, P, ws + L.edges[0], st));
+  const bool vec = cfg->vector_edges != 0;
+  const size_t EW = vec ? (size_t)D : 1;   // floats per edge per pair
+  const size_t ES = (size_t)M * EW;        // stride between the four edge types
+  if (vec) {  // model.py:202: the scalar edges are broadcast over the feature dimension
+    DRIN_TRY(run_static_edges(cfg, batch, P, ws + L.edges_scalar, st));
+    DRIN_TRY(launch_expand_edges(ws + L.edges_scalar, ws + L.edges[0], 4 * M, D, st));
+  } else {
+    DRIN_TRY(run_static_edges(cfg, batch, P, ws + L.edges[0], st));
+  }
 
   // VertexEncoder (model.py:26-46): four Linears
   float* vm0 = ws + L.vm[0];
@@ -390,7 +407,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
                           prec, st));
   DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
                           M, D, R, false, prec, st));
-  DRIN_TRY(tap(trace, 0, L, ws, B, M, D, st));
+  DRIN_TRY(tap(trace, 0, L, ws, B, M, D, st, EW));
 
   bool all_enabled = true;
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
@@ -403,10 +420,10 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     const float* e = ws + L.edges[l];
     if (!all_enabled) {  // edges = [e * m ...] (model.py:122)
       float* me = ws + L.masked[l];
-      for (int k = 0; k < 4; ++k) DRIN_TRY(launch_scale_div(e + k * M, me + k * M, M, cfg->edge_enabled[k], 1.0f, st));
+      for (int k = 0; k < 4; ++k) DRIN_TRY(launch_scale_div(e + k * ES, me + k * ES, (int64_t)ES, cfg->edge_enabled[k], 1.0f, st));
       e = me;
     }
-    const float *e_tt = e, *e_ti = e + M, *e_it = e + 2 * M, *e_ii = e + 3 * M;
+    const float *e_tt = e, *e_ti = e + ES, *e_it = e + 2 * ES, *e_ii = e + 3 * ES;
     const float* mt = ws + L.vm[l];
     const float* mi = mt + (size_t)B * D;
     const float* et = ws + L.ve[l];
@@ -414,11 +431,21 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     float* agg_m = ws + L.agg_m[l];
     float* agg_e = ws + L.agg_e[l];
     // neighbour aggregation, vertex_graph of model.py:105
-    DRIN_TRY(launch_mention_aggregate(e_tt, et, e_ti, ei, mt, agg_m, B, N, D, st));
-    DRIN_TRY(launch_entity_aggregate(e_tt, mt, e_it, mi, et, agg_e, B, N, D, st));
-    if (live_image) {
-      DRIN_TRY(launch_mention_aggregate(e_it, et, e_ii, ei, mi, agg_m + (size_t)B * D, B, N, D, st));
-      DRIN_TRY(launch_entity_aggregate(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
+    if (vec) {
+      const float inv_n = 1.0f / (float)N;
+      DRIN_TRY(launch_mention_reduce_vec(e_tt, et, e_ti, ei, mt, agg_m, B, N, D, inv_n, true, st));
+      DRIN_TRY(launch_entity_aggregate_vec(e_tt, mt, e_it, mi, et, agg_e, B, N, D, st));
+      if (live_image) {
+        DRIN_TRY(launch_mention_reduce_vec(e_it, et, e_ii, ei, mi, agg_m + (size_t)B * D, B, N, D, inv_n, true, st));
+        DRIN_TRY(launch_entity_aggregate_vec(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
+      }
+    } else {
+      DRIN_TRY(launch_mention_aggregate(e_tt, et, e_ti, ei, mt, agg_m, B, N, D, st));
+      DRIN_TRY(launch_entity_aggregate(e_tt, mt, e_it, mi, et, agg_e, B, N, D, st));
+      if (live_image) {
+        DRIN_TRY(launch_mention_aggregate(e_it, et, e_ii, ei, mi, agg_m + (size_t)B * D, B, N, D, st));
+        DRIN_TRY(launch_entity_aggregate(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
+      }
     }
     const int types = live_image ? 2 : 1;
     // shared W_h + LayerNorm + GELU for all vertex types of the layer (model.py:128)
@@ -434,7 +461,18 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
                                    (int64_t)types * M, D, cfg->layer_norm_eps, st));
     // dynamic edges, edge_graph of model.py:107: (mt,et) (mt,ei) (mi,et) (mi,ei)
     float* e_next = ws + L.edges[l + 1];
-    if (live_edges) {
+    if (live_edges && vec) {
+      // model.py:150-152,133: cat(W_u(u), W_v(v)) + e -> W_m -> sigmoid, W_u / W_v: D -> D/2
+      float* fu = ws + L.fu[l];
+      float* fv = ws + L.fv[l];
+      float* pre = ws + L.pre[l];
+      const int H = D / 2;
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, H, 2 * (int64_t)B, H, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, H, 2 * M, H, D, false, prec, st));
+      DRIN_TRY(launch_edge_pre_vec(fu, fv, e, pre, B, N, D, st));
+      DRIN_TRY(launch_gemm_nt(pre, D, W.w_m, D, W.b_m, e_next, D, 4 * M, D, D, false, prec, st));
+      DRIN_TRY(launch_sigmoid_inplace(e_next, 4 * M * D, st));
+    } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
       DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st));
@@ -445,10 +483,10 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
         DRIN_TRY(launch_edge_update(fuk, fvk, e + k * M, e_next + k * M, B, N, D, st));
       }
     } else if (!cfg->dynamic_edges) {
-      hipError_t err = hipMemcpyAsync(e_next, e, 4 * M * sizeof(float), hipMemcpyDeviceToDevice, st);
+      hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);
       if (err != hipSuccess) return hip_fail(err, "hipMemcpyAsync(static edges)");
     }
-    if (full) DRIN_TRY(tap(trace, l + 1, L, ws, B, M, D, st));
+    if (full) DRIN_TRY(tap(trace, l + 1, L, ws, B, M, D, st, EW));
   }
   // score (model.py:207-209)
   return launch_cosine_rows(ws + L.vm[nl], ws + L.ve[nl], D, scores, B, N, D, cfg->cosine_eps, 1.0f, st);
@@ -557,12 +595,14 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   };
   float* g_vm[2] = {carve(2 * BD), carve(2 * BD)};
   float* g_ve[2] = {carve(2 * MD), carve(2 * MD)};
-  float* g_e[2] = {carve(4 * M), carve(4 * M)};
+  const bool vec = cfg->vector_edges != 0;
+  const size_t EW = vec ? (size_t)D : 1, ES = M * EW;  // floats per edge per pair, stride between edge types
+  float* g_e[2] = {carve(4 * ES), carve(4 * ES)};
   float* dA_m = carve(2 * BD);
   float* dA_e = carve(2 * MD);
   float* dfu = carve(2 * BD);
   float* dfv = carve(2 * MD);
-  float* dpre = carve(4 * M);
+  float* dpre = carve(4 * ES);
   float* cos_scratch = carve(3 * M);
   if ((size_t)(sp - (ws + L.bwd_scratch)) > L.bwd_scratch_floats) {
     set_error("internal: backward scratch overflow");
@@ -613,7 +653,20 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     const float* ei = et + MD;
     const bool edge_update = cfg->dynamic_edges && have_edge;  // this layer's edge update is live
     const float* de_extra = nullptr;
-    if (edge_update) {
+    if (edge_update && vec) {
+      // (d, vector edges) e' = sigmoid(W_m(cat(W_u(u), W_v(v)) + e) + b_m)  (model.py:150-152,133)
+      const int H = D / 2;
+      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st));         // dz
+      if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st));
+      DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st));
+      DRIN_TRY(launch_gemm_nn(dpre, D, W.w_m, D, g_e[cur], D, 4 * (int64_t)M, D, D, false, prec, st));  // d(cat + e)
+      DRIN_TRY(launch_edge_pre_vec_bwd(g_e[cur], dfu, dfv, B, N, D, st));
+      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, H, et, D, G.w_v, D, 2 * (int64_t)M, H, D, prec, st));
+      DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, H, st));
+      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, H, mt, D, G.w_u, D, 2 * (int64_t)B, H, D, prec, st));
+      DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, H, st));
+      de_extra = g_e[cur];
+    } else if (edge_update) {
       // (d) e'_k = sigmoid(mean_d(fu fv) + e_k)  (model.py:148-153,133)
       DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)M, st));
       const float* fu = ws + L.fu[l];
@@ -633,14 +686,26 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     } else if (!cfg->dynamic_edges && have_edge) {
       de_extra = g_e[cur];  // static edges pass through (model.py:136)
     }
-    // (e) entity side of the aggregation backward + edge gradients
-    DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
-                                    g_e[nxt], B, N, D, cfg->edge_enabled, st));
-    if (edge_update) DRIN_TRY(launch_gemm_nn(dfv, D, W.w_v, D, g_ve[nxt], D, 2 * (int64_t)M, D, D, true, prec, st));
-    // (f) mention side
-    DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
-    DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
-    if (edge_update) DRIN_TRY(launch_gemm_nn(dfu, D, W.w_u, D, g_vm[nxt], D, 2 * (int64_t)B, D, D, true, prec, st));
+    if (vec) {
+      const int H = D / 2;
+      // (e) entity side of the aggregation backward + edge gradients, element-wise with vector edges
+      DRIN_TRY(launch_entity_side_bwd_vec(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt],
+                                          g_ve[nxt] + MD, g_e[nxt], B, N, D, cfg->edge_enabled, st));
+      if (edge_update) DRIN_TRY(launch_gemm_nn(dfv, H, W.w_v, D, g_ve[nxt], D, 2 * (int64_t)M, D, H, true, prec, st));
+      // (f) mention side
+      DRIN_TRY(launch_mention_reduce_vec(e, dA_et, e + ES, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, false, st));
+      DRIN_TRY(launch_mention_reduce_vec(e + 2 * ES, dA_et, e + 3 * ES, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, false, st));
+      if (edge_update) DRIN_TRY(launch_gemm_nn(dfu, H, W.w_u, D, g_vm[nxt], D, 2 * (int64_t)B, D, H, true, prec, st));
+    } else {
+      // (e) entity side of the aggregation backward + edge gradients
+      DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
+                                      g_e[nxt], B, N, D, cfg->edge_enabled, st));
+      if (edge_update) DRIN_TRY(launch_gemm_nn(dfv, D, W.w_v, D, g_ve[nxt], D, 2 * (int64_t)M, D, D, true, prec, st));
+      // (f) mention side
+      DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
+      DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
+      if (edge_update) DRIN_TRY(launch_gemm_nn(dfu, D, W.w_u, D, g_vm[nxt], D, 2 * (int64_t)B, D, D, true, prec, st));
+    }
     have_image = true;
     have_edge = true;
     cur = nxt;

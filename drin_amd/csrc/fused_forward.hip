@@ -104,6 +104,10 @@ static int fused_supported(const drin_config* c) {
     set_error("fused path: built for num_layers == 2 (got %d); use drin_forward", c->num_layers);
     return DRIN_E_UNSUPPORTED;
   }
+  if (c->vector_edges) {
+    set_error("fused path: vector edge features (model.py:112-116) run on the layer-by-layer path; use drin_forward");
+    return DRIN_E_UNSUPPORTED;
+  }
   if (c->mention_object_inner > 1 || c->entity_object_inner > 1 || c->entity_image_inner > 1) {
     set_error("fused path: inner feature dims > 1 need the pooled path of drin_forward");
     return DRIN_E_UNSUPPORTED;

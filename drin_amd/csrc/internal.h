@@ -113,4 +113,19 @@ int launch_entity_side_bwd(const float* dA_mt, const float* dA_mi, const float* 
                            const float* de_extra, float* d_et, float* d_ei, float* de, int B, int N, int D,
                            const float* mask, hipStream_t st);
 
+// ---- vector-edge ablation (vector_kernels.hip) --------------------------------------------------
+int launch_expand_edges(const float* es, float* out, int64_t pairs4, int D, hipStream_t st);
+int launch_mention_reduce_vec(const float* w1, const float* v1, const float* w2, const float* v2, const float* u,
+                              float* out, int B, int N, int D, float scale, bool mean_style, hipStream_t st);
+int launch_entity_aggregate_vec(const float* e1, const float* m1, const float* e2, const float* m2, const float* v,
+                                float* out, int B, int N, int D, hipStream_t st);
+int launch_edge_pre_vec(const float* fu, const float* fv, const float* e, float* pre, int B, int N, int D,
+                        hipStream_t st);
+int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st);
+int launch_edge_pre_vec_bwd(const float* dpre, float* dfu, float* dfv, int B, int N, int D, hipStream_t st);
+int launch_entity_side_bwd_vec(const float* dA_mt, const float* dA_mi, const float* dA_et, const float* dA_ei,
+                               const float* mt, const float* mi, const float* et, const float* ei, const float* e,
+                               const float* de_extra, float* d_et, float* d_ei, float* de, int B, int N, int D,
+                               const float* mask, hipStream_t st);
+
 }  // namespace drin

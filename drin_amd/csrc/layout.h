@@ -38,6 +38,8 @@ struct Layout {
   size_t ln_stat_e[DRIN_MAX_LAYERS] = {};   // [2][2][M]
   size_t fu[DRIN_MAX_LAYERS] = {};          // [2][B][D]  W_u(mt), W_u(mi)
   size_t fv[DRIN_MAX_LAYERS] = {};          // [2][M][D]  W_v(et), W_v(ei)
+  size_t edges_scalar = 0;                  // [4][M]     scalar static edges before model.py:202 expands them (vector edges)
+  size_t pre[DRIN_MAX_LAYERS] = {};         // [4][M][D]  W_m input cat(fu, fv) + e (vector edges)
   size_t bwd_scratch = 0;                   // backward temporaries (training only)
   size_t bwd_scratch_floats = 0;
 
@@ -53,6 +55,8 @@ struct Layout {
     const size_t B = (size_t)c.batch, N = (size_t)c.num_candidates, D = (size_t)c.embed_dim, R = (size_t)c.image_dim;
     const size_t M = B * N;
     const int nl = c.num_layers;
+    const size_t EW = c.vector_edges ? D : 1;  // floats per edge per pair
+    edges_scalar = take(c.vector_edges ? 4 * M : 0);
     span_mean = take(B * D);
     mimg_pool = take(B * R);
     mobj_pool = take(c.mention_object_inner > 1 ? B * c.mention_objects * R : 0);
@@ -61,12 +65,13 @@ struct Layout {
     xet_pool = take(c.entity_tokens > 0 ? M * D : 0);
     if (train) {
       for (int l = 0; l <= nl; ++l) {
-        edges[l] = take(4 * M);
+        edges[l] = take(4 * M * EW);
         vm[l] = take(2 * B * D);
         ve[l] = take(2 * M * D);
       }
       for (int l = 0; l < nl; ++l) {
-        masked[l] = take(4 * M);
+        masked[l] = take(4 * M * EW);
+        pre[l] = take(c.vector_edges ? 4 * M * D : 0);
         agg_m[l] = take(2 * B * D);
         agg_e[l] = take(2 * M * D);
         h_m[l] = take(2 * B * D);
@@ -77,10 +82,10 @@ struct Layout {
         fv[l] = take(2 * M * D);
       }
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
-      bwd_scratch_floats = 4 * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M + 64) + (3 * M + 64);
+      bwd_scratch_floats = 4 * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
       bwd_scratch = take(bwd_scratch_floats);
     } else {
-      size_t e2[2] = {take(4 * M), take(4 * M)};
+      size_t e2[2] = {take(4 * M * EW), take(4 * M * EW)};
       size_t vm2[2] = {take(2 * B * D), take(2 * B * D)};
       size_t ve2[2] = {take(2 * M * D), take(2 * M * D)};
       for (int l = 0; l <= nl; ++l) {
@@ -88,10 +93,12 @@ struct Layout {
         vm[l] = vm2[l & 1];
         ve[l] = ve2[l & 1];
       }
-      const size_t s_masked = take(4 * M), s_agg_m = take(2 * B * D), s_agg_e = take(2 * M * D);
+      const size_t s_masked = take(4 * M * EW), s_agg_m = take(2 * B * D), s_agg_e = take(2 * M * D);
       const size_t s_fu = take(2 * B * D);
+      const size_t s_pre = take(c.vector_edges ? 4 * M * D : 0);
       for (int l = 0; l < nl; ++l) {
         masked[l] = s_masked;
+        pre[l] = s_pre;
         agg_m[l] = s_agg_m;
         agg_e[l] = s_agg_e;
         // pre-LN values are written straight into the next vertex buffer and normalised in place

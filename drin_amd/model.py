@@ -53,8 +53,11 @@ class GCNLayer(nn.Module):  # drin/model.py:109-119 (scaler edges: w_m is Identi
     def __init__(self, cfg: DrinConfig):
         super().__init__()
         d = cfg.gcn_embed_dim
+        vector = cfg.gcn_edge_feature == "vector"
         self.w_h = nn.Linear(d, d)
-        self.w_u, self.w_v = [nn.Linear(d, d) for _ in range(2)]
+        if vector:
+            self.w_m = nn.Linear(d, d)                                      # model.py:112
+        self.w_u, self.w_v = [nn.Linear(d, d // 2 if vector else d) for _ in range(2)]   # model.py:113-116
         self.layer_norm = nn.LayerNorm(d)
 
 
@@ -73,18 +76,21 @@ def _param_list(model: "Model") -> List[torch.Tensor]:
     for layer in model.gcn_layers:
         ps += [layer.w_h.weight, layer.w_h.bias, layer.w_u.weight, layer.w_u.bias, layer.w_v.weight, layer.w_v.bias,
                layer.layer_norm.weight, layer.layer_norm.bias]
+        if hasattr(layer, "w_m"):
+            ps += [layer.w_m.weight, layer.w_m.bias]
     return ps
 
 
-def _fill_params(struct, tensors: Sequence[Optional[torch.Tensor]]) -> None:
+def _fill_params(struct, tensors: Sequence[Optional[torch.Tensor]], per_layer: int = 8) -> None:
+    """`per_layer`: 8 tensors per GCN layer, 10 with vector edges (w_m, b_m appended)."""
     names = ("w_mention_text", "b_mention_text", "w_entity_text", "b_entity_text",
              "w_mention_image", "b_mention_image", "w_entity_image", "b_entity_image")
     for n, t in zip(names, tensors[:8]):
         setattr(struct, n, _ptr(t))
-    lnames = ("w_h", "b_h", "w_u", "b_u", "w_v", "b_v", "ln_weight", "ln_bias")
-    for l in range((len(tensors) - 8) // 8):
+    lnames = ("w_h", "b_h", "w_u", "b_u", "w_v", "b_v", "ln_weight", "ln_bias", "w_m", "b_m")[:per_layer]
+    for l in range((len(tensors) - 8) // per_layer):
         for j, n in enumerate(lnames):
-            setattr(struct.layer[l], n, _ptr(tensors[8 + 8 * l + j]))
+            setattr(struct.layer[l], n, _ptr(tensors[8 + per_layer * l + j]))
 
 
 class EntityTable:
@@ -212,6 +218,8 @@ class _Call:
             cfg.layer_norm_eps, cfg.cosine_eps, cfg.miei_eps, cfg.clip_logit_scale)
         c.precision = precision
         c.num_entities = etf.shape[0] if table else 0
+        c.vector_edges = 1 if cfg.gcn_edge_feature == "vector" else 0
+        self.per_layer = 10 if c.vector_edges else 8
         self.cfg = c
         b = _lib.DrinBatchC()
         for name, t in zip(("mention_text", "mention_start", "mention_end", "mention_image", "mention_object",
@@ -256,7 +264,7 @@ class _DrinScore(torch.autograd.Function):
         versions = params
         params = tuple(p.detach().contiguous() for p in params)
         pc = _lib.DrinParamsC()
-        _fill_params(pc, params)
+        _fill_params(pc, params, call.per_layer)
         if not training and prepared is not None and lib.drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
             # inference: fused two-layer path on weights folded once per weight version
             pbuf = prepared.get(call, versions, pc)
@@ -281,19 +289,20 @@ class _DrinScore(torch.autograd.Function):
         call, params = ctx.call, ctx.params
         grads = [torch.zeros_like(p) for p in params]
         gc = _lib.DrinParamGradsC()
-        _fill_params(gc, grads)
+        _fill_params(gc, grads, call.per_layer)
         g = grad_scores.to(torch.float32).contiguous()
         stream = torch.cuda.current_stream(call.device).cuda_stream
         _lib.check(lib.drin_backward(C.byref(call.cfg), C.byref(call.batch), C.byref(ctx.pc), ctx.ws.data_ptr(),
                                      ctx.ws.numel(), g.data_ptr(), C.byref(gc), stream))
-        nl = (len(params) - 8) // 8
+        pl = call.per_layer
+        nl = (len(params) - 8) // pl
         out = list(grads)
         # parameters the score does not depend on get no gradient at all in the reference (.grad is None):
-        # the last layer's edge update is dead (model.py:130-134), and static edges never use w_u / w_v
+        # the last layer's edge update is dead (model.py:130-134), and static edges never use w_u / w_v (/ w_m)
         dead_layers = range(nl) if not call.cfg.dynamic_edges else range(nl - 1, nl)
         for l in dead_layers:
-            for j in (2, 3, 4, 5):
-                out[8 + 8 * l + j] = None
+            for j in (2, 3, 4, 5) + ((8, 9) if pl == 10 else ()):
+                out[8 + pl * l + j] = None
         return (None, None, None, *out)
 
 
@@ -342,14 +351,15 @@ class Model(nn.Module):
         call = _Call(self.cfg, batch, self.precision)
         params = tuple(p.detach().contiguous() for p in _param_list(self))
         pc = _lib.DrinParamsC()
-        _fill_params(pc, params)
+        _fill_params(pc, params, call.per_layer)
         B, N, D, nl, dev = call.B, call.N, call.D, self.cfg.num_gcn_layers, call.device
+        edge_shape = (4, B, N, D) if call.cfg.vector_edges else (4, B, N)
         tr = _lib.DrinTraceC()
         out: Dict[str, torch.Tensor] = {}
         for l in range(nl + 1):
             for field, key, shape in (("mention_text_vertex", f"mt{l}", (B, D)), ("mention_image_vertex", f"mi{l}", (B, D)),
                                       ("entity_text_vertex", f"et{l}", (B, N, D)), ("entity_image_vertex", f"ei{l}", (B, N, D)),
-                                      ("edges", f"edges{l}", (4, B, N))):
+                                      ("edges", f"edges{l}", edge_shape)):
                 t = torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
                 out[key] = t
                 getattr(tr, field)[l] = t.data_ptr()

@@ -99,7 +99,7 @@ def make_batch(
     return seq
 
 
-STATE_DICT_SHAPES = lambda D, R, layers: (  # noqa: E731 - SURVEY.md §8(b) state_dict contract
+STATE_DICT_SHAPES = lambda D, R, layers, vector=False: (  # noqa: E731 - SURVEY.md §8(b) state_dict contract
     [
         ("vertex_encoder.mention_text_encoder.final_layer.linear.weight", (D, D)),
         ("vertex_encoder.mention_text_encoder.final_layer.linear.bias", (D,)),
@@ -114,14 +114,11 @@ STATE_DICT_SHAPES = lambda D, R, layers: (  # noqa: E731 - SURVEY.md §8(b) stat
         (f"gcn_layers.{l}.{name}", shape)
         for l in range(layers)
         for name, shape in (
-            ("w_h.weight", (D, D)),
-            ("w_h.bias", (D,)),
-            ("w_u.weight", (D, D)),
-            ("w_u.bias", (D,)),
-            ("w_v.weight", (D, D)),
-            ("w_v.bias", (D,)),
-            ("layer_norm.weight", (D,)),
-            ("layer_norm.bias", (D,)),
+            [("w_h.weight", (D, D)), ("w_h.bias", (D,))]
+            + ([("w_m.weight", (D, D)), ("w_m.bias", (D,))] if vector else [])   # model.py:112
+            + [("w_u.weight", (D // 2 if vector else D, D)), ("w_u.bias", (D // 2 if vector else D,)),
+               ("w_v.weight", (D // 2 if vector else D, D)), ("w_v.bias", (D // 2 if vector else D,)),
+               ("layer_norm.weight", (D,)), ("layer_norm.bias", (D,))]
         )
     ]
 )
@@ -136,7 +133,8 @@ def make_state_dict(cfg: DrinConfig, seed: int = 7, as_torch: bool = True) -> Di
     g = _rng(seed, 1)
     sd: Dict[str, np.ndarray] = {}
     fan_in = None
-    for key, shape in STATE_DICT_SHAPES(cfg.gcn_embed_dim, cfg.resnet_embed_dim, cfg.num_gcn_layers):
+    for key, shape in STATE_DICT_SHAPES(cfg.gcn_embed_dim, cfg.resnet_embed_dim, cfg.num_gcn_layers,
+                                        cfg.gcn_edge_feature == "vector"):
         if "layer_norm.weight" in key:
             v = 1.0 + 0.1 * _normal(g, shape)
         elif "layer_norm.bias" in key:

@@ -75,7 +75,9 @@ typedef struct {
   float clip_scale;         /* 100   (model.py:203)                                               */
   int32_t precision;        /* drin_precision                                                     */
   int32_t num_entities;     /* rows of the entity TABLES when drin_batch.entity_index is set, else 0    */
-  int32_t reserved[2];
+  int32_t vector_edges;     /* gcn_edge_feature == "vector" (args.py:33): edges are [B, N, D], w_m is a Linear,
+                               w_u / w_v map D -> D/2 (model.py:112-116,151-152).  Layer-by-layer path only. */
+  int32_t reserved[1];
 } drin_config;
 
 /* The 14 tensors `Model.forward` unpacks (drin/model.py:165-180), device pointers.
@@ -105,6 +107,7 @@ typedef struct {
 /* One GCNLayer's parameters (drin/model.py:109-119); nn.Linear layout weight[out][in]. */
 typedef struct {
   const float *w_h, *b_h, *w_u, *b_u, *w_v, *b_v, *ln_weight, *ln_bias;
+  const float *w_m, *b_m; /* vector edges only (model.py:112): [D, D], [D]; then w_u / w_v are [D/2, D] */
 } drin_layer_params;
 
 #define DRIN_MAX_LAYERS 8
@@ -124,7 +127,7 @@ typedef struct {
 typedef struct {
   float *w_mention_text, *b_mention_text, *w_entity_text, *b_entity_text;
   float *w_mention_image, *b_mention_image, *w_entity_image, *b_entity_image;
-  struct { float *w_h, *b_h, *w_u, *b_u, *w_v, *b_v, *ln_weight, *ln_bias; } layer[DRIN_MAX_LAYERS];
+  struct { float *w_h, *b_h, *w_u, *b_u, *w_v, *b_v, *ln_weight, *ln_bias, *w_m, *b_m; } layer[DRIN_MAX_LAYERS];
 } drin_param_grads;
 
 /* Optional taps of intermediate values for tests/debugging (any pointer may be NULL).
@@ -134,7 +137,7 @@ typedef struct {
   float* mention_image_vertex[DRIN_MAX_LAYERS + 1]; /* [B, D]    */
   float* entity_text_vertex[DRIN_MAX_LAYERS + 1];   /* [B, N, D] */
   float* entity_image_vertex[DRIN_MAX_LAYERS + 1];  /* [B, N, D] */
-  float* edges[DRIN_MAX_LAYERS + 1];                /* [4, B, N] order tt, ti, it, ii */
+  float* edges[DRIN_MAX_LAYERS + 1];                /* [4, B, N] ([4, B, N, D] with vector edges) order tt, ti, it, ii */
 } drin_trace;
 
 /* ---- housekeeping ------------------------------------------------------------------------- */

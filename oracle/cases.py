@@ -18,6 +18,9 @@ CASES = {
     "tiny_wd_static": (DrinConfig(gcn_edge_type="static", **TINY), 3, 6, 8, True, True),
     "tiny_wd_layers1": (DrinConfig(num_gcn_layers=1, **TINY), 3, 7, 8, True, True),
     "tiny_wd_layers3": (DrinConfig(num_gcn_layers=3, **TINY), 3, 8, 8, True, True),
+    "tiny_wd_vector": (DrinConfig(gcn_edge_feature="vector", **TINY), 3, 12, 8, True, True),
+    "tiny_wm_vector_static": (DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6,
+                                         gcn_edge_feature="vector", gcn_edge_type="static", **TINY), 2, 13, 8, True, True),
     "tiny_wm_n37": (DrinConfig(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=9, **TINY), 4, 9, 8, True, False),
 }
 

@@ -106,8 +106,9 @@ def edge_encoder(batch: Sequence[torch.Tensor], cos_eps: float = 1e-8, miei_eps:
 
 
 def gcn_layer(p: Dict[str, torch.Tensor], l: int, vertexes: List[torch.Tensor], edges: List[torch.Tensor],
-              edge_enabled: Sequence[float], dynamic: bool, ln_eps: float = 1e-5):
-    """`GCNLayer.forward` (drin/model.py:121-153), scaler-edge mode."""
+              edge_enabled: Sequence[float], dynamic: bool, ln_eps: float = 1e-5, vector: bool = False):
+    """`GCNLayer.forward` (drin/model.py:121-153).  `vector`: gcn_edge_feature == "vector" - edges are
+    [B, N, D] (model.py:140-141 skipped), w_u / w_v map to D/2 and are concatenated (:151-152), w_m is a Linear (:112)."""
     pre = f"gcn_layers.{l}."
     D = vertexes[0].shape[-1]
     edges = [e * m for e, m in zip(edges, edge_enabled)]               # :122
@@ -115,7 +116,7 @@ def gcn_layer(p: Dict[str, torch.Tensor], l: int, vertexes: List[torch.Tensor], 
     for u, nb in zip(vertexes, VERTEX_GRAPH):                          # :124-129
         acc = torch.zeros_like(u)
         for ei, vi in nb:
-            e, v = edges[ei][..., None], vertexes[vi]
+            e, v = (edges[ei] if vector else edges[ei][..., None]), vertexes[vi]
             if v.dim() == 3:
                 acc = acc + (e * v).mean(1)                            # mention <- entity  :143-144
             else:
@@ -128,6 +129,10 @@ def gcn_layer(p: Dict[str, torch.Tensor], l: int, vertexes: List[torch.Tensor], 
         for e, (ui, vi) in zip(edges, EDGE_GRAPH):
             fu = F.linear(vertexes[ui], p[pre + "w_u.weight"], p[pre + "w_u.bias"])
             fv = F.linear(vertexes[vi], p[pre + "w_v.weight"], p[pre + "w_v.bias"])
+            if vector:                                                 # :151-152 then w_m Linear (:112,133)
+                cat = torch.cat([fu[:, None, :].expand(-1, fv.shape[1], -1), fv], dim=-1)
+                new_e.append(torch.sigmoid(F.linear(cat + e, p[pre + "w_m.weight"], p[pre + "w_m.bias"])))
+                continue
             new_e.append(torch.sigmoid((fu[:, None, :] * fv).mean(-1) + e))   # :148-153, w_m = Identity :112
     else:
         new_e = edges                                                  # :136
@@ -136,7 +141,7 @@ def gcn_layer(p: Dict[str, torch.Tensor], l: int, vertexes: List[torch.Tensor], 
 
 def forward(p: Dict[str, torch.Tensor], batch: Sequence[torch.Tensor], *, token_level: Optional[bool] = None,
             num_layers: int = 2, edge_enabled: Sequence[float] = (1, 1, 1, 1), dynamic: bool = True,
-            dtype: torch.dtype = torch.float32, trace: Optional[dict] = None) -> torch.Tensor:
+            dtype: torch.dtype = torch.float32, trace: Optional[dict] = None, vector: bool = False) -> torch.Tensor:
     """`Model.forward` (drin/model.py:164-209) -> scores [B, N]."""
     batch = [t.to(dtype) if t.is_floating_point() else t for t in batch[:14]]
     p = {k: v.to(dtype) for k, v in p.items()}
@@ -145,11 +150,14 @@ def forward(p: Dict[str, torch.Tensor], batch: Sequence[torch.Tensor], *, token_
     vertexes = vertex_encoder(p, batch, token_level)                   # :181-190
     mtet, miei = edge_encoder(batch)                                   # :191-200
     edges = [mtet, batch[13] / 100, batch[12] / 100, miei]             # :201-204  (tt, ti, it, ii)
+    if vector:                                                         # :202
+        D = vertexes[0].shape[-1]
+        edges = [e.unsqueeze(-1).expand(-1, -1, D) for e in edges]
     if trace is not None:
         trace["vertex0"] = [v.clone() for v in vertexes]
         trace["edge0"] = [e.clone() for e in edges]
     for l in range(num_layers):                                        # :205-206
-        vertexes, edges = gcn_layer(p, l, vertexes, edges, edge_enabled, dynamic)
+        vertexes, edges = gcn_layer(p, l, vertexes, edges, edge_enabled, dynamic, vector=vector)
         if trace is not None:
             trace[f"vertex{l + 1}"] = [v.clone() for v in vertexes]
             trace[f"edge{l + 1}"] = [e.clone() for e in edges]

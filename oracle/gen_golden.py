@@ -186,6 +186,12 @@ def main():
     dst = os.path.join(REPO, "tests", "golden")
     os.makedirs(dst, exist_ok=True)
     torch.set_num_threads(8)
+    only = sys.argv[1:]
+    if only:  # regenerate just the named cases
+        for name in only:
+            np.savez_compressed(os.path.join(dst, f"{name}.npz"), **run_case(name))
+            print("wrote", name)
+        return
     for name in CASES:
         np.savez_compressed(os.path.join(dst, f"{name}.npz"), **run_case(name))
         print("wrote", name)

@@ -171,8 +171,13 @@ def test_forward_matches_reference_golden(golden_dir, name):
     assert err <= 2e-5, "fp32 MFMA path should sit at fp32 rounding level, far inside the 1e-4 budget"
     full = CASES[name][4]
     nl = cfg.num_gcn_layers
-    np.testing.assert_allclose(out["edges0"][0].numpy(), g["mtet"], atol=2e-6)
-    np.testing.assert_allclose(out["edges0"][3].numpy(), g["miei"], atol=2e-6)
+    e0 = out["edges0"]
+    if cfg.gcn_edge_feature == "vector":      # model.py:182-183 repeats the scalar edge along the embedding
+        assert e0.shape == (4, e0.shape[1], cfg.num_candidates_model, cfg.gcn_embed_dim)
+        assert torch.equal(e0, e0[..., :1].expand_as(e0))
+        e0 = e0[..., 0]
+    np.testing.assert_allclose(e0[0].numpy(), g["mtet"], atol=2e-6)
+    np.testing.assert_allclose(e0[3].numpy(), g["miei"], atol=2e-6)
     for l in range(nl + 1):
         np.testing.assert_allclose(out[f"mt{l}"].numpy(), g[f"mt{l}"], atol=2e-5, rtol=1e-4)
         np.testing.assert_allclose(out[f"mi{l}"].numpy(), g[f"mi{l}"], atol=2e-5, rtol=1e-4)
@@ -421,6 +426,39 @@ def test_backward_vs_oracle_autograd_reference_batch():
         denom = r.norm().item() + 1e-12
         rel = (got - r).norm().item() / denom
         assert rel <= 2e-3, (k, rel)
+
+
+@pytest.mark.parametrize("maker,B,edge_type", [(DrinConfig, 16, "dynamic"), (wikimel_config, 3, "dynamic"), (DrinConfig, 5, "static")])
+def test_vector_edges_vs_oracle(maker, B, edge_type):
+    """gcn_edge_feature="vector" (model.py:112-116,136-149) at the reference's widths: scores and every
+    parameter gradient against autograd through the oracle; the Module never takes the folded path."""
+    from drin_amd.metrics import TripletLoss
+    cfg = maker(gcn_edge_feature="vector", gcn_edge_type=edge_type)
+    sd = synth.make_state_dict(cfg, 17)
+    batch = synth.make_batch(cfg, B, 47)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_scores = O.forward(p, batch, dynamic=edge_type == "dynamic", vector=True)
+    ref_loss = O.triplet_loss(batch[-1], ref_scores, cfg.triplet_margin)
+    ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
+    model = Model(cfg).to(DEV)
+    model.load_state_dict(sd)
+    dbatch = _to_dev(batch)
+    with torch.no_grad():
+        _lib.profile_begin()
+        s = model(dbatch[:-1])
+        prof = _lib.profile_end()
+    assert prof["stream"][1] == 0, "vector edges are not folded: the layer-by-layer path must run"
+    err = (s.cpu() - ref_scores.detach()).abs().max().item()
+    print(f"vector {cfg.dataset_name} {edge_type}: max |score - oracle| = {err:.3e}")
+    assert err <= 2e-5
+    loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5
+    grads = _grads_of(model, loss)
+    for (k, got), r in zip(grads.items(), ref):
+        assert (got is None) == (r is None), k
+        if r is not None:
+            rel = (got - r).norm().item() / (r.norm().item() + 1e-12)
+            assert rel <= 2e-3, (k, rel)
 
 
 def test_training_loop_on_device_tracks_cpu_oracle_loop(tmp_path):

@@ -27,8 +27,9 @@ def test_config_defaults_follow_reference_args():
     assert wd.metrics_topk == (1, 3, 5) and wm.metrics_topk == (1, 5, 10, 20, 50)    # args.py:114,120
     assert wd.batch_size == wm.batch_size == 64 and wd.learning_rate == 1e-3 and wd.triplet_margin == 0.25
     assert abs(wd.acc_correction[0] - 2292 / 13205) < 1e-12
-    with pytest.raises(NotImplementedError):
-        DrinConfig(gcn_edge_feature="vector").validate()
+    DrinConfig(gcn_edge_feature="vector").validate()                                 # args.py:30 spelling "scaler" | "vector"
+    with pytest.raises(ValueError):
+        DrinConfig(gcn_edge_feature="scalar").validate()
 
 
 def test_state_dict_contract():
@@ -38,6 +39,12 @@ def test_state_dict_contract():
     assert list(sd) == [k for k, _ in synth.STATE_DICT_SHAPES(768, 2048, 2)]
     assert [tuple(v.shape) for v in sd.values()] == [s for _, s in synth.STATE_DICT_SHAPES(768, 2048, 2)]
     assert sum(v.numel() for v in sd.values()) == 7_875_072
+    # vector edges (model.py:112-116): w_m between w_h and w_u, half-width w_u / w_v
+    cfg = DrinConfig(gcn_edge_feature="vector", **TINY)
+    sd = Model(cfg).state_dict()
+    want = synth.STATE_DICT_SHAPES(64, 128, 2, True)
+    assert list(sd) == [k for k, _ in want] and [tuple(v.shape) for v in sd.values()] == [s for _, s in want]
+    assert tuple(sd["gcn_layers.0.w_u.weight"].shape) == (32, 64) and "gcn_layers.1.w_m.bias" in sd
 
 
 def test_model_refuses_to_run_without_gpu_tensors():

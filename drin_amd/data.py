@@ -18,11 +18,14 @@ from torch.utils.data import DataLoader, Dataset
 
 from . import synth
 from .config import DrinConfig
+from .npy_stream import NpyWriter, open_npy
 
 SPLITS = ("train", "valid", "test")
 
 
 def _load(path: str, mmap: Optional[str] = None) -> np.ndarray:
+    if mmap == "r":
+        return open_npy(path)          # header checked against the file size first (unclosed / truncated writers)
     return np.load(path, mmap_mode=mmap)
 
 
@@ -209,7 +212,15 @@ def write_synthetic_dataset(cfg: DrinConfig, root: str, sizes=(256, 64, 64), see
     """
     os.makedirs(root, exist_ok=True)
     N = cfg.num_candidates_model
-    save = lambda name, arr: np.save(os.path.join(root, name), arr)  # noqa: E731
+
+    def save(name, arr):
+        arr = np.asarray(arr)
+        if arr.dtype.kind not in "iuf":                      # QID strings: not a streaming-writer type (utils.py:148-166)
+            np.save(os.path.join(root, name), arr)
+            return
+        with NpyWriter(os.path.join(root, name)) as w:       # item by item, as preprocess/*.py write them
+            w.extend(arr if arr.ndim > 1 else (np.asarray(v) for v in arr))   # 0-d items for 1-D files
+
     wm = cfg.dataset_name == "wikimel"
     if wm:
         tab = synth.make_batch(cfg.with_(num_candidates_data=num_entities - 1), 1, seed + 1000, as_torch=False)

@@ -87,6 +87,9 @@ EXPORTS = {
     "drin_split_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "drin_linear_planes_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "drin_loss_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "drin_triplet_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_int32), C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_profile_begin": (C.c_int, [C.c_int]),
     "drin_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "drin_kernel_class_name": (C.c_char_p, [C.c_int]),

@@ -25,7 +25,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .config import DrinConfig
-from .metrics import TopkAccuracy, TripletLoss
+from .metrics import DeviceLossMetric, TopkAccuracy, TripletLoss
 
 
 def _world() -> int:
@@ -100,13 +100,20 @@ class MELRunner:
     """`MELModel` of `train.py:20-56` without Lightning."""
 
     def __init__(self, cfg: DrinConfig, model: nn.Module, device, global_batch_loss: bool = False,
-                 log: Optional[Callable[[str], None]] = None, entity_table=None):
+                 log: Optional[Callable[[str], None]] = None, entity_table=None, device_loss: Optional[bool] = None):
         """`entity_table`: a device-resident `drin_amd.model.EntityTable`; the loaders then yield the 11-item
-        table-form batches of `drin_amd.data.IndexedMELData` (candidate indices instead of gathered features)."""
+        table-form batches of `drin_amd.data.IndexedMELData` (candidate indices instead of gathered features).
+        `device_loss`: loss + top-k counters through the library's `drin_triplet_topk` (default on a GPU; the
+        gathered global-batch loss keeps the torch classes)."""
         self.cfg, self.model, self.device = cfg, model, torch.device(device)
         self.entity_table = entity_table
         self.loss = TripletLoss(cfg.triplet_margin)
         self.metrics = [TopkAccuracy(k, self.device) for k in cfg.metrics_topk]
+        if device_loss and global_batch_loss:
+            raise ValueError("the gathered global-batch loss runs through the torch TripletLoss; pass device_loss=False")
+        if device_loss is None:
+            device_loss = self.device.type == "cuda" and not global_batch_loss
+        self.device_loss = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk, self.device) if device_loss else None
         self.bucket = GradBucket(list(model.parameters()))
         self.global_batch_loss = global_batch_loss
         self.log = log
@@ -129,6 +136,8 @@ class MELRunner:
             dist.all_gather(ys, y.contiguous())
             # the gathered loss is the GLOBAL mean; scale so that averaging grads over ranks reproduces it
             loss = self.loss(torch.cat(ys, 0), _GatherScores.apply(y_hat)) * world
+        elif self.device_loss is not None:
+            return self.device_loss(y, y_hat)                          # loss and all top-k counters in one call
         else:
             loss = self.loss(y, y_hat)
         with torch.no_grad():
@@ -137,14 +146,17 @@ class MELRunner:
         return loss
 
     def _topk(self, split: int) -> List[float]:
+        if self.device_loss is not None:
+            return [a / (1 - self.cfg.acc_correction[split]) for a in self.device_loss.accuracies()]
         return [float(m.compute()) / (1 - self.cfg.acc_correction[split]) for m in self.metrics]
 
     def run_epoch(self, loader, split: int, optimizer: Optional[torch.optim.Optimizer]) -> StepLog:
-        for m in self.metrics:                                         # EpochLogger.epoch_start (train.py:72-74)
+        meters = [self.device_loss] if self.device_loss is not None else self.metrics
+        for m in meters:                                               # EpochLogger.epoch_start (train.py:72-74)
             m.reset()
         training = optimizer is not None
         self.model.train(training)
-        total, steps = 0.0, 0
+        total, steps = torch.zeros((), dtype=torch.float64, device=self.device), 0   # summed on the device: no per-step read-back
         for batch in loader:
             if training:
                 optimizer.zero_grad(set_to_none=True)
@@ -155,11 +167,11 @@ class MELRunner:
             else:
                 with torch.no_grad():
                     loss = self.forward_step(batch, split)
-            total += float(loss.detach())
+            total += loss.detach()
             steps += 1
-        for m in self.metrics:
+        for m in meters:
             m.sync()
-        mean_loss = total / max(steps, 1)
+        mean_loss = float(total) / max(steps, 1)
         if _world() > 1:
             t = torch.tensor([mean_loss], device=self.device)
             dist.all_reduce(t)

@@ -209,6 +209,21 @@ DRIN_API int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const vo
                                     const float* bias, float* y, int64_t rows, int32_t n_out, int32_t k,
                                     void* stream);
 
+/* ---- caller-side loss and metric of one batch --------------------------------- *
+ * Replaces, for scores already on the device, `TripletLoss.forward` (common/utils.py:26-43, called at
+ * train.py:34) and `TopkAccuracy.update` (utils.py:60-66, train.py:36-37), and the autograd backward of
+ * the former:
+ *   scores   [batch, num_candidates] fp32 (num_candidates includes the answer slot, dropped like
+ *            utils.py:36-37);  answer [batch, num_candidates-1] uint8 one-hot (all-zero row: no gold);
+ *   loss     [1] fp32 (written);  d_scores [batch, num_candidates] fp32 = d loss / d scores, or NULL;
+ *   correct  [num_topk] int64, ACCUMULATED (+=) like the metric's `correct` state; `topk` is a HOST array
+ *            of up to 8 values of k; the caller adds `batch` to its `total`.
+ * Ties count as correct (`y_pred >= lower`), NaN scores order as in torch.topk, a NaN loss propagates. */
+DRIN_API size_t drin_loss_workspace_bytes(int32_t batch);
+DRIN_API int drin_triplet_topk(const float* scores, const uint8_t* answer, int32_t batch, int32_t num_candidates,
+                               float margin, const int32_t* topk, int32_t num_topk, float* loss, float* d_scores,
+                               int64_t* correct, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- in-process kernel timing (bench.py's roofline leg) ---------------------------------------- */
 
 /* Kernel classes the launches are attributed to. */

@@ -72,3 +72,18 @@ def test_null_arguments_are_reported_not_crashed():
     assert b"NULL" in lib.drin_last_error()
     assert lib.drin_forward(C.byref(c), C.byref(b), None, None, 0, None, 0, None, None) == _lib.E_NULL
     assert lib.drin_profile_end(None, None) == _lib.E_SHAPE
+
+
+def test_loss_entry_point_validates_on_host():
+    lib = _lib.load()
+    assert lib.drin_loss_workspace_bytes(0) == 0 and lib.drin_loss_workspace_bytes(64) == 64 * 40
+    ks = (C.c_int32 * 2)(1, 5)
+    one = C.c_void_p(16)   # never dereferenced: every check below fails before a launch
+    assert lib.drin_triplet_topk(one, one, 0, 11, 0.25, ks, 2, one, None, one, one, 4096, None) == _lib.E_SHAPE
+    assert lib.drin_triplet_topk(one, one, 4, 11, 0.25, ks, 9, one, None, one, one, 4096, None) == _lib.E_SHAPE
+    ks[1] = 11                                                             # torch.topk(k > row length) raises too
+    assert lib.drin_triplet_topk(one, one, 4, 11, 0.25, ks, 2, one, None, one, one, 4096, None) == _lib.E_SHAPE
+    assert b"top-k 11" in lib.drin_last_error()
+    ks[1] = 5
+    assert lib.drin_triplet_topk(None, one, 4, 11, 0.25, ks, 2, one, None, one, one, 4096, None) == _lib.E_NULL
+    assert lib.drin_triplet_topk(one, one, 4, 11, 0.25, ks, 2, one, None, one, one, 8, None) == _lib.E_WORKSPACE

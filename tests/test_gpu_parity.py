@@ -594,3 +594,86 @@ def test_inner_feature_dims_take_the_pooled_path():
     with torch.no_grad():
         got = model(_to_dev(batch)).cpu()
     assert (got - ref).abs().max().item() <= 2e-5
+
+
+# ---- caller-side loss + metric on the device ---------------------------------------------
+def _loss_case(B, N, seed, ties=False):
+    g = np.random.Generator(np.random.Philox(key=[seed, 21]))
+    yhat = (g.random(size=(B, N), dtype=np.float32) * 2 - 1)
+    if ties:
+        yhat = np.round(yhat * 4) / 4                       # many equal scores: the `>=` tie rule matters
+    onehot = np.concatenate([np.eye(N - 1, dtype=np.uint8), np.zeros((1, N - 1), dtype=np.uint8)], 0)
+    y = onehot[g.integers(0, N, size=B)]
+    return torch.from_numpy(yhat), torch.from_numpy(y)
+
+
+def test_device_loss_matches_reference_triplet_golden(golden_dir):
+    from drin_amd.metrics import DeviceLossMetric
+    g = _golden(golden_dir, "triplet")
+    for i in range(3):
+        yhat, y = torch.from_numpy(g[f"yhat{i}"]).to(DEV), torch.from_numpy(g[f"y{i}"]).to(DEV)
+        loss = DeviceLossMetric(0.25, (), DEV)(y, yhat)
+        assert abs(loss.item() - float(g[f"loss{i}"])) <= 2e-7 * max(1.0, abs(float(g[f"loss{i}"]))), i
+
+
+@pytest.mark.parametrize("B,N,ties", [(1, 2, False), (3, 4, True), (64, 11, False), (64, 101, False), (64, 101, True),
+                                      (300, 37, True), (4500, 11, False)])
+def test_device_loss_metric_vs_oracle(B, N, ties):
+    """Loss, d loss / d scores and the top-k counters against the oracle's restatement of utils.py:26-73
+    (pinned by the reference's own TripletLoss goldens and hand-computed TopkAccuracy cases)."""
+    from drin_amd.metrics import DeviceLossMetric
+    yhat, y = _loss_case(B, N, 100 + B + N, ties)
+    ks = [k for k in (1, 3, 5, 10, 20, 50) if k <= N - 1]
+    ref_in = yhat.clone().requires_grad_(True)
+    ref = O.triplet_loss(y, ref_in, 0.25)
+    ref.backward()
+    m = DeviceLossMetric(0.25, ks, DEV)
+    d_in = yhat.to(DEV).requires_grad_(True)
+    loss = m(y.to(DEV), d_in)
+    (loss * 3.0).backward()                                  # an upstream factor must scale the gradient
+    assert abs(loss.item() - ref.item()) <= 3e-7 * max(1.0, abs(ref.item()))
+    np.testing.assert_allclose(d_in.grad.cpu().numpy() / 3.0, ref_in.grad.numpy(), atol=2e-7 * ref_in.grad.abs().max().item() + 1e-12,
+                               rtol=2e-6)
+    assert torch.count_nonzero(d_in.grad[:, -1]).item() == 0
+    m(y.to(DEV), yhat.to(DEV))                               # second batch: counters accumulate
+    want = [2 * int(O.topk_counts(yhat, y, k)[0]) for k in ks]
+    assert m.correct.tolist() == want and m.total == 2 * B
+    m.reset()
+    assert m.correct.tolist() == [0] * len(ks) and m.total == 0
+
+
+def test_device_loss_nan_row_and_missing_gold():
+    """A NaN score row (empty mention span, ghmfc.py:59) poisons the loss like torch.clamp does and is never
+    counted; an all-zero answer row (data.py:159-161) contributes no hit."""
+    from drin_amd.metrics import DeviceLossMetric, TopkAccuracy, TripletLoss
+    yhat, y = _loss_case(6, 11, 5)
+    y[2] = 0
+    m = DeviceLossMetric(0.25, (1, 3), DEV)
+    m(y.to(DEV), yhat.to(DEV))
+    assert m.correct.tolist() == [int(O.topk_counts(yhat, y, k)[0]) for k in (1, 3)]
+    yhat[4] = float("nan")
+    m.reset()
+    loss = m(y.to(DEV), yhat.to(DEV))
+    assert torch.isnan(loss) and torch.isnan(TripletLoss(0.25)(y, yhat))
+    for q, k in enumerate((1, 3)):
+        t = TopkAccuracy(k)
+        t.update(yhat, y)
+        assert m.correct[q].item() == t.correct.item()
+
+
+def test_runner_with_device_loss_matches_torch_loss(tmp_path):
+    """MELRunner with the library's loss/metric call reports the same history as with the torch classes."""
+    from drin_amd.data import create_datasets, write_synthetic_dataset
+    from drin_amd.train import MELRunner, seed_everything
+    cfg = DrinConfig(batch_size=8, metrics_topk=(1, 3, 5), shuffle_train_data=False, **TINY)
+    write_synthetic_dataset(cfg, str(tmp_path), sizes=(32, 16, 16), seed=11)
+    hist = {}
+    for fused in (True, False):
+        seed_everything(0)
+        loaders = create_datasets(cfg, str(tmp_path), num_workers=0)
+        model = Model(cfg).to(DEV)
+        runner = MELRunner(cfg, model, DEV, device_loss=fused)
+        assert (runner.device_loss is not None) == fused
+        hist[fused] = runner.fit(loaders, num_epoch=2, test_epoch_interval=2)
+    for a, b in zip(hist[True].train + hist[True].valid + hist[True].test, hist[False].train + hist[False].valid + hist[False].test):
+        assert abs(a.loss - b.loss) <= 2e-5 and a.topk == pytest.approx(b.topk, abs=1e-9)

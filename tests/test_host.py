@@ -175,3 +175,10 @@ def test_indexed_loader_matches_gathered_loader(tmp_path):
     assert len(rebuilt) == 15
     for a, b in zip(full, rebuilt):
         assert torch.equal(a, b)
+
+
+def test_device_loss_metric_refuses_host_tensors():
+    from drin_amd.metrics import DeviceLossMetric
+    m = DeviceLossMetric(0.25, (1, 3), "cpu")
+    with pytest.raises(RuntimeError, match="AMD GPU only"):
+        m(torch.zeros(2, 3, dtype=torch.uint8), torch.zeros(2, 4))

@@ -213,6 +213,8 @@ def main():
                     help="wikimel: 100-cand token-level (headline); wikidiverse: 10-cand pooled; table: BASELINE config 5 - "
                          "1000 candidates per mention gathered on the device from a table of --entities random entities")
     ap.add_argument("--entities", type=int, default=1_000_000)
+    ap.add_argument("--entity-cache", action="store_true",
+                    help="table workload: score from the per-entity precompute cache (SURVEY.md 8f-2; built during warm-up)")
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 4096 wikimel / 16384 wikidiverse / 512 table)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
@@ -263,6 +265,8 @@ def main():
         cand = torch.randint(0, E, (B, N), device=dev, generator=g)
         sims = 20.0 + 5.0 * torch.randn(2, B, N, device=dev, generator=g)
         batch = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+        if args.entity_cache:
+            table.enable_cache()
     else:
         batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
     pairs_per_step = B * N
@@ -309,21 +313,29 @@ def main():
         x3 = args.precision == "bf16x3"
         flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
         bytes_pair = algorithmic_bytes_per_pair(cfg, batch)
-        kernel_names = {"stream": "k_entity_stream", "gemm_planes": "k_gemm_x3_planes", "gemm_x3": "k_gemm_bf16x3",
+        cached = args.workload == "table" and args.entity_cache
+        stream_bytes_pair = bytes_pair
+        if cached:
+            # k_cached_pairs: one gathered cache row in (h_t, h_i, c^, o^, sg and, with dynamic edges, fv_t, fv_i),
+            # the candidate index and two similarities; et' planes and the four layer-2 edges out
+            row = ((5 if cfg.gcn_edge_type == "dynamic" else 3) * D + R + 4) * 4
+            stream_bytes_pair = row + 8 + 8 + D * 4 + 16
+            flops_pair = 2.0 * D * D
+        kernel_names = {"stream": "k_cached_pairs" if cached else "k_entity_stream", "gemm_planes": "k_gemm_x3_planes", "gemm_x3": "k_gemm_bf16x3",
                         "gemm": "k_gemm_f32"}
         if dom == "stream":
             # algorithmic = compulsory input bytes of the step; traffic = PMC-measured HBM bytes
-            work = bytes_pair * pairs_per_step * args.steps / max(launches, 1)
+            work = stream_bytes_pair * pairs_per_step * args.steps / max(launches, 1)
             achieved = work / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": measured_traffic("k_entity_stream", B, args.precision, fused),
+                    "traffic": None if cached else measured_traffic("k_entity_stream", B, args.precision, fused),
                     "launches": int(launches), "avg_launch_ms": per_launch_ms}
         else:
             # algorithmic FLOPs the kernel's launches cover in one step / their summed time.  In split-bf16
             # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
             if dom == "gemm_planes":
-                step_flops = pairs_per_step * 2 * (2.0 * D * D)          # x_t C_t^T and et' W_h2^T
+                step_flops = pairs_per_step * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
             elif dom == "gemm_x3" and fused:
                 step_flops = pairs_per_step * 2.0 * R * D                # x_i C_i^T (+ large mention-side problems)
             else:
@@ -350,8 +362,8 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "hbm_fraction_whole_path": bytes_pair * value / world / (PEAK_HBM_GBS * 1e9),
-            "path": ("fused two-layer" if fused else "layer-by-layer") + ", " + args.precision,
-            "algorithmic": {"bytes_per_pair": bytes_pair, "flops_per_pair_executed": flops_pair,
+            "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + args.precision,
+            "algorithmic": {"bytes_per_pair": bytes_pair, "dominant_kernel_bytes_per_pair": stream_bytes_pair, "flops_per_pair_executed": flops_pair,
                             "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -84,6 +84,13 @@ EXPORTS = {
     "drin_prepare": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinParamsC), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_forward_prepared": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "drin_entity_cache_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
+    "drin_entity_cache_build_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
+    "drin_cached_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
+    "drin_build_entity_cache": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "drin_forward_cached": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "drin_split_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "drin_linear_planes_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

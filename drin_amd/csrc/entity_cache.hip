@@ -1,0 +1,606 @@
+// Per-entity precompute cache for table-form inference: drin_build_entity_cache /
+// drin_forward_cached.
+//
+// With frozen weights everything the first GCN layer takes from an ENTITY is a function of that entity alone,
+// not of the (mention, candidate) pair.  One row per entity of a device-resident table holds
+//
+//   h_t  = x_t (W_h1 W_et)^T                 [D]   layer-1 entity-text contraction   (model.py:128,146)
+//   h_i  = x_i (W_h1 W_ei)^T                 [D]   layer-1 entity-image contraction
+//   fv_t = W_v1 (W_et x_t + b_et) + b_v1     [D]   edge-update operand W_v(et0)      (model.py:148-153)
+//   fv_i = W_v1 (W_ei x_i + b_ei) + b_v1     [D]
+//   c^   = cls / max(|cls|, eps)             [D]   CLS / pooler row, normalised      (model.py:71-76)
+//   o^   = sum_j es_j obj_j / max(|obj_j|, eps)   [R]   score-weighted normalised objects (model.py:84-92)
+//   sg   = sum_j es_j                        [1]   (+ 3 pad)
+//
+// (x_t = pooled entity text, ghmfc.py:245-249; x_i = image row.)  The image-image edge factorises because the
+// cosine is bilinear in the normalised rows:  sum_ij cos(m_i, o_j) ms_i es_j = (sum_i ms_i m^_i) . o^ .
+// A pair then needs no W_et / W_ei / W_v contraction at all: per pair 4.33 of the 5.51 MFLOP of the folded
+// path disappear, and so does the pass over the token-level entity text.  What remains per pair is ONE
+// gathered read of the cache row (k_cached_pairs: edges, both layer-1 entity vertices, every cross-candidate
+// sum of both layers), the layer-2 contraction et' W_h2^T and k_pair_final.
+//
+// The cache is a function of the weights: it is rebuilt (one pass over the table + four table-sized GEMMs)
+// whenever they change, so it serves inference / evaluation with frozen weights - never training.
+#include <string.h>
+
+#include "fused.h"
+#include "internal.h"
+#include "layout.h"
+#include "row_ops.h"
+
+namespace drin {
+
+static inline size_t cache_row_floats(const drin_config& c) { return 5 * (size_t)c.embed_dim + c.image_dim + 4; }
+constexpr int64_t kCacheSlab = 262144;  // entities per builder slab (pooled-text scratch: slab * D floats)
+
+struct CacheBuildArgs {
+  const float* entity_text;          // TOKENS: [E, T, D] else [E, D]
+  const int64_t* entity_mask;        // TOKENS: [E, T]
+  const float* entity_object;        // [E, Ke, R]
+  const float* entity_object_score;  // [E, Ke]
+  float* xt;                         // [rows, D] pooled text of this slab (GEMM operand)
+  float* cache;                      // row e0 of the slab
+  int64_t ldc, rows;
+  int D4, R4, T, Ke;
+  float cos_eps;
+};
+
+// one wave per entity
+template <int DV, int RV, bool TOKENS>
+__global__ void __launch_bounds__(256) k_entity_cache_rows(const CacheBuildArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= a.rows) return;
+  const int D4 = a.D4, R4 = a.R4, D = D4 * 4, R = R4 * 4;
+  float* row = a.cache + e * a.ldc;
+  Row<DV> xt, cls;
+  if (TOKENS) {  // ghmfc.py:245-249: mean of tokens 1 .. ntok-2; model.py:73-75: token 0 feeds the cosine
+    const int T = a.T;
+    int cnt = 0;
+    for (int t = lane; t < T; t += 64) cnt += (int)a.entity_mask[e * T + t];
+    cnt = (int)wave_sum((float)cnt);
+    int stop = cnt - 1;
+    if (stop < 0) stop += T;
+    stop = stop < 0 ? 0 : (stop > T ? T : stop);
+    const float* base = a.entity_text + e * (int64_t)T * D;
+    cls = load_row<DV>(base, lane, D4);
+    Row<DV> acc = zero_row<DV>();
+    int t = 1;
+    for (; t + 4 <= stop; t += 4) {  // same association as k_entity_stream: the two paths pool bit-identically
+      const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
+      const Row<DV> r1 = load_row<DV>(base + (int64_t)(t + 1) * D, lane, D4);
+      const Row<DV> r2 = load_row<DV>(base + (int64_t)(t + 2) * D, lane, D4);
+      const Row<DV> r3 = load_row<DV>(base + (int64_t)(t + 3) * D, lane, D4);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) acc.v[j] = (((acc.v[j] + r0.v[j]) + r1.v[j]) + r2.v[j]) + r3.v[j];
+    }
+    for (; t < stop; ++t) {
+      const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) acc.v[j] = acc.v[j] + r0.v[j];
+    }
+    const float den = stop > 1 ? (float)(stop - 1) : 0.0f;  // empty slice: 0 / 0 = NaN like the reference
+#pragma unroll
+    for (int j = 0; j < DV; ++j)
+      xt.v[j] = make_float4(acc.v[j].x / den, acc.v[j].y / den, acc.v[j].z / den, acc.v[j].w / den);
+  } else {
+    xt = load_row<DV>(a.entity_text + e * D, lane, D4);
+    cls = xt;
+  }
+  store_row<DV>(a.xt + e * D, xt, lane, D4);
+  {
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(dot_rows<DV>(cls, cls))), a.cos_eps);
+#pragma unroll
+    for (int j = 0; j < DV; ++j) cls.v[j] = cls.v[j] * inv;
+    store_row<DV>(row + 4 * D, cls, lane, D4);
+  }
+  Row<RV> o = zero_row<RV>();
+  float sg = 0.f;
+  for (int j = 0; j < a.Ke; ++j) {
+    const Row<RV> eo = load_row<RV>(a.entity_object + (e * a.Ke + j) * R, lane, R4);
+    const float es = a.entity_object_score[e * a.Ke + j];
+    axpy_row<RV>(o, es / fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps), eo);
+    sg += es;
+  }
+  store_row<RV>(row + 5 * D, o, lane, R4);
+  if (lane == 0) st4(row + 5 * D + R, make_float4(sg, 0.f, 0.f, 0.f));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct CachedArgs {
+  const float* cache;            // [E][ldc]
+  int64_t ldc, num_entities;
+  const int64_t* entity_index;   // [M]
+  const float* miet;             // [M]
+  const float* mtei;             // [M]
+  const float* span_mean;        // [B, D]
+  const float* mobj;             // [B, Km, R]
+  const float* mscore;           // [B, Km]
+  const float* fu;               // rows b and B + b, row stride ldfu: W_u1(mt0), W_u1(mi0) incl. bias
+  const float* hm;               // rows b and B + b, row stride ldhm: W_h1 mt0, W_h1 mi0 (no bias)
+  const float* c_t;              // [D] W_h1 b_et + b_h1
+  const float* c_i;              // [D] W_h1 b_ei + b_h1
+  const float* gamma;            // layer-1 LayerNorm
+  const float* beta;
+  float* e1m;                    // [4][M] layer-2 edges (already multiplied by the edge switch)
+  float* et1;                    // [M, D] or NULL
+  void* et1_hi;                  // bf16 hi / lo planes of et1, or NULL
+  void* et1_lo;
+  float* c_part;                 // [B][chunks][2 D + 4]: sum e h for the two mention vertices, 4 edge sums
+  float* s2_part;                // [B][chunks][2 D]: layer-2 mention aggregates
+  int B, N, D4, R4, Km, chunks, ldfu, ldhm, dynamic;
+  float mask[4];
+  float cos_eps, miei_eps, clip, ln_eps;
+};
+
+// grid (chunks, B), 256 threads; wave w takes candidates c0 + w, c0 + w + 4, ... of its chunk
+template <int DV, int RV>
+__global__ void __launch_bounds__(256) k_cached_pairs(const CachedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D4 = a.D4, R4 = a.R4, D = D4 * 4, R = R4 * 4;
+  float* l_s = lds;               // [D]   span mean / max(|.|, eps)
+  float* l_mu = l_s + D;          // [R]   sum_i ms_i mobj_i / max(|mobj_i|, eps)
+  float* l_fu = l_mu + R;         // [2 D] W_u(mt0), W_u(mi0)
+  float* l_const = l_fu + 2 * D;  // [6 D] hm_t, hm_i, c_t, c_i, gamma, beta
+  float* l_red = l_const + 6 * D; // [4 D] cross-wave reduction
+  float* l_small = l_red + 4 * D; // [Km] ms_i / |mobj_i|, then [4] edge sums   (Km <= 8)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.y;
+  const int64_t M = (int64_t)a.B * a.N;
+  const int per = (a.N + a.chunks - 1) / a.chunks;
+  const int n_begin = blockIdx.x * per, n_end = min(a.N, n_begin + per);
+  const bool dyn = a.dynamic != 0;
+
+  // ---- per-workgroup prologue ---------------------------------------------------------------------------
+  {
+    const float* src[6] = {a.hm + b * a.ldhm, a.hm + ((int64_t)a.B + b) * a.ldhm, a.c_t, a.c_i, a.gamma, a.beta};
+#pragma unroll
+    for (int v = 0; v < 6; ++v)
+      for (int i = threadIdx.x; i < D4; i += 256) st4(l_const + v * D + i * 4, ld4(src[v] + i * 4));
+    if (dyn)
+      for (int i = threadIdx.x; i < 2 * D4; i += 256) {
+        const int which = i / D4, c4 = i - which * D4;
+        st4(l_fu + i * 4, ld4(a.fu + ((int64_t)which * a.B + b) * a.ldfu + c4 * 4));
+      }
+  }
+  for (int i = wave; i < a.Km; i += 4) {  // model.py:88 re-normalises the same mention rows for every pair
+    const Row<RV> m = load_row<RV>(a.mobj + (b * a.Km + i) * R, lane, R4);
+    const float nrm = fmaxf(sqrtf(wave_sum(dot_rows<RV>(m, m))), a.cos_eps);
+    if (lane == 0) l_small[i] = a.mscore[b * a.Km + i] / nrm;
+  }
+  if (wave == 0) {
+    Row<DV> s = load_row<DV>(a.span_mean + b * D, lane, D4);
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(dot_rows<DV>(s, s))), a.cos_eps);
+#pragma unroll
+    for (int j = 0; j < DV; ++j) s.v[j] = s.v[j] * inv;
+    store_row<DV>(l_s, s, lane, D4);
+  }
+  __syncthreads();
+  float sum_ms = 0.f;
+  for (int i = 0; i < a.Km; ++i) sum_ms += a.mscore[b * a.Km + i];
+  for (int c4 = threadIdx.x; c4 < R4; c4 += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < a.Km; ++i) acc = fma4(l_small[i], ld4(a.mobj + (b * a.Km + i) * R + c4 * 4), acc);
+    st4(l_mu + c4 * 4, acc);
+  }
+  __syncthreads();
+  const float *l_hm_t = l_const, *l_hm_i = l_const + D, *l_ct = l_const + 2 * D, *l_ci = l_const + 3 * D;
+  const float *l_gamma = l_const + 4 * D, *l_beta = l_const + 5 * D;
+
+  Row<DV> A_t = zero_row<DV>(), A_i = zero_row<DV>(), S_t = zero_row<DV>(), S_i = zero_row<DV>();
+  float sg_tt = 0.f, sg_ti = 0.f, sg_it = 0.f, sg_ii = 0.f;
+  const float inv_d = 1.0f / (float)D;
+
+  for (int n = n_begin + wave; n < n_end; n += 4) {
+    const int64_t p = b * a.N + n;
+    int64_t e = a.entity_index[p];
+    e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
+    const float* row = a.cache + e * a.ldc;
+    // the whole row is requested up front: ~23 KB in flight per wave
+    const Row<DV> ht = load_row<DV>(row, lane, D4);
+    const Row<DV> hi = load_row<DV>(row + D, lane, D4);
+    const Row<DV> chat = load_row<DV>(row + 4 * D, lane, D4);
+    const Row<RV> ohat = load_row<RV>(row + 5 * D, lane, R4);
+    const float sg_e = row[5 * D + R];
+    // ---- static edges (model.py:71-92, 201-204) ------------------------------------------------------------
+    const float e_tt = wave_sum(dot_row_lds<DV>(chat, l_s, lane, D4)) * a.mask[0];
+    const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
+    const float e_it = (a.miet[p] / a.clip) * a.mask[2];
+    const float e_ii = wave_sum(dot_row_lds<RV>(ohat, l_mu, lane, R4)) / (sum_ms * sg_e + a.miei_eps) * a.mask[3];
+    // ---- layer-2 edges (model.py:148-153; static: pass-through, model.py:136) ------------------------------
+    float n_tt = e_tt, n_ti = e_ti, n_it = e_it, n_ii = e_ii;
+    if (dyn) {
+      const Row<DV> fvt = load_row<DV>(row + 2 * D, lane, D4);
+      const Row<DV> fvi = load_row<DV>(row + 3 * D, lane, D4);
+      n_tt = sigmoidf(wave_sum(dot_row_lds<DV>(fvt, l_fu, lane, D4)) * inv_d + e_tt);
+      n_ti = sigmoidf(wave_sum(dot_row_lds<DV>(fvi, l_fu, lane, D4)) * inv_d + e_ti);
+      n_it = sigmoidf(wave_sum(dot_row_lds<DV>(fvt, l_fu + D, lane, D4)) * inv_d + e_it);
+      n_ii = sigmoidf(wave_sum(dot_row_lds<DV>(fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
+    }
+    n_tt *= a.mask[0];
+    n_ti *= a.mask[1];
+    n_it *= a.mask[2];
+    n_ii *= a.mask[3];
+    if (lane == 0) {
+      a.e1m[p] = n_tt;
+      a.e1m[M + p] = n_ti;
+      a.e1m[2 * M + p] = n_it;
+      a.e1m[3 * M + p] = n_ii;
+    }
+    // ---- layer-1 mention aggregates, already through W_h1 (model.py:143-144) -------------------------------
+    axpy_row<DV>(A_t, e_tt, ht);
+    axpy_row<DV>(A_t, e_ti, hi);
+    axpy_row<DV>(A_i, e_it, ht);
+    axpy_row<DV>(A_i, e_ii, hi);
+    sg_tt += e_tt;
+    sg_ti += e_ti;
+    sg_it += e_it;
+    sg_ii += e_ii;
+    // ---- layer-1 entity vertices (model.py:128,146) and the layer-2 mention aggregates ----------------------
+    const Row<DV> et1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4), l_gamma,
+                                            l_beta, lane, D4, a.ln_eps);
+    if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
+    if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
+    axpy_row<DV>(S_t, n_tt, et1);
+    const Row<DV> ei1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4), l_gamma,
+                                            l_beta, lane, D4, a.ln_eps);
+    axpy_row<DV>(S_i, n_ti, ei1);
+  }
+
+  // ---- fixed-order cross-wave reduction, one partial per (mention, chunk) --------------------------------
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < D4) {
+          float* q = l_red + c4 * 4;
+          st4(q, w == 0 ? A_t.v[j] : ld4(q) + A_t.v[j]);
+          st4(q + D, w == 0 ? A_i.v[j] : ld4(q + D) + A_i.v[j]);
+          st4(q + 2 * D, w == 0 ? S_t.v[j] : ld4(q + 2 * D) + S_t.v[j]);
+          st4(q + 3 * D, w == 0 ? S_i.v[j] : ld4(q + 3 * D) + S_i.v[j]);
+        }
+      }
+      if (lane == 0) {
+        float* s4 = l_small + 8;
+        s4[0] = (w == 0 ? 0.f : s4[0]) + sg_tt;
+        s4[1] = (w == 0 ? 0.f : s4[1]) + sg_ti;
+        s4[2] = (w == 0 ? 0.f : s4[2]) + sg_it;
+        s4[3] = (w == 0 ? 0.f : s4[3]) + sg_ii;
+      }
+    }
+  }
+  __syncthreads();
+  float* out1 = a.c_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D + 4);
+  float* out2 = a.s2_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D);
+  for (int i = threadIdx.x; i < 2 * D4; i += 256) {
+    st4(out1 + i * 4, ld4(l_red + i * 4));
+    st4(out2 + i * 4, ld4(l_red + 2 * D + i * 4));
+  }
+  if (threadIdx.x < 4) out1[2 * D + threadIdx.x] = l_small[8 + threadIdx.x];
+}
+
+// Pre-LayerNorm layer-1 mention vertices from the chunk partials (model.py:143-144 + :128), W_h1 already applied:
+//   out[0][b] = (A_t + sg_tt wb_t + sg_ti wb_i) / N + hm_t[b] + b_h1,  wb = W_h1 b_e = cb - b_h1
+//   out[1][b] = (A_i + sg_it wb_t + sg_ii wb_i) / N + hm_i[b] + b_h1
+__global__ void __launch_bounds__(256) k_mention_layer1_cached(const float* __restrict__ part, const float* __restrict__ hm,
+                                                               int ldhm, const float* __restrict__ cb_t,
+                                                               const float* __restrict__ cb_i, const float* __restrict__ b_h,
+                                                               float* __restrict__ out, int B, int D, int chunks, float inv_n) {
+  const int64_t b = blockIdx.y;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const int width = 2 * D + 4;
+  float at = 0.f, ai = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float* p = part + (b * chunks + c) * (int64_t)width;
+    at += p[d];
+    ai += p[D + d];
+    s0 += p[2 * D];
+    s1 += p[2 * D + 1];
+    s2 += p[2 * D + 2];
+    s3 += p[2 * D + 3];
+  }
+  const float bh = b_h[d], wt = cb_t[d] - bh, wi = cb_i[d] - bh;
+  out[b * D + d] = (at + s0 * wt + s1 * wi) * inv_n + hm[b * ldhm + d] + bh;
+  out[((int64_t)B + b) * D + d] = (ai + s2 * wt + s3 * wi) * inv_n + hm[((int64_t)B + b) * ldhm + d] + bh;
+}
+
+struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats
+  size_t span_mean, mimg, vm0, hmfu, e1m, c_part, s2_part, vm1, hm2, agg2, mt2, et1, p_et1, h2, total;
+  int chunks;
+  void build(const drin_config& c) {
+    const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
+    chunks = (int)((N + 15) / 16);  // a function of N only: a mention scores bit-identically in any batch
+    size_t off = 0;
+    auto take = [&off](size_t n) {
+      const size_t o = off;
+      off += (n + 63) & ~(size_t)63;
+      return o;
+    };
+    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL;
+    span_mean = take(B * D);
+    mimg = take(B * R);
+    vm0 = take(2 * B * D);
+    hmfu = take(2 * B * 2 * D);
+    e1m = take(4 * M);
+    c_part = take(B * chunks * (2 * D + 4));
+    s2_part = take(B * chunks * 2 * D);
+    vm1 = take(2 * B * D);
+    hm2 = take(2 * B * D);
+    agg2 = take(B * D);
+    mt2 = take(B * D);
+    et1 = take(planes ? 0 : M * D);
+    p_et1 = take(planes ? M * D : 0);  // hi plane (M*D bf16) then lo plane
+    h2 = take(M * D);
+    total = off;
+  }
+};
+
+static int cache_supported(const drin_config* c) {
+  DRIN_TRY(fused_supported(c));
+  if (c->num_entities <= 0) {
+    set_error("entity cache: cfg.num_entities = %d (the entity_* tensors must be tables)", c->num_entities);
+    return DRIN_E_SHAPE;
+  }
+  if (c->mention_objects > 8) {
+    set_error("entity cache: at most 8 mention objects (got %d)", c->mention_objects);
+    return DRIN_E_UNSUPPORTED;
+  }
+  return DRIN_OK;
+}
+
+template <int DV, int RV>
+static int launch_cached_pairs_t(const CachedArgs& a, hipStream_t st) {
+  const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;
+  const size_t lds = sizeof(float) * (13 * D + R + 16);
+  auto kern = k_cached_pairs<DV, RV>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cached_pairs)");
+    attr_done = true;
+  }
+  KernelTimer timer(DRIN_KC_STREAM, st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), lds, st, a);
+  DRIN_CHECK_LAUNCH("k_cached_pairs");
+  return DRIN_OK;
+}
+
+}  // namespace drin
+
+using namespace drin;
+
+extern "C" {
+
+DRIN_API size_t drin_entity_cache_bytes(const drin_config* cfg) {
+  if (validate_config(cfg) != DRIN_OK || cache_supported(cfg) != DRIN_OK) return 0;
+  return (size_t)cfg->num_entities * cache_row_floats(*cfg) * sizeof(float);
+}
+
+DRIN_API size_t drin_entity_cache_build_workspace_bytes(const drin_config* cfg) {
+  if (validate_config(cfg) != DRIN_OK || cache_supported(cfg) != DRIN_OK) return 0;
+  const int64_t slab = cfg->num_entities < kCacheSlab ? cfg->num_entities : kCacheSlab;
+  return (size_t)slab * cfg->embed_dim * sizeof(float);
+}
+
+DRIN_API size_t drin_cached_workspace_bytes(const drin_config* cfg) {
+  if (validate_config(cfg) != DRIN_OK || cache_supported(cfg) != DRIN_OK) return 0;
+  CachedLayout L;
+  L.build(*cfg);
+  return L.total * sizeof(float);
+}
+
+DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* tables, const drin_params* params,
+                                     const void* prepared, void* cache, size_t cache_bytes, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(cache_supported(cfg));
+  if (!tables || !params || !prepared || !cache || !workspace) {
+    set_error("drin_build_entity_cache: NULL argument");
+    return DRIN_E_NULL;
+  }
+  if (!tables->entity_text || !tables->entity_image || !tables->entity_object || !tables->entity_object_score ||
+      (cfg->entity_tokens > 0 && !tables->entity_text_mask)) {
+    set_error("drin_build_entity_cache: NULL entity table");
+    return DRIN_E_NULL;
+  }
+  if (cache_bytes < drin_entity_cache_bytes(cfg) || workspace_bytes < drin_entity_cache_build_workspace_bytes(cfg) ||
+      !aligned16(cache) || !aligned16(workspace)) {
+    set_error("drin_build_entity_cache: cache %zu / workspace %zu bytes (need %zu / %zu, 16-byte aligned)", cache_bytes,
+              workspace_bytes, drin_entity_cache_bytes(cfg), drin_entity_cache_build_workspace_bytes(cfg));
+    return DRIN_E_WORKSPACE;
+  }
+  Prepared P;
+  P.build(*cfg);
+  hipStream_t st = (hipStream_t)stream;
+  const float* pb = (const float*)prepared;
+  const int D = cfg->embed_dim, R = cfg->image_dim, T = cfg->entity_tokens;
+  const int64_t E = cfg->num_entities;
+  const int64_t ldc = (int64_t)cache_row_floats(*cfg);
+  const bool dyn = cfg->dynamic_edges != 0;
+  const int prec = cfg->precision;
+  float* xt = (float*)workspace;
+  for (int64_t e0 = 0; e0 < E; e0 += kCacheSlab) {
+    const int64_t rows = E - e0 < kCacheSlab ? E - e0 : kCacheSlab;
+    float* crow = (float*)cache + e0 * ldc;
+    CacheBuildArgs a;
+    memset(&a, 0, sizeof(a));
+    a.entity_text = tables->entity_text + e0 * (int64_t)(T > 0 ? T : 1) * D;
+    a.entity_mask = T > 0 ? tables->entity_text_mask + e0 * T : nullptr;
+    a.entity_object = tables->entity_object + e0 * (int64_t)cfg->entity_objects * R;
+    a.entity_object_score = tables->entity_object_score + e0 * cfg->entity_objects;
+    a.xt = xt;
+    a.cache = crow;
+    a.ldc = ldc;
+    a.rows = rows;
+    a.D4 = D / 4;
+    a.R4 = R / 4;
+    a.T = T;
+    a.Ke = cfg->entity_objects;
+    a.cos_eps = cfg->cosine_eps;
+    {
+      KernelTimer timer(DRIN_KC_STREAM, st);
+      const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+      const bool tiny = a.D4 <= 64 && a.R4 <= 64;
+      if (tiny && T > 0)
+        hipLaunchKernelGGL((k_entity_cache_rows<1, 1, true>), grid, block, 0, st, a);
+      else if (tiny)
+        hipLaunchKernelGGL((k_entity_cache_rows<1, 1, false>), grid, block, 0, st, a);
+      else if (T > 0)
+        hipLaunchKernelGGL((k_entity_cache_rows<3, 8, true>), grid, block, 0, st, a);
+      else
+        hipLaunchKernelGGL((k_entity_cache_rows<3, 8, false>), grid, block, 0, st, a);
+      DRIN_CHECK_LAUNCH("k_entity_cache_rows");
+    }
+    const float* ximg = tables->entity_image + e0 * (int64_t)R;
+    // h_t = x_t C_t^T, h_i = x_i C_i^T
+    DRIN_TRY(launch_gemm_nt(xt, D, pb + P.c_txt, D, nullptr, crow, ldc, rows, D, D, false, prec, st));
+    DRIN_TRY(launch_gemm_nt(ximg, R, pb + P.c_img, R, nullptr, crow + D, ldc, rows, D, R, false, prec, st));
+    if (dyn) {  // fv = x (W_v1 W_e)^T + (W_v1 b_e + b_v1); etmp keeps W_v1 [W_et | W_ei] un-transposed, row stride D + R
+      DRIN_TRY(launch_gemm_nt(xt, D, pb + P.etmp, D + R, pb + P.k_t, crow + 2 * D, ldc, rows, D, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(ximg, R, pb + P.etmp + D, D + R, pb + P.k_i, crow + 3 * D, ldc, rows, D, R, false, prec, st));
+    }
+  }
+  return DRIN_OK;
+}
+
+DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
+                                 const void* cache, void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(cache_supported(cfg));
+  if (!b || !params || !prepared || !cache || !workspace || !scores) {
+    set_error("drin_forward_cached: NULL argument");
+    return DRIN_E_NULL;
+  }
+  if (!b->entity_index || !b->mention_text || !b->mention_start || !b->mention_end || !b->mention_image ||
+      !b->mention_object || !b->mention_object_score || !b->miet_similarity || !b->mtei_similarity) {
+    set_error("drin_forward_cached: NULL mention tensor / entity_index / similarity");
+    return DRIN_E_NULL;
+  }
+  CachedLayout L;
+  L.build(*cfg);
+  if (workspace_bytes < L.total * sizeof(float) || !aligned16(workspace) || !aligned16(cache)) {
+    set_error("drin_forward_cached: workspace has %zu bytes (needs %zu) or a buffer is not 16-byte aligned",
+              workspace_bytes, L.total * sizeof(float));
+    return DRIN_E_WORKSPACE;
+  }
+  Prepared P;
+  P.build(*cfg);
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const float* pb = (const float*)prepared;
+  const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
+  const int64_t M = (int64_t)B * N;
+  if (B == 0) return DRIN_OK;
+  if (B > 65535) {
+    set_error("drin_forward_cached: batch %d exceeds the grid limit; split the batch", B);
+    return DRIN_E_SHAPE;
+  }
+  const int prec = cfg->precision;
+  const bool planes = (prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL) && (D % 32 == 0);
+  const drin_layer_params& L1 = params->layer[0];
+  const drin_layer_params& L2 = params->layer[1];
+  __bf16* e1_hi = reinterpret_cast<__bf16*>(ws + L.p_et1);
+  const size_t MD = (size_t)M * D;
+  if (!planes && (prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL)) {
+    set_error("drin_forward_cached: split-bf16 precision needs embed_dim %% 32 == 0 (got %d)", D);
+    return DRIN_E_UNSUPPORTED;
+  }
+
+  // (1) mention-side pooling and vertex-encoder Linears, [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1]
+  DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B, cfg->mention_tokens, D, st));
+  DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
+  float* vm0 = ws + L.vm0;
+  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, prec, st));
+  float* hmfu = ws + L.hmfu;
+  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st));
+
+  // (2) one gathered pass over the cache rows: edges, layer-1 entity vertices, all cross-candidate sums
+  CachedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cache = (const float*)cache;
+  a.ldc = (int64_t)cache_row_floats(*cfg);
+  a.num_entities = cfg->num_entities;
+  a.entity_index = b->entity_index;
+  a.miet = b->miet_similarity;
+  a.mtei = b->mtei_similarity;
+  a.span_mean = ws + L.span_mean;
+  a.mobj = b->mention_object;
+  a.mscore = b->mention_object_score;
+  a.fu = hmfu + D;
+  a.ldfu = 2 * D;
+  a.hm = hmfu;
+  a.ldhm = 2 * D;
+  a.c_t = pb + P.cb_t;
+  a.c_i = pb + P.cb_i;
+  a.gamma = L1.ln_weight;
+  a.beta = L1.ln_bias;
+  a.e1m = ws + L.e1m;
+  a.et1 = planes ? nullptr : ws + L.et1;
+  a.et1_hi = planes ? e1_hi : nullptr;
+  a.et1_lo = planes ? e1_hi + MD : nullptr;
+  a.c_part = ws + L.c_part;
+  a.s2_part = ws + L.s2_part;
+  a.B = B;
+  a.N = N;
+  a.D4 = D / 4;
+  a.R4 = R / 4;
+  a.Km = cfg->mention_objects;
+  a.chunks = L.chunks;
+  a.dynamic = cfg->dynamic_edges != 0;
+  for (int k = 0; k < 4; ++k) a.mask[k] = cfg->edge_enabled[k];
+  a.cos_eps = cfg->cosine_eps;
+  a.miei_eps = cfg->miei_eps;
+  a.clip = cfg->clip_scale;
+  a.ln_eps = cfg->layer_norm_eps;
+  if (a.D4 <= 64 && a.R4 <= 64)
+    DRIN_TRY((launch_cached_pairs_t<1, 1>(a, st)));
+  else
+    DRIN_TRY((launch_cached_pairs_t<3, 8>(a, st)));
+
+  // (3) layer-1 mention vertices, then what layer 2 needs from them
+  float* vm1 = ws + L.vm1;
+  {
+    KernelTimer timer(DRIN_KC_GCN, st);
+    hipLaunchKernelGGL(k_mention_layer1_cached, dim3((unsigned)cdiv(D, 256), (unsigned)B), dim3(256), 0, st, ws + L.c_part,
+                       hmfu, 2 * D, pb + P.cb_t, pb + P.cb_i, L1.b_h, vm1, B, D, L.chunks, 1.0f / (float)N);
+    DRIN_CHECK_LAUNCH("k_mention_layer1_cached");
+  }
+  DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
+  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, prec, st));
+  // (4) layer-2 mention-text vertex
+  DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, prec, st));
+  DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
+  // (5) layer-2 entity-text contraction, vertex and score
+  float* h2 = ws + L.h2;
+  if (planes) {
+    const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
+    DRIN_TRY(launch_gemm_x3_planes(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, nullptr, h2, D, M, D, D, st));
+  } else {
+    DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
+  }
+  FinalArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.h2 = h2;
+  fa.hm2 = ws + L.hm2;
+  fa.b_h2 = L2.b_h;
+  fa.gamma = L2.ln_weight;
+  fa.beta = L2.ln_bias;
+  fa.e1m = ws + L.e1m;
+  fa.mt2 = ws + L.mt2;
+  fa.scores = scores;
+  fa.B = B;
+  fa.N = N;
+  fa.D4 = D / 4;
+  fa.chunks = L.chunks;
+  fa.ln_eps = cfg->layer_norm_eps;
+  fa.cos_eps = cfg->cosine_eps;
+  return launch_pair_final(fa, st);
+}
+
+}  // extern "C"

@@ -25,34 +25,6 @@
 
 namespace drin {
 
-struct Prepared {  // offsets in floats
-  size_t wcat1, bcat1, ecat, etmp, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
-  size_t p_ctxt, p_cimg, p_wh2;  // bf16 (hi, lo) planes of the three pair-sized GEMM weights; lo follows hi
-  void build(const drin_config& c) {
-    const size_t D = c.embed_dim, R = c.image_dim;
-    size_t off = 0;
-    auto take = [&off](size_t n) {
-      const size_t o = off;
-      off += (n + 63) & ~(size_t)63;
-      return o;
-    };
-    wcat1 = take(2 * D * D);      // [W_h1; W_u1]           [2D, D]
-    bcat1 = take(2 * D);          // [0; b_u1]
-    ecat = take(D * (D + R));     // ([W_v1 W_et | W_v1 W_ei])^T  [D + R, D]  (nn.Linear layout: q = fu ecat^T)
-    etmp = take(D * (D + R));     // scratch of drin_prepare: the un-transposed product
-    k_t = take(D);                // W_v1 b_et + b_v1
-    k_i = take(D);                // W_v1 b_ei + b_v1
-    c_txt = take(D * D);          // W_h1 W_et              [D, D]
-    c_img = take(D * R);          // W_h1 W_ei              [D, R]
-    cb_t = take(D);               // W_h1 b_et + b_h1
-    cb_i = take(D);               // W_h1 b_ei + b_h1
-    p_ctxt = take(D * D);         // hi plane D*D bf16 (= D*D/2 floats) then lo plane
-    p_cimg = take(D * R);
-    p_wh2 = take(D * D);
-    total = off;
-  }
-};
-
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
       et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, total;
@@ -99,7 +71,7 @@ struct FusedLayout {  // workspace offsets in floats
   }
 };
 
-static int fused_supported(const drin_config* c) {
+int fused_supported(const drin_config* c) {
   if (c->num_layers != 2) {
     set_error("fused path: built for num_layers == 2 (got %d); use drin_forward", c->num_layers);
     return DRIN_E_UNSUPPORTED;

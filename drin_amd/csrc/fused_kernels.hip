@@ -9,88 +9,9 @@
 #include "device_utils.h"
 #include "fused.h"
 #include "internal.h"
+#include "row_ops.h"
 
 namespace drin {
-
-template <int V>
-struct Row {
-  float4 v[V];
-};
-
-template <int V>
-__device__ __forceinline__ Row<V> load_row(const float* __restrict__ p, int lane, int n4) {
-  Row<V> r;
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const int c4 = lane + 64 * j;
-    r.v[j] = c4 < n4 ? ld4(p + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  return r;
-}
-template <int V>
-__device__ __forceinline__ void store_row(float* __restrict__ p, const Row<V>& r, int lane, int n4) {
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < n4) st4(p + c4 * 4, r.v[j]);
-  }
-}
-// v = hi + lo in bf16 (operand planes of the split-bf16 GEMM, gemm_x3_planes.hip)
-template <int V>
-__device__ __forceinline__ void store_row_planes(void* __restrict__ hi, void* __restrict__ lo, int64_t row_off,
-                                                 const Row<V>& r, int lane, int n4) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  __bf16* ph = reinterpret_cast<__bf16*>(hi) + row_off;
-  __bf16* pl = reinterpret_cast<__bf16*>(lo) + row_off;
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < n4) {
-      const float4 v = r.v[j];
-      bf16x4 h, l;
-      h[0] = (__bf16)v.x;
-      h[1] = (__bf16)v.y;
-      h[2] = (__bf16)v.z;
-      h[3] = (__bf16)v.w;
-      l[0] = (__bf16)(v.x - (float)h[0]);
-      l[1] = (__bf16)(v.y - (float)h[1]);
-      l[2] = (__bf16)(v.z - (float)h[2]);
-      l[3] = (__bf16)(v.w - (float)h[3]);
-      *reinterpret_cast<bf16x4*>(ph + c4 * 4) = h;
-      *reinterpret_cast<bf16x4*>(pl + c4 * 4) = l;
-    }
-  }
-}
-template <int V>
-__device__ __forceinline__ float dot_rows(const Row<V>& a, const Row<V>& b) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < V; ++j) s += dot4(a.v[j], b.v[j]);
-  return s;
-}
-template <int V>
-__device__ __forceinline__ void axpy_row(Row<V>& acc, float w, const Row<V>& x) {
-#pragma unroll
-  for (int j = 0; j < V; ++j) acc.v[j] = fma4(w, x.v[j], acc.v[j]);
-}
-template <int V>
-__device__ __forceinline__ Row<V> zero_row() {
-  Row<V> r;
-#pragma unroll
-  for (int j = 0; j < V; ++j) r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  return r;
-}
-// dot with a vector that lives in LDS (same lane -> column map)
-template <int V>
-__device__ __forceinline__ float dot_row_lds(const Row<V>& a, const float* lds, int lane, int n4) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < n4) s += dot4(a.v[j], ld4(lds + c4 * 4));
-  }
-  return s;
-}
 
 // ------------------------------------------------------------------------------------------------
 // grid (chunks, B), 256 threads.  Wave w of the workgroup takes candidates c0 + w, c0 + w + 4, ...
@@ -421,104 +342,6 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm + GELU of one row held in registers (model.py:128)
-template <int DV>
-__device__ __forceinline__ Row<DV> ln_gelu_row(const Row<DV>& h, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, int lane, int D4, float eps) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
-  const float inv_d = 1.0f / (float)(D4 * 4);
-  const float mu = wave_sum(s) * inv_d;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4) {
-      const float dx = h.v[j].x - mu, dy = h.v[j].y - mu, dz = h.v[j].z - mu, dw = h.v[j].w - mu;
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
-  Row<DV> y;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4) {
-      const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
-      y.v[j].x = gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
-      y.v[j].y = gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
-      y.v[j].z = gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
-      y.v[j].w = gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
-    } else {
-      y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  return y;
-}
-
-// The same with gamma / beta held in LDS (per-workgroup constants of the pair kernels)
-template <int DV>
-__device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float* gamma, const float* beta, int lane,
-                                                   int D4, float eps) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
-  const float inv_d = 1.0f / (float)(D4 * 4);
-  const float mu = wave_sum(s) * inv_d;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4) {
-      const float dx = h.v[j].x - mu, dy = h.v[j].y - mu, dz = h.v[j].z - mu, dw = h.v[j].w - mu;
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
-  Row<DV> y;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4) {
-      const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
-      y.v[j].x = gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
-      y.v[j].y = gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
-      y.v[j].z = gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
-      y.v[j].w = gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
-    } else {
-      y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  return y;
-}
-
-// out = base + w1 u1 + w2 u2 + c with u1, u2, c in LDS
-template <int DV>
-__device__ __forceinline__ Row<DV> combine_rows_lds(const Row<DV>& base, float w1, const float* u1, float w2,
-                                                    const float* u2, const float* c, int lane, int D4) {
-  Row<DV> r;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4)
-      r.v[j] = fma4(w1, ld4(u1 + c4 * 4), fma4(w2, ld4(u2 + c4 * 4), base.v[j] + ld4(c + c4 * 4)));
-    else
-      r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  return r;
-}
-
-// out = base + w1 u1 + w2 u2 + c
-template <int DV>
-__device__ __forceinline__ Row<DV> combine_rows(const Row<DV>& base, float w1, const Row<DV>& u1, float w2,
-                                                const Row<DV>& u2, const Row<DV>& c) {
-  Row<DV> r;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) r.v[j] = fma4(w1, u1.v[j], fma4(w2, u2.v[j], base.v[j] + c.v[j]));
-  return r;
-}
-
 // Layer-1 entity vertices from the folded contractions (grid (chunks, B), 256 threads):
 //   et1[p] = gelu(LN(Hraw_t[p] + e_tt hm_t[b] + e_it hm_i[b] + c_t))          -> written (layer-2 GEMM operand)
 //   ei1[p] = gelu(LN(Hraw_i[p] + e_ti hm_t[b] + e_ii hm_i[b] + c_i))          -> registers only

@@ -100,6 +100,34 @@ class EntityTable:
 
     def __init__(self, text, mask, image, object, object_score):
         self.text, self.mask, self.image, self.object, self.object_score = text, mask, image, object, object_score
+        self.cache_enabled = False
+        self._cache: Optional[torch.Tensor] = None
+        self._cache_key = None
+
+    def enable_cache(self, on: bool = True) -> "EntityTable":
+        """Let inference calls score from a per-entity precompute cache (`drin_build_entity_cache`):
+        23.5 KB per entity at D=768 / R=2048, rebuilt by the first inference call after any weight change."""
+        self.cache_enabled = on
+        if not on:
+            self._cache, self._cache_key = None, None
+        return self
+
+    def _get_cache(self, call: "_Call", key, pc, prepared: torch.Tensor) -> torch.Tensor:
+        key = (key, call.cfg.precision, call.cfg.num_entities, self.text.data_ptr())
+        if key != self._cache_key or self._cache is None:
+            lib = _lib.load()
+            n = lib.drin_entity_cache_bytes(C.byref(call.cfg))
+            if n == 0:
+                raise _lib.DrinError(_lib.E_UNSUPPORTED, lib.drin_last_error().decode())
+            self._cache = None                                        # release the stale one before allocating
+            cache = torch.empty(n, dtype=torch.uint8, device=call.device)
+            ws = torch.empty(max(lib.drin_entity_cache_build_workspace_bytes(C.byref(call.cfg)), 16), dtype=torch.uint8,
+                             device=call.device)
+            stream = torch.cuda.current_stream(call.device).cuda_stream
+            _lib.check(lib.drin_build_entity_cache(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), prepared.data_ptr(),
+                                                   cache.data_ptr(), n, ws.data_ptr(), ws.numel(), stream))
+            self._cache, self._cache_key = cache, key
+        return self._cache
 
     @property
     def num_entities(self) -> int:
@@ -107,7 +135,9 @@ class EntityTable:
 
     def to(self, device) -> "EntityTable":
         mv = lambda t: None if t is None else t.to(device)  # noqa: E731
-        return EntityTable(mv(self.text), mv(self.mask), mv(self.image), mv(self.object), mv(self.object_score))
+        moved = EntityTable(mv(self.text), mv(self.mask), mv(self.image), mv(self.object), mv(self.object_score))
+        moved.cache_enabled = self.cache_enabled
+        return moved
 
     def gather(self, index: torch.Tensor):
         """Per-pair tensors exactly as `MELData.__getitem__` + collate would deliver them (data.py:87-93)."""
@@ -326,15 +356,17 @@ class Model(nn.Module):
             # table form: inference gathers inside the stream kernel; everything else (training,
             # exact-fp32 precision, geometries off the fused path) gathers with torch indexing first
             inference = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
-            in_kernel = (inference and self._prepared is not None and self.cfg.num_gcn_layers == 2
-                         and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL))
-            if in_kernel:
-                t = batch.table
+            planes = self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL)
+            t = batch.table
+            if inference and self._prepared is not None and self.cfg.num_gcn_layers == 2 and (planes or t.cache_enabled):
                 seq = batch.mention + [t.text, t.mask, t.image, t.object, t.object_score,
                                        batch.miet_similarity, batch.mtei_similarity]
                 call = _Call(self.cfg, seq, self.precision, entity_index=batch.candidates)
                 if _lib.load().drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
-                    return _DrinScore.apply(call, self._prepared, False, *params)
+                    if t.cache_enabled:                                # per-entity precompute cache
+                        return self._forward_cached(call, t, params)
+                    if planes:
+                        return _DrinScore.apply(call, self._prepared, False, *params)
             batch = batch.gathered()
         call = _Call(self.cfg, batch, self.precision)
         if call.B == 0:
@@ -343,6 +375,25 @@ class Model(nn.Module):
         # caller's mode is read here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _DrinScore.apply(call, self._prepared, training, *params)
+
+    @torch.no_grad()
+    def _forward_cached(self, call: _Call, table: EntityTable, params) -> torch.Tensor:
+        """Table-form inference from the per-entity cache (`drin_forward_cached`)."""
+        lib = _lib.load()
+        if call.B == 0:
+            return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
+        det = tuple(p.detach().contiguous() for p in params)
+        pc = _lib.DrinParamsC()
+        _fill_params(pc, det, call.per_layer)
+        pbuf = self._prepared.get(call, params, pc)
+        cache = table._get_cache(call, self._prepared.key, pc, pbuf)
+        n = lib.drin_cached_workspace_bytes(C.byref(call.cfg))
+        ws = torch.empty(max(n, 16), dtype=torch.uint8, device=call.device)
+        scores = torch.empty(call.B, call.N, dtype=torch.float32, device=call.device)
+        stream = torch.cuda.current_stream(call.device).cuda_stream
+        _lib.check(lib.drin_forward_cached(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), pbuf.data_ptr(),
+                                           cache.data_ptr(), ws.data_ptr(), ws.numel(), scores.data_ptr(), stream))
+        return scores
 
     @torch.no_grad()
     def forward_traced(self, batch: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:

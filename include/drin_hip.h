@@ -201,6 +201,26 @@ DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* bat
                                    const void* prepared, void* workspace, size_t workspace_bytes, float* scores,
                                    void* stream);
 
+/* ---- per-entity precompute cache for table-form inference ---------------------- *
+ * With frozen weights, what the first GCN layer takes from an entity (its rows of the entity_* tables,
+ * `drin/data.py:87-93`) does not depend on the mention: `W_h1 W_et x_t`, `W_h1 W_ei x_i`, `W_v1(et0)`,
+ * `W_v1(ei0)`, the normalised CLS row and the score-weighted normalised object row are computed ONCE per
+ * entity and weight version into `cache` ([num_entities][5 D + R + 4] fp32).  drin_forward_cached then
+ * scores table-form batches (drin_batch.entity_index + the mention-side tensors + the two similarity
+ * matrices; the entity_* pointers are not read) with one gathered pass over cache rows and the layer-2
+ * contraction - same scores as drin_forward_prepared to fp32 re-association.  `cfg.num_entities` = table
+ * rows; `prepared` = the drin_prepare buffer of the same weights.  `tables`: a drin_batch whose entity_*
+ * fields point at the tables (other fields unused). */
+DRIN_API size_t drin_entity_cache_bytes(const drin_config* cfg);
+DRIN_API size_t drin_entity_cache_build_workspace_bytes(const drin_config* cfg);
+DRIN_API size_t drin_cached_workspace_bytes(const drin_config* cfg);
+DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* tables, const drin_params* params,
+                                     const void* prepared, void* cache, size_t cache_bytes, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
+                                 const void* prepared, const void* cache, void* workspace, size_t workspace_bytes,
+                                 float* scores, void* stream);
+
 /* Building blocks of the split-bf16 precision: x = hi + lo with hi, lo bf16 planes (n % 4 == 0), and the
  * contraction y = x w^T (+ bias) on such planes by LDS-DMA + bf16 MFMA (k % 32 == 0).  Plane pointers are
  * device pointers to bf16 arrays with the row strides of the fp32 originals. */

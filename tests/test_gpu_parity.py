@@ -596,6 +596,93 @@ def test_inner_feature_dims_take_the_pooled_path():
     assert (got - ref).abs().max().item() <= 2e-5
 
 
+# ---- per-entity precompute cache ----------------------------------------------------------
+@pytest.mark.parametrize("kw", [
+    dict(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY),
+    dict(num_candidates_data=20, **TINY),
+    dict(num_candidates_data=20, gcn_edge_type="static", **TINY),
+    dict(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=7, gcn_edge_enabled=(1, 0, 1, 1), **TINY),
+    dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16,
+         resnet_num_region=4),
+], ids=["tiny_tokens", "tiny_pooled", "tiny_static", "tiny_mask", "wikimel_dims"])
+def test_entity_cache_scores_match_oracle_and_uncached(kw):
+    """Scoring from the per-entity cache == the oracle on the gathered 14-sequence (1e-5) == the un-cached
+    table path (fp32 re-association only), for both precisions; a weight update rebuilds the cache."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = DrinConfig(**kw)
+    token_level = cfg.token_level_entities
+    sd = synth.make_state_dict(cfg, 8)
+    E, B, N = 83, 5, cfg.num_candidates_model
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 71)
+    table = EntityTable(tab[7][0], tab[8][0] if token_level else None, tab[9][0], tab[10][0], tab[11][0]).to(DEV)
+    men = _to_dev(synth.make_batch(cfg, B, 72))
+    cand = torch.randint(0, E, (B, N), generator=torch.Generator().manual_seed(3)).to(DEV)
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    ref = O.forward(sd, [t.cpu() for t in ib.gathered()], dynamic=cfg.gcn_edge_type == "dynamic",
+                    edge_enabled=cfg.gcn_edge_enabled)
+    for precision in ("bf16x3_all", "f32"):
+        model = Model(cfg, precision=precision).to(DEV).eval()
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            table.enable_cache(False)
+            plain = model(ib)
+            table.enable_cache()
+            _lib.profile_begin()
+            cached = model(ib)
+            prof = _lib.profile_end()
+            again = model(ib)                                   # second call: cache reused, same bits
+        err = (cached.cpu() - ref).abs().max().item()
+        print(f"{precision}: cached max |score - oracle| = {err:.3e}, vs un-cached {(cached - plain).abs().max().item():.3e}")
+        assert err <= 1e-5 and (cached - plain).abs().max().item() <= 4e-6
+        assert torch.equal(cached, again)
+        assert table._cache is not None and table._cache.numel() == E * (5 * cfg.gcn_embed_dim + cfg.resnet_embed_dim + 4) * 4
+        # a weight update invalidates the cache (it is a function of the weights)
+        key = table._cache_key
+        with torch.no_grad():
+            model.vertex_encoder.entity_image_linear.weight.mul_(1.5)
+            moved = model(ib)
+            table.enable_cache(False)
+            moved_plain = model(ib)
+            table.enable_cache()
+        assert table._cache_key != key
+        assert (moved - moved_plain).abs().max().item() <= 4e-6 and (moved - cached).abs().max().item() > 1e-4
+    # training never takes the cache
+    model = Model(cfg).to(DEV)
+    model.load_state_dict(sd)
+    model(ib).sum().backward()
+    assert model.gcn_layers[0].w_h.weight.grad is not None
+    table.enable_cache(False)
+
+
+def test_entity_cache_out_of_range_index_and_nan_entity():
+    """Out-of-range candidate indices clamp like the stream kernel's gather; an entity whose token slice is
+    empty (ntok <= 2, ghmfc.py:248) scores NaN for its pairs only."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=12, max_entity_attr_token_len=6, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    E, B, N = 30, 3, cfg.num_candidates_model
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 5)
+    mask = tab[8][0].clone()
+    mask[7] = 0
+    mask[7, :2] = 1                                             # ntok = 2: mean of an empty slice
+    table = EntityTable(tab[7][0], mask, tab[9][0], tab[10][0], tab[11][0]).to(DEV).enable_cache()
+    men = _to_dev(synth.make_batch(cfg, B, 6))
+    cand = torch.randint(0, E, (B, N), generator=torch.Generator().manual_seed(1))
+    cand[cand == 7] = 8
+    cand[0, 3] = 7
+    cand[1, 0], cand[2, 5] = -4, E + 9
+    model = Model(cfg, precision="bf16x3_all").to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        s = model(IndexedBatch(men[:7], table, cand.to(DEV), men[12], men[13])).cpu()
+        clamped = cand.clamp(0, E - 1)
+        table.enable_cache(False)
+        s2 = model(IndexedBatch(men[:7], table, clamped.to(DEV), men[12], men[13])).cpu()
+    assert torch.isnan(s[0]).all() and torch.isnan(s2[0]).all()   # the NaN vertex reaches the mention aggregates
+    assert not torch.isnan(s[1:]).any()
+    assert (s[1:] - s2[1:]).abs().max().item() <= 4e-6
+
+
 # ---- caller-side loss + metric on the device (SURVEY.md 8f-3) ---------------------------------------------
 def _loss_case(B, N, seed, ties=False):
     g = np.random.Generator(np.random.Philox(key=[seed, 21]))

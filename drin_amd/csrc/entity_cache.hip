@@ -134,22 +134,50 @@ struct CachedArgs {
 };
 
 // grid (chunks, B), 256 threads; wave w takes candidates c0 + w, c0 + w + 4, ... of its chunk
-template <int DV, int RV>
-__global__ void __launch_bounds__(256) k_cached_pairs(const CachedArgs a) {
+#ifndef DRIN_CACHED_PAIRS_WG_PER_CU
+#define DRIN_CACHED_PAIRS_WG_PER_CU 2
+#endif
+// EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048) - the column guards of the row helpers fold away and the
+// loop body becomes straight-line code
+template <int DV, int RV, bool EXACT>
+__global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pairs(const CachedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int D4 = a.D4, R4 = a.R4, D = D4 * 4, R = R4 * 4;
+  const int D4 = EXACT ? DV * 64 : a.D4, R4 = EXACT ? RV * 64 : a.R4, D = D4 * 4, R = R4 * 4;
   float* l_s = lds;               // [D]   span mean / max(|.|, eps)
   float* l_mu = l_s + D;          // [R]   sum_i ms_i mobj_i / max(|mobj_i|, eps)
   float* l_fu = l_mu + R;         // [2 D] W_u(mt0), W_u(mi0)
   float* l_const = l_fu + 2 * D;  // [6 D] hm_t, hm_i, c_t, c_i, gamma, beta
-  float* l_red = l_const + 6 * D; // [4 D] cross-wave reduction
-  float* l_small = l_red + 4 * D; // [Km] ms_i / |mobj_i|, then [4] edge sums   (Km <= 8)
+  float* l_small = l_const + 6 * D; // [Km] ms_i / |mobj_i| (Km <= 8), then [4][4] per-wave edge sums
+  float* l_acc = l_small + 32;    // [4 waves][3 D] A_t, A_i, S2: the cross-candidate sums live in LDS, not in VGPRs -
+                                  // the register file is what bounds how much of the NEXT row can be in flight
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t b = blockIdx.y;
   const int64_t M = (int64_t)a.B * a.N;
   const int per = (a.N + a.chunks - 1) / a.chunks;
   const int n_begin = blockIdx.x * per, n_end = min(a.N, n_begin + per);
   const bool dyn = a.dynamic != 0;
+
+  // Candidate rows of this wave, 4 at a time (candidates base + wave + 4 k of a 16-candidate group): requested as
+  // vector loads well before they are needed, then made wave-uniform - as scalars the row base lives in SGPRs and
+  // every load of the row shares it.
+  auto request_indices = [&](int64_t (&v)[4], int base) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = base + wave + 4 * k;
+      v[k] = n < n_end ? a.entity_index[b * a.N + n] : 0;
+    }
+  };
+  auto uniform_indices = [&](int64_t (&dst)[4], const int64_t (&v)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t e = v[k];
+      e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)e), hi = __builtin_amdgcn_readfirstlane((uint32_t)(e >> 32));
+      dst[k] = (int64_t)(((uint64_t)hi << 32) | lo);
+    }
+  };
+  int64_t ent[4], ent_v[4];
+  request_indices(ent_v, n_begin);  // lands under the prologue
 
   // ---- per-workgroup prologue ---------------------------------------------------------------------------
   {
@@ -163,6 +191,27 @@ __global__ void __launch_bounds__(256) k_cached_pairs(const CachedArgs a) {
         st4(l_fu + i * 4, ld4(a.fu + ((int64_t)which * a.B + b) * a.ldfu + c4 * 4));
       }
   }
+  struct PairRow {  // the operands of the edge phase: 17 KB of the 23.5 KB row
+    Row<DV> chat, fvt, fvi;
+    Row<RV> ohat;
+    float sg, mtei, miet;
+  };
+  auto fetch = [&](PairRow& r, int64_t e, int64_t p) {
+    const float* row = a.cache + e * a.ldc;
+    r.chat = load_row<DV>(row + 4 * D, lane, D4);
+    r.ohat = load_row<RV>(row + 5 * D, lane, R4);
+    r.sg = row[5 * D + R];
+    if (dyn) {
+      r.fvt = load_row<DV>(row + 2 * D, lane, D4);
+      r.fvi = load_row<DV>(row + 3 * D, lane, D4);
+    }
+    r.mtei = a.mtei[p];
+    r.miet = a.miet[p];
+  };
+  PairRow ra, rb;  // two named buffers (an indexed array of them ends up in scratch memory)
+  uniform_indices(ent, ent_v);
+  if (n_begin + wave < n_end) fetch(ra, ent[0], b * a.N + n_begin + wave);  // first row: in flight under the rest of the prologue
+
   for (int i = wave; i < a.Km; i += 4) {  // model.py:88 re-normalises the same mention rows for every pair
     const Row<RV> m = load_row<RV>(a.mobj + (b * a.Km + i) * R, lane, R4);
     const float nrm = fmaxf(sqrtf(wave_sum(dot_rows<RV>(m, m))), a.cos_eps);
@@ -187,40 +236,57 @@ __global__ void __launch_bounds__(256) k_cached_pairs(const CachedArgs a) {
   const float *l_hm_t = l_const, *l_hm_i = l_const + D, *l_ct = l_const + 2 * D, *l_ci = l_const + 3 * D;
   const float *l_gamma = l_const + 4 * D, *l_beta = l_const + 5 * D;
 
-  Row<DV> A_t = zero_row<DV>(), A_i = zero_row<DV>(), S_t = zero_row<DV>(), S_i = zero_row<DV>();
+  // A_t / A_i: layer-1 aggregates of the mention text / image vertex (already through W_h1);
+  // S2 = sum_n (e1_tt et' + e1_ti ei'): the two layer-2 aggregates only ever appear added (model.py:143)
+  float* acc = l_acc + wave * 3 * D;
+#pragma unroll
+  for (int j = 0; j < 3 * DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < 3 * D4) st4(acc + c4 * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  auto accumulate2 = [&](float* dst, float w1, const Row<DV>& x1, float w2, const Row<DV>& x2) {
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const int c4 = lane + 64 * j;
+      if (c4 < D4) st4(dst + c4 * 4, fma4(w1, x1.v[j], fma4(w2, x2.v[j], ld4(dst + c4 * 4))));
+    }
+  };
   float sg_tt = 0.f, sg_ti = 0.f, sg_it = 0.f, sg_ii = 0.f;
   const float inv_d = 1.0f / (float)D;
 
-  for (int n = n_begin + wave; n < n_end; n += 4) {
+  // A chunk is one group of at most 16 candidates, 4 per wave.  Per pair the dependent chain is index -> row ->
+  // arithmetic; left alone it costs three serial HBM round trips per pair.  So: candidate indices are fetched
+  // before the prologue, all loads of a row are issued together, and the edge-phase operands of the NEXT row are
+  // requested as soon as the (short) edge phase of the current one has freed their registers - they land
+  // under the long LayerNorm / GELU phase.
+  auto step = [&](const PairRow& cur, PairRow& nxt, const int n, const int64_t e_cur, const int64_t e_next) {
+    if (n >= n_end) return;
     const int64_t p = b * a.N + n;
-    int64_t e = a.entity_index[p];
-    e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
-    const float* row = a.cache + e * a.ldc;
-    // the whole row is requested up front: ~23 KB in flight per wave
-    const Row<DV> ht = load_row<DV>(row, lane, D4);
-    const Row<DV> hi = load_row<DV>(row + D, lane, D4);
-    const Row<DV> chat = load_row<DV>(row + 4 * D, lane, D4);
-    const Row<RV> ohat = load_row<RV>(row + 5 * D, lane, R4);
-    const float sg_e = row[5 * D + R];
+    const PairRow& r = cur;
+    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later pairs' loads into this one (spills)
+    // the vertex-phase operands of THIS pair: requested now, needed after the edge phase
+    const Row<DV> ht = load_row<DV>(a.cache + e_cur * a.ldc, lane, D4);
+    const Row<DV> hi = load_row<DV>(a.cache + e_cur * a.ldc + D, lane, D4);
     // ---- static edges (model.py:71-92, 201-204) ------------------------------------------------------------
-    const float e_tt = wave_sum(dot_row_lds<DV>(chat, l_s, lane, D4)) * a.mask[0];
-    const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
-    const float e_it = (a.miet[p] / a.clip) * a.mask[2];
-    const float e_ii = wave_sum(dot_row_lds<RV>(ohat, l_mu, lane, R4)) / (sum_ms * sg_e + a.miei_eps) * a.mask[3];
+    const float e_tt = wave_sum(dot_row_lds<DV>(r.chat, l_s, lane, D4)) * a.mask[0];
+    const float e_ti = (r.mtei / a.clip) * a.mask[1];
+    const float e_it = (r.miet / a.clip) * a.mask[2];
+    const float e_ii = wave_sum(dot_row_lds<RV>(r.ohat, l_mu, lane, R4)) / (sum_ms * r.sg + a.miei_eps) * a.mask[3];
     // ---- layer-2 edges (model.py:148-153; static: pass-through, model.py:136) ------------------------------
     float n_tt = e_tt, n_ti = e_ti, n_it = e_it, n_ii = e_ii;
     if (dyn) {
-      const Row<DV> fvt = load_row<DV>(row + 2 * D, lane, D4);
-      const Row<DV> fvi = load_row<DV>(row + 3 * D, lane, D4);
-      n_tt = sigmoidf(wave_sum(dot_row_lds<DV>(fvt, l_fu, lane, D4)) * inv_d + e_tt);
-      n_ti = sigmoidf(wave_sum(dot_row_lds<DV>(fvi, l_fu, lane, D4)) * inv_d + e_ti);
-      n_it = sigmoidf(wave_sum(dot_row_lds<DV>(fvt, l_fu + D, lane, D4)) * inv_d + e_it);
-      n_ii = sigmoidf(wave_sum(dot_row_lds<DV>(fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
+      n_tt = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvt, l_fu, lane, D4)) * inv_d + e_tt);
+      n_ti = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvi, l_fu, lane, D4)) * inv_d + e_ti);
+      n_it = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvt, l_fu + D, lane, D4)) * inv_d + e_it);
+      n_ii = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
     }
     n_tt *= a.mask[0];
     n_ti *= a.mask[1];
     n_it *= a.mask[2];
     n_ii *= a.mask[3];
+    __builtin_amdgcn_sched_barrier(0);
+    if (n + 4 < n_end) fetch(nxt, e_next, p + 4);
+    __builtin_amdgcn_sched_barrier(0);
     if (lane == 0) {
       a.e1m[p] = n_tt;
       a.e1m[M + p] = n_ti;
@@ -228,10 +294,8 @@ __global__ void __launch_bounds__(256) k_cached_pairs(const CachedArgs a) {
       a.e1m[3 * M + p] = n_ii;
     }
     // ---- layer-1 mention aggregates, already through W_h1 (model.py:143-144) -------------------------------
-    axpy_row<DV>(A_t, e_tt, ht);
-    axpy_row<DV>(A_t, e_ti, hi);
-    axpy_row<DV>(A_i, e_it, ht);
-    axpy_row<DV>(A_i, e_ii, hi);
+    accumulate2(acc, e_tt, ht, e_ti, hi);
+    accumulate2(acc + D, e_it, ht, e_ii, hi);
     sg_tt += e_tt;
     sg_ti += e_ti;
     sg_it += e_it;
@@ -241,44 +305,41 @@ __global__ void __launch_bounds__(256) k_cached_pairs(const CachedArgs a) {
                                             l_beta, lane, D4, a.ln_eps);
     if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
     if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
-    axpy_row<DV>(S_t, n_tt, et1);
     const Row<DV> ei1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4), l_gamma,
                                             l_beta, lane, D4, a.ln_eps);
-    axpy_row<DV>(S_i, n_ti, ei1);
+    accumulate2(acc + 2 * D, n_tt, et1, n_ti, ei1);
+  };
+  {  // a chunk is one group of at most 16 candidates (chunks = ceil(N / 16))
+    const int n0 = n_begin + wave;
+    step(ra, rb, n0, ent[0], ent[1]);
+    step(rb, ra, n0 + 4, ent[1], ent[2]);
+    step(ra, rb, n0 + 8, ent[2], ent[3]);
+    step(rb, ra, n0 + 12, ent[3], 0);
   }
 
   // ---- fixed-order cross-wave reduction, one partial per (mention, chunk) --------------------------------
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-#pragma unroll
-      for (int j = 0; j < DV; ++j) {
-        const int c4 = lane + 64 * j;
-        if (c4 < D4) {
-          float* q = l_red + c4 * 4;
-          st4(q, w == 0 ? A_t.v[j] : ld4(q) + A_t.v[j]);
-          st4(q + D, w == 0 ? A_i.v[j] : ld4(q + D) + A_i.v[j]);
-          st4(q + 2 * D, w == 0 ? S_t.v[j] : ld4(q + 2 * D) + S_t.v[j]);
-          st4(q + 3 * D, w == 0 ? S_i.v[j] : ld4(q + 3 * D) + S_i.v[j]);
-        }
-      }
-      if (lane == 0) {
-        float* s4 = l_small + 8;
-        s4[0] = (w == 0 ? 0.f : s4[0]) + sg_tt;
-        s4[1] = (w == 0 ? 0.f : s4[1]) + sg_ti;
-        s4[2] = (w == 0 ? 0.f : s4[2]) + sg_it;
-        s4[3] = (w == 0 ? 0.f : s4[3]) + sg_ii;
-      }
-    }
+  if (lane == 0) {
+    float* s4 = l_small + 8 + 4 * wave;
+    s4[0] = sg_tt;
+    s4[1] = sg_ti;
+    s4[2] = sg_it;
+    s4[3] = sg_ii;
   }
   __syncthreads();
   float* out1 = a.c_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D + 4);
   float* out2 = a.s2_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D);
+  auto waves_sum = [&](int i) {  // float4 column i of the [3 D] accumulators, waves in order
+    return ((ld4(l_acc + i * 4) + ld4(l_acc + 3 * D + i * 4)) + ld4(l_acc + 6 * D + i * 4)) + ld4(l_acc + 9 * D + i * 4);
+  };
   for (int i = threadIdx.x; i < 2 * D4; i += 256) {
-    st4(out1 + i * 4, ld4(l_red + i * 4));
-    st4(out2 + i * 4, ld4(l_red + 2 * D + i * 4));
+    st4(out1 + i * 4, waves_sum(i));
+    // k_mention_input2 adds the two halves of its partial: the merged sum goes in the first, zero in the second
+    st4(out2 + i * 4, i < D4 ? waves_sum(2 * D4 + i) : make_float4(0.f, 0.f, 0.f, 0.f));
   }
-  if (threadIdx.x < 4) out1[2 * D + threadIdx.x] = l_small[8 + threadIdx.x];
+  if (threadIdx.x < 4) {
+    const float* s4 = l_small + 8 + threadIdx.x;
+    out1[2 * D + threadIdx.x] = ((s4[0] + s4[4]) + s4[8]) + s4[12];
+  }
 }
 
 // Pre-LayerNorm layer-1 mention vertices from the chunk partials (model.py:143-144 + :128), W_h1 already applied:
@@ -312,7 +373,9 @@ struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
-    chunks = (int)((N + 15) / 16);  // a function of N only: a mention scores bit-identically in any batch
+    // a function of N only, so a mention scores bit-identically in any batch.  (64 candidates per workgroup for
+    // long lists - amortising the prologue 4x - measured SLOWER: 1.97 vs 1.49 ms at N = 1001.)
+    chunks = (int)((N + 15) / 16);
     size_t off = 0;
     auto take = [&off](size_t n) {
       const size_t o = off;
@@ -351,11 +414,11 @@ static int cache_supported(const drin_config* c) {
   return DRIN_OK;
 }
 
-template <int DV, int RV>
+template <int DV, int RV, bool EXACT>
 static int launch_cached_pairs_t(const CachedArgs& a, hipStream_t st) {
   const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;
-  const size_t lds = sizeof(float) * (13 * D + R + 16);
-  auto kern = k_cached_pairs<DV, RV>;
+  const size_t lds = sizeof(float) * (9 * D + R + 32 + 12 * D);
+  auto kern = k_cached_pairs<DV, RV, EXACT>;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -558,9 +621,11 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   a.clip = cfg->clip_scale;
   a.ln_eps = cfg->layer_norm_eps;
   if (a.D4 <= 64 && a.R4 <= 64)
-    DRIN_TRY((launch_cached_pairs_t<1, 1>(a, st)));
+    DRIN_TRY((launch_cached_pairs_t<1, 1, false>(a, st)));
+  else if (a.D4 == 192 && a.R4 == 512)
+    DRIN_TRY((launch_cached_pairs_t<3, 8, true>(a, st)));
   else
-    DRIN_TRY((launch_cached_pairs_t<3, 8>(a, st)));
+    DRIN_TRY((launch_cached_pairs_t<3, 8, false>(a, st)));
 
   // (3) layer-1 mention vertices, then what layer 2 needs from them
   float* vm1 = ws + L.vm1;

@@ -15,10 +15,11 @@ namespace drin {
 
 // ------------------------------------------------------------------------------------------------
 // grid (chunks, B), 256 threads.  Wave w of the workgroup takes candidates c0 + w, c0 + w + 4, ...
-template <int DV, int RV, bool TOKENS>
+// EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048): the column guards of the row helpers fold away
+template <int DV, int RV, bool TOKENS, bool EXACT>
 __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int D4 = a.D4, R4 = a.R4, D = D4 * 4, R = R4 * 4;
+  const int D4 = EXACT ? DV * 64 : a.D4, R4 = EXACT ? RV * 64 : a.R4, D = D4 * 4, R = R4 * 4;
   float* l_mobj = lds;                          // [Km][R]
   float* l_q = l_mobj + a.Km * R;               // [2][R]   q_ti, q_ii
   float* l_red = l_q + 2 * R;                   // [2 D + 2 R] cross-wave reduction of the weighted sums
@@ -223,10 +224,10 @@ size_t entity_stream_lds_bytes(const StreamArgs& a) {
   return sizeof(float) * (a.Km * R + 2 * R + 2 * D + 2 * R + 3 * D + a.Km + 4);
 }
 
-template <int DV, int RV, bool TOKENS>
+template <int DV, int RV, bool TOKENS, bool EXACT>
 static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
   const size_t lds = entity_stream_lds_bytes(a);
-  auto kern = k_entity_stream<DV, RV, TOKENS>;
+  auto kern = k_entity_stream<DV, RV, TOKENS, EXACT>;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -247,8 +248,12 @@ int launch_entity_stream(const StreamArgs& a, hipStream_t st) {
     return DRIN_E_SHAPE;
   }
   const bool tok = a.T > 0;
-  if (a.D4 <= 64 && a.R4 <= 64) return tok ? launch_stream_t<1, 1, true>(a, st) : launch_stream_t<1, 1, false>(a, st);
-  if (a.D4 <= 192 && a.R4 <= 512) return tok ? launch_stream_t<3, 8, true>(a, st) : launch_stream_t<3, 8, false>(a, st);
+  if (a.D4 <= 64 && a.R4 <= 64)
+    return tok ? launch_stream_t<1, 1, true, false>(a, st) : launch_stream_t<1, 1, false, false>(a, st);
+  if (a.D4 == 192 && a.R4 == 512)
+    return tok ? launch_stream_t<3, 8, true, true>(a, st) : launch_stream_t<3, 8, false, true>(a, st);
+  if (a.D4 <= 192 && a.R4 <= 512)
+    return tok ? launch_stream_t<3, 8, true, false>(a, st) : launch_stream_t<3, 8, false, false>(a, st);
   set_error("entity_stream: D=%d R=%d outside the built instantiations", a.D4 * 4, a.R4 * 4);
   return DRIN_E_UNSUPPORTED;
 }
@@ -346,11 +351,11 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 //   et1[p] = gelu(LN(Hraw_t[p] + e_tt hm_t[b] + e_it hm_i[b] + c_t))          -> written (layer-2 GEMM operand)
 //   ei1[p] = gelu(LN(Hraw_i[p] + e_ti hm_t[b] + e_ii hm_i[b] + c_i))          -> registers only
 // and the layer-2 mention aggregates  S2_t[b] = sum_n e1_tt et1,  S2_i[b] = sum_n e1_ti ei1  per chunk.
-template <int DV>
+template <int DV, bool EXACT>
 __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
   __shared__ __attribute__((aligned(16))) float l_red[2 * DV * 256];
   __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm_t, hm_i, c_t, c_i, gamma, beta
-  const int D4 = a.D4, D = D4 * 4;
+  const int D4 = EXACT ? DV * 64 : a.D4, D = D4 * 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t b = blockIdx.y;
   const int64_t M = (int64_t)a.B * a.N;
@@ -405,9 +410,11 @@ int launch_pair_layer1(const PairArgs& a, hipStream_t st) {
   if (a.B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
   if (a.D4 <= 64)
-    hipLaunchKernelGGL(k_pair_layer1<1>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
-  else if (a.D4 <= 192)
-    hipLaunchKernelGGL(k_pair_layer1<3>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_pair_layer1<1, false>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 == 192)
+    hipLaunchKernelGGL((k_pair_layer1<3, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 < 192)
+    hipLaunchKernelGGL((k_pair_layer1<3, false>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
   else {
     set_error("pair_layer1: D=%d outside the built instantiations", a.D4 * 4);
     return DRIN_E_UNSUPPORTED;
@@ -446,10 +453,10 @@ int launch_mention_input2(const float* part, const float* mt1, float* out, int B
 // Layer-2 entity-text vertex and the score (model.py:128 for et'', :207-209), grid (chunks, B), 256 threads:
 //   et2 = gelu(LN(H2raw[p] + e1_tt hm2_t[b] + e1_it hm2_i[b] + b_h2)),  score[p] = cos(mt2[b], et2)
 // The five per-mention / constant vectors live in LDS; each wave walks candidates of its chunk.
-template <int DV>
+template <int DV, bool EXACT>
 __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
   __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm2_t, hm2_i, b_h2, gamma, beta, mt2
-  const int D4 = a.D4, D = D4 * 4;
+  const int D4 = EXACT ? DV * 64 : a.D4, D = D4 * 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t b = blockIdx.y;
   const int64_t M = (int64_t)a.B * a.N;
@@ -481,9 +488,11 @@ int launch_pair_final(const FinalArgs& a, hipStream_t st) {
   if (a.B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
   if (a.D4 <= 64)
-    hipLaunchKernelGGL(k_pair_final<1>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
-  else if (a.D4 <= 192)
-    hipLaunchKernelGGL(k_pair_final<3>, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_pair_final<1, false>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 == 192)
+    hipLaunchKernelGGL((k_pair_final<3, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 < 192)
+    hipLaunchKernelGGL((k_pair_final<3, false>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
   else {
     set_error("pair_final: D=%d outside the built instantiations", a.D4 * 4);
     return DRIN_E_UNSUPPORTED;

@@ -74,6 +74,8 @@ EXPORTS = {
     "drin_edges_fwd": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.c_void_p, C.c_void_p, C.c_void_p]),
     "drin_pool_fwd": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drin_linear_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "drin_linear_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "drin_forward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                C.c_size_t, C.c_void_p, C.c_int, C.POINTER(DrinTraceC), C.c_void_p]),
     "drin_backward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
@@ -137,7 +139,7 @@ def profile_begin(max_launches: int = 65536) -> None:
 
 
 def profile_end() -> dict:
-    """{class name: (gpu milliseconds, launches)} since profile_begin on this thread."""
+    """{class name: (gpu milliseconds, launches)} since profile_begin (launches from every thread)."""
     ms = (C.c_double * KERNEL_CLASSES)()
     n = (C.c_int64 * KERNEL_CLASSES)()
     check(load().drin_profile_end(ms, n))

@@ -1,9 +1,13 @@
 // C ABI of libdrin_hip.so (include/drin_hip.h): argument validation, workspace layout and the launch
 // sequence of Model.forward (drin/model.py:164-209).  Host code only; kernels live in the sibling files.
 #include <stdarg.h>
+
+#include <atomic>
+#include <mutex>
 #include <stdio.h>
 #include <string.h>
 
+#include "fused.h"
 #include "internal.h"
 #include "layout.h"
 
@@ -23,20 +27,27 @@ int hip_fail(hipError_t e, const char* what) {
   return DRIN_E_HIP;
 }
 
-// ---- thread-local kernel profile ---------------------------------------------------------------
+// ---- process-wide kernel profile ---------------------------------------------------------------
+// One profile at a time per process; launches from ANY thread are attributed while it is open (autograd
+// runs drin_backward on its own thread).  Slots are claimed with an atomic counter; begin / end are
+// serialised by a mutex and must not race with launches they are meant to bracket.
 struct Profile {
-  bool open = false;
-  int capacity = 0, used = 0;
+  std::atomic<bool> open{false};
+  int capacity = 0;
+  std::atomic<int> used{0};
   hipEvent_t* start = nullptr;
   hipEvent_t* stop = nullptr;
   int* cls = nullptr;
 };
-static thread_local Profile g_prof;
+static Profile g_prof;
+static std::mutex g_prof_mutex;
 
 KernelTimer::KernelTimer(int kernel_class, hipStream_t st) : slot(-1), stream(st) {
   Profile& p = g_prof;
-  if (!p.open || p.used >= p.capacity) return;
-  slot = p.used++;
+  if (!p.open.load(std::memory_order_acquire)) return;
+  const int s = p.used.fetch_add(1, std::memory_order_relaxed);
+  if (s >= p.capacity) return;
+  slot = s;
   p.cls[slot] = kernel_class;
   (void)hipEventRecord(p.start[slot], st);
 }
@@ -53,7 +64,11 @@ static void profile_free(Profile& p) {
   delete[] p.start;
   delete[] p.stop;
   delete[] p.cls;
-  p = Profile();
+  p.start = p.stop = nullptr;
+  p.cls = nullptr;
+  p.capacity = 0;
+  p.used.store(0);
+  p.open.store(false);
 }
 
 int validate_config(const drin_config* c) {
@@ -350,6 +365,33 @@ int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y,
   return launch_gemm_nt(x, k, w, k, bias, y, n_out, rows, n_out, k, false, precision, (hipStream_t)stream);
 }
 
+int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t rows,
+                    int32_t n_out, int32_t k, int32_t precision, float* scratch, void* stream) {
+  if (!dy || (dx && !w) || (dw && !x)) {
+    set_error("drin_linear_bwd: NULL operand");
+    return DRIN_E_NULL;
+  }
+  if (rows < 0 || n_out <= 0 || k <= 0) {
+    set_error("drin_linear_bwd: bad shape rows=%lld n_out=%d k=%d", (long long)rows, n_out, k);
+    return DRIN_E_SHAPE;
+  }
+  if (rows == 0) return DRIN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool x3 = precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL;
+  if (dx) {
+    // the contraction index of dx = dy W is n: the NT kernel needs W^T [k][n_out]
+    if (x3 && scratch && rows >= 1024 && (n_out % 32) == 0 && (k % 4) == 0) {
+      DRIN_TRY(launch_transpose(w, scratch, n_out, k, st));
+      DRIN_TRY(launch_gemm_nt_bf16x3(dy, n_out, scratch, n_out, nullptr, dx, k, rows, k, n_out, st));
+    } else {
+      DRIN_TRY(launch_gemm_nn(dy, n_out, w, k, dx, k, rows, k, n_out, false, precision, st));
+    }
+  }
+  if (dw) DRIN_TRY(launch_gemm_tn(dy, n_out, x, k, dw, k, rows, n_out, k, precision, st));
+  if (db) DRIN_TRY(launch_colsum(dy, db, rows, n_out, st));
+  return DRIN_OK;
+}
+
 int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                  size_t workspace_bytes, float* scores, int keep_for_backward, const drin_trace* trace, void* stream) {
   DRIN_TRY(validate_config(cfg));
@@ -493,8 +535,9 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
 }
 
 int drin_profile_begin(int max_launches) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   Profile& p = g_prof;
-  if (p.open) profile_free(p);
+  if (p.open.load()) profile_free(p);
   if (max_launches <= 0 || max_launches > (1 << 20)) {
     set_error("drin_profile_begin: max_launches=%d outside (0, 2^20]", max_launches);
     return DRIN_E_SHAPE;
@@ -512,15 +555,16 @@ int drin_profile_begin(int max_launches) {
     }
   }
   p.capacity = max_launches;
-  p.used = 0;
-  p.open = true;
+  p.used.store(0);
+  p.open.store(true, std::memory_order_release);
   return DRIN_OK;
 }
 
 int drin_profile_end(double* ms_by_class, int64_t* launches_by_class) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   Profile& p = g_prof;
-  if (!p.open) {
-    set_error("drin_profile_end: no profile open on this thread");
+  if (!p.open.load()) {
+    set_error("drin_profile_end: no profile open");
     return DRIN_E_SHAPE;
   }
   for (int k = 0; k < DRIN_KC_COUNT; ++k) {
@@ -528,7 +572,10 @@ int drin_profile_end(double* ms_by_class, int64_t* launches_by_class) {
     if (launches_by_class) launches_by_class[k] = 0;
   }
   int status = DRIN_OK;
-  for (int i = 0; i < p.used; ++i) {
+  p.open.store(false);  // launches from other threads stop claiming slots from here on
+  const int claimed = p.used.load();
+  const int used = claimed < p.capacity ? claimed : p.capacity;
+  for (int i = 0; i < used; ++i) {
     hipError_t e = hipEventSynchronize(p.stop[i]);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
@@ -542,7 +589,7 @@ int drin_profile_end(double* ms_by_class, int64_t* launches_by_class) {
       if (launches_by_class) launches_by_class[k] += 1;
     }
   }
-  if (status == DRIN_OK && p.used >= p.capacity) {
+  if (status == DRIN_OK && claimed >= p.capacity) {
     set_error("drin_profile_end: profile overflowed its %d launch slots", p.capacity);
     status = DRIN_E_SHAPE;
   }
@@ -612,6 +659,21 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   bool all_enabled = true;
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
 
+  // dX (+)= dY W.  Pair-sized products in split-bf16 precision run on the NT kernel against W^T, transposed into
+  // workspace scratch right before use (a D x D transpose is ~3 us; the product it feeds is 2.5x faster than
+  // the exact-fp32 MFMA one); everything else takes the exact fp32 NN kernel.
+  const bool x3 = prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL;
+  auto gemm_nn = [&](const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int64_t rows, int n_out,
+                     int k_red, bool accumulate) -> int {
+    // w is [k_red][n_out] contiguous
+    if (x3 && rows >= 1024 && (k_red % 32) == 0 && (n_out % 4) == 0 && (size_t)k_red * n_out <= (size_t)D * D) {
+      float* wt = ws + L.wt;
+      DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));
+      return launch_gemm_nt_bf16x3(dy, lddy, wt, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate);
+    }
+    return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st);
+  };
+
   // score = cos(mt_L, et_L) (model.py:207-209)
   int cur = 0;
   DRIN_TRY(launch_cosine_bwd(ws + L.vm[nl], ws + L.ve[nl], grad_scores, g_vm[cur], g_ve[cur], cos_scratch, B, N, D,
@@ -630,17 +692,17 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     const float* st_e = ws + L.ln_stat_e[l];
     // (a) LayerNorm + GELU backward; column sums give dgamma, dbeta and db_h
     DRIN_TRY(launch_layernorm_gelu_bwd(ws + L.h_m[l], st_m, st_m + 2 * (size_t)B, W.ln_weight, W.ln_bias, gm,
-                                       G.ln_weight, G.ln_bias, G.b_h, (int64_t)types * B, D, st));
+                                       G.ln_weight, G.ln_bias, G.b_h, ws + L.ln_part, (int64_t)types * B, D, st));
     DRIN_TRY(launch_layernorm_gelu_bwd(ws + L.h_e[l], st_e, st_e + 2 * M, W.ln_weight, W.ln_bias, ge, G.ln_weight,
-                                       G.ln_bias, G.b_h, (int64_t)types * M, D, st));
+                                       G.ln_bias, G.b_h, ws + L.ln_part, (int64_t)types * M, D, st));
     // (b) dW_h += dH^T A
     if (G.w_h) {
       DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st));
       DRIN_TRY(launch_gemm_tn(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D, prec, st));
     }
     // (c) dA = dH W_h
-    DRIN_TRY(launch_gemm_nn(gm, D, W.w_h, D, dA_m, D, (int64_t)types * B, D, D, false, prec, st));
-    DRIN_TRY(launch_gemm_nn(ge, D, W.w_h, D, dA_e, D, (int64_t)types * M, D, D, false, prec, st));
+    DRIN_TRY(gemm_nn(gm, D, W.w_h, dA_m, D, (int64_t)types * B, D, D, false));
+    DRIN_TRY(gemm_nn(ge, D, W.w_h, dA_e, D, (int64_t)types * M, D, D, false));
     const float* dA_mt = dA_m;
     const float* dA_mi = types == 2 ? dA_m + BD : nullptr;
     const float* dA_et = dA_e;
@@ -659,7 +721,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st));         // dz
       if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st));
       DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st));
-      DRIN_TRY(launch_gemm_nn(dpre, D, W.w_m, D, g_e[cur], D, 4 * (int64_t)M, D, D, false, prec, st));  // d(cat + e)
+      DRIN_TRY(gemm_nn(dpre, D, W.w_m, g_e[cur], D, 4 * (int64_t)M, D, D, false));  // d(cat + e)
       DRIN_TRY(launch_edge_pre_vec_bwd(g_e[cur], dfu, dfv, B, N, D, st));
       if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, H, et, D, G.w_v, D, 2 * (int64_t)M, H, D, prec, st));
       DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, H, st));
@@ -691,20 +753,20 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       // (e) entity side of the aggregation backward + edge gradients, element-wise with vector edges
       DRIN_TRY(launch_entity_side_bwd_vec(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt],
                                           g_ve[nxt] + MD, g_e[nxt], B, N, D, cfg->edge_enabled, st));
-      if (edge_update) DRIN_TRY(launch_gemm_nn(dfv, H, W.w_v, D, g_ve[nxt], D, 2 * (int64_t)M, D, H, true, prec, st));
+      if (edge_update) DRIN_TRY(gemm_nn(dfv, H, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, H, true));
       // (f) mention side
       DRIN_TRY(launch_mention_reduce_vec(e, dA_et, e + ES, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, false, st));
       DRIN_TRY(launch_mention_reduce_vec(e + 2 * ES, dA_et, e + 3 * ES, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, false, st));
-      if (edge_update) DRIN_TRY(launch_gemm_nn(dfu, H, W.w_u, D, g_vm[nxt], D, 2 * (int64_t)B, D, H, true, prec, st));
+      if (edge_update) DRIN_TRY(gemm_nn(dfu, H, W.w_u, g_vm[nxt], D, 2 * (int64_t)B, D, H, true));
     } else {
       // (e) entity side of the aggregation backward + edge gradients
       DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
                                       g_e[nxt], B, N, D, cfg->edge_enabled, st));
-      if (edge_update) DRIN_TRY(launch_gemm_nn(dfv, D, W.w_v, D, g_ve[nxt], D, 2 * (int64_t)M, D, D, true, prec, st));
+      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, D, true));
       // (f) mention side
       DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
       DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
-      if (edge_update) DRIN_TRY(launch_gemm_nn(dfu, D, W.w_u, D, g_vm[nxt], D, 2 * (int64_t)B, D, D, true, prec, st));
+      if (edge_update) DRIN_TRY(gemm_nn(dfu, D, W.w_u, g_vm[nxt], D, 2 * (int64_t)B, D, D, true));
     }
     have_image = true;
     have_edge = true;

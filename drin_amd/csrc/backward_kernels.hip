@@ -9,6 +9,7 @@
 namespace drin {
 
 constexpr int MAXV = 4;  // float4 columns per lane: D <= 1024
+constexpr int kLnBwdMaxBlocks = 1024;
 
 // ------------------------------------------------------------------------------------------------
 // score = cos(x[b], y[p]) (model.py:207-209), torch>=2 form: xn = x / max(|x|, eps), yn likewise.
@@ -131,8 +132,7 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restr
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* g,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ dbias, int64_t rows, int D4) {
+                                                            float* __restrict__ partial, int64_t rows, int D4) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 gm[MAXV], bt[MAXV];
   float4 a_dg[MAXV], a_db[MAXV], a_dh[MAXV];
@@ -188,44 +188,64 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restr
       }
     }
   }
-  // combine the four waves' column sums through LDS, then one atomic per column per block
-  // three passes (one quantity at a time) keep LDS at 4 waves * MAXV * 64 float4 = 16 KiB
+  // combine the four waves' column sums through LDS (one quantity at a time keeps LDS at 16 KiB), then ONE row of
+  // partial sums per block: partial[block][q][D].  A second kernel adds the blocks in order - no atomics: a thousand
+  // blocks adding to the same 2 304 addresses serialised in L2 (106 us per call at 12 928 rows), and the sums were
+  // run-order dependent.
   __shared__ float4 comb[4][MAXV][64];
+  const int D = D4 * 4;
   for (int q = 0; q < 3; ++q) {
-    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+    float* dst = partial + ((int64_t)blockIdx.x * 3 + q) * D;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) comb[wave][j][lane] = q == 0 ? a_dg[j] : (q == 1 ? a_db[j] : a_dh[j]);
     __syncthreads();
-    if (dst != nullptr && wave == 0) {
+    if (wave == 0) {
 #pragma unroll
       for (int j = 0; j < MAXV; ++j) {
         const int c4 = lane + 64 * j;
-        if (c4 < D4) {
-          const float4 t = (comb[0][j][lane] + comb[1][j][lane]) + (comb[2][j][lane] + comb[3][j][lane]);
-          atomicAdd(dst + c4 * 4 + 0, t.x);
-          atomicAdd(dst + c4 * 4 + 1, t.y);
-          atomicAdd(dst + c4 * 4 + 2, t.z);
-          atomicAdd(dst + c4 * 4 + 3, t.w);
-        }
+        if (c4 < D4) st4(dst + c4 * 4, (comb[0][j][lane] + comb[1][j][lane]) + (comb[2][j][lane] + comb[3][j][lane]));
       }
     }
   }
 }
 
+// dst_q[c] += sum_blocks partial[block][q][c]   (q: dgamma, dbeta, dbias; a NULL dst is skipped)
+__global__ void __launch_bounds__(256) k_add_block_partials(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias, int blocks,
+                                                            int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.y;
+  float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+  if (c >= D || dst == nullptr) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains, fixed association
+  int b = 0;
+  for (; b + 4 <= blocks; b += 4) {
+    s0 += partial[((int64_t)(b + 0) * 3 + q) * D + c];
+    s1 += partial[((int64_t)(b + 1) * 3 + q) * D + c];
+    s2 += partial[((int64_t)(b + 2) * 3 + q) * D + c];
+    s3 += partial[((int64_t)(b + 3) * 3 + q) * D + c];
+  }
+  for (; b < blocks; ++b) s0 += partial[((int64_t)b * 3 + q) * D + c];
+  dst[c] += (s0 + s1) + (s2 + s3);
+}
+
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, int64_t rows,
-                              int D, hipStream_t st) {
+                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
+                              int64_t rows, int D, hipStream_t st) {
   if (rows <= 0) return DRIN_OK;
   if (D % 4 || D > 256 * MAXV) {
     set_error("layernorm_gelu_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
     return DRIN_E_SHAPE;
   }
-  const int64_t blocks = cdiv(rows, 4) < 1024 ? cdiv(rows, 4) : 1024;
+  const int64_t blocks = cdiv(rows, 4) < kLnBwdMaxBlocks ? cdiv(rows, 4) : kLnBwdMaxBlocks;
   KernelTimer timer(DRIN_KC_GCN, st);
   hipLaunchKernelGGL(k_layernorm_gelu_bwd, dim3((unsigned)blocks), dim3(256), 0, st, h, mean, rstd, gamma, beta, g,
-                     dgamma, dbeta, dbias, rows, D / 4);
+                     partial, rows, D / 4);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
+  hipLaunchKernelGGL(k_add_block_partials, dim3((unsigned)cdiv(D, 256), 3), dim3(256), 0, st, partial, dgamma, dbeta, dbias,
+                     (int)blocks, D);
+  DRIN_CHECK_LAUNCH("k_add_block_partials");
   return DRIN_OK;
 }
 
@@ -287,20 +307,42 @@ int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t 
 // ------------------------------------------------------------------------------------------------
 // out[b, :] = scale * (sum_n w1[b,n] v1[b,n,:] + sum_n w2[b,n] v2[b,n,:]) + u[b, :]
 // (v2 / u may be NULL).  The transposes of the entity<-mention and edge-update products.
-__global__ void __launch_bounds__(64) k_mention_reduce(const float* __restrict__ w1, const float* __restrict__ v1,
-                                                       const float* __restrict__ w2, const float* __restrict__ v2,
-                                                       const float* __restrict__ u, float* __restrict__ out, int N,
-                                                       int D4, float scale) {
-  const int c4 = blockIdx.x * 64 + threadIdx.x;
-  if (c4 >= D4) return;
+// Block = 4 waves x 64 float4 columns: wave w sums candidates w, w + 4, ... (four loads in flight), the waves are
+// combined through LDS in order - a mention-sized batch (B = 64) is only 3 B blocks, so the candidate loop must not
+// be one serial chain per thread.
+__global__ void __launch_bounds__(256) k_mention_reduce(const float* __restrict__ w1, const float* __restrict__ v1,
+                                                        const float* __restrict__ w2, const float* __restrict__ v2,
+                                                        const float* __restrict__ u, float* __restrict__ out, int N,
+                                                        int D4, float scale) {
+  __shared__ float4 comb[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c4 = blockIdx.x * 64 + lane;
   const int64_t b = blockIdx.y;
-  const int64_t off = (b * N) * (int64_t)D4 * 4 + (int64_t)c4 * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int n = 0; n < N; ++n) {
-    s = fma4(w1[b * N + n], ld4(v1 + off + (int64_t)n * D4 * 4), s);
-    if (v2 != nullptr) s = fma4(w2[b * N + n], ld4(v2 + off + (int64_t)n * D4 * 4), s);
+  if (c4 < D4) {
+    const int64_t off = (b * N) * (int64_t)D4 * 4 + (int64_t)c4 * 4, row = (int64_t)D4 * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    int n = wave;
+    for (; n + 4 < N; n += 8) {  // two candidates of this wave per trip
+      const float4 a0 = ld4(v1 + off + n * row), a1 = ld4(v1 + off + (n + 4) * row);
+      s = fma4(w1[b * N + n], a0, s);
+      t = fma4(w1[b * N + n + 4], a1, t);
+      if (v2 != nullptr) {
+        const float4 c0 = ld4(v2 + off + n * row), c1 = ld4(v2 + off + (n + 4) * row);
+        s = fma4(w2[b * N + n], c0, s);
+        t = fma4(w2[b * N + n + 4], c1, t);
+      }
+    }
+    for (; n < N; n += 4) {
+      s = fma4(w1[b * N + n], ld4(v1 + off + n * row), s);
+      if (v2 != nullptr) s = fma4(w2[b * N + n], ld4(v2 + off + n * row), s);
+    }
+    s = s + t;
   }
-  s = s * scale;
+  comb[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || c4 >= D4) return;
+  s = ((comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane])) * scale;
   if (u != nullptr) s = s + ld4(u + b * (int64_t)D4 * 4 + (int64_t)c4 * 4);
   st4(out + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, s);
 }
@@ -312,7 +354,7 @@ int launch_mention_reduce(const float* w1, const float* v1, const float* w2, con
     const int nb = B - b0 < 65535 ? B - b0 : 65535;
     const int64_t po = (int64_t)b0 * N, vo = po * D;
     KernelTimer timer(DRIN_KC_GCN, st);
-    hipLaunchKernelGGL(k_mention_reduce, dim3((unsigned)cdiv(D / 4, 64), (unsigned)nb), dim3(64), 0, st, w1 + po,
+    hipLaunchKernelGGL(k_mention_reduce, dim3((unsigned)cdiv(D / 4, 64), (unsigned)nb), dim3(256), 0, st, w1 + po,
                        v1 + vo, w2 ? w2 + po : nullptr, v2 ? v2 + vo : nullptr, u ? u + (int64_t)b0 * D : nullptr,
                        out + (int64_t)b0 * D, N, D / 4, scale);
     DRIN_CHECK_LAUNCH("k_mention_reduce");

@@ -130,7 +130,7 @@ template <int BM, int BN, int WM, int WN, bool W_PLANES>
 __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
                   const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
-                  int64_t ldc, int64_t M, int N, int K) {
+                  int64_t ldc, int64_t M, int N, int K, int accumulate) {
   using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t m0 = (int64_t)blockIdx.y * BM;
@@ -231,14 +231,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int64_t row = m0 + wm * (BM / WM) + i * 16 + c * 4 + v;
-        if (row < M) C[row * ldc + col] = acc[i][j][v] + bv;
+        if (row < M) {
+          float* dst = C + row * ldc + col;
+          *dst = acc[i][j][v] + bv + (accumulate ? *dst : 0.f);
+        }
       }
     }
 }
 
 template <int BM, int BN, int WM, int WN, bool W_PLANES>
 static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
-                  const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st) {
+                  const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate) {
   using G = Cfg<BM, BN, WM, WN>;
   const int64_t mt = cdiv(M, BM);
   if (mt > 65535) {
@@ -256,7 +259,7 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
   dim3 grid((unsigned)cdiv(N, BN), (unsigned)mt);
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi, (const __bf16*)w_lo,
-                     ldw, bias, y, ldy, M, N, K);
+                     ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
   return DRIN_OK;
 }
@@ -265,14 +268,15 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
 
 // w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
-                          int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo) {
+                          int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo,
+                          bool accumulate) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   if ((K % x3::BK) || K <= 0) {  // odd reduction lengths take the exact fp32 kernel (guarded loads)
     if (!w) {
       set_error("gemm_bf16x3: K=%d is not a multiple of 32 and no fp32 weights were given", K);
       return DRIN_E_SHAPE;
     }
-    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, M, N, K, false, DRIN_PREC_F32, st);
+    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, M, N, K, accumulate, DRIN_PREC_F32, st);
   }
   const bool planes = w_hi != nullptr && w_lo != nullptr;
   if ((ldx % 4) || !aligned16(x) ||
@@ -283,10 +287,10 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   // pair-sized problems: 256 x 256 tiles; anything that would not fill the chip with them: 64 x 128 tiles
   const bool big = cdiv(M, 256) * cdiv(N, 256) >= 192;
   if (big)
-    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st)
-                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st);
-  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st)
-                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st);
+    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate)
+                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
+  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate)
+                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
 }
 
 }  // namespace drin

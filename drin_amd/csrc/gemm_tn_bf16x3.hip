@@ -1,0 +1,226 @@
+// Weight-gradient contraction on the bf16 matrix cores, fp32-equivalent ("bf16x3", see gemm_bf16x3.hip):
+//   y[n, k] += sum_m a[m, n] * b[m, k]          (dW = dY^T X: both operands are m-major, the reduction index
+//                                                is the ROW of both matrices; M = pairs, y = one weight matrix)
+//
+// The bf16 MFMAs want 8 consecutive values of the reduction index per lane, but in memory consecutive m
+// are a whole row apart.  Each thread therefore loads a 4 (m) x 4 (columns) fp32 block - one float4 from
+// each of four consecutive rows - transposes it in registers, splits it into bf16 hi / lo and writes four
+// 8-byte pieces (4 consecutive m of one column) to LDS.  LDS holds the tile as [column][32 m] rows of 64 B,
+// exactly what the MFMA fragments read with ds_read_b128.
+//
+// LDS layout: the four columns of a thread's block (4 cg + j) would land 256 B apart - the bank period -
+// so logical row p lives at physical row (p & 3) * ROWS/4 + (p >> 2): the pieces a wave writes with one
+// instruction (j fixed, 8 neighbouring column groups x 8 m-groups) then form 512 contiguous bytes.  The
+// 16-byte chunk index is XORed with (p & 3) so that the 16 rows of a fragment read (4 row residues x 4
+// physical neighbours) fall on 16 distinct bank quads.
+//
+// The reduction is split over workgroups (M is 10^4 .. 10^5, the output has 9 .. 24 tiles of 256 x 256); partial
+// tiles are added to y with fp32 atomics, like the exact-fp32 kernel of gemm_f32.hip.
+#include "device_utils.h"
+#include "internal.h"
+
+namespace drin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace x3tn {
+
+constexpr int BK = 32;      // reduction rows per LDS stage
+constexpr int TILE = 256;   // output tile: 256 (n) x 256 (k)
+constexpr int THREADS = 512;
+constexpr int PLANE = TILE * 64;             // one bf16 plane of one operand: 256 rows x 64 B
+constexpr int BUF_BYTES = 4 * PLANE;         // A hi, A lo, B hi, B lo
+constexpr int LDS_BYTES = 2 * BUF_BYTES;     // double buffered: 128 KiB
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return ((((row & 3) * (TILE / 4)) + (row >> 2)) << 6) + ((chunk ^ (row & 3)) << 4);
+}
+
+// 32 (m) x 256 (columns) fp32 staged by 512 threads: lane = (m-group mg = lane >> 3, column group cgl = lane & 7),
+// wave w covers column groups 8 w .. 8 w + 7; a column group is 4 adjacent columns.
+struct TransposeStager {
+  const float* p;   // first row of the reduction range, this thread's column
+  int64_t ld;
+  int mg, cg;
+  float4 v[4];
+
+  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld_, int col0, int ncols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    mg = lane >> 3;
+    cg = wave * 8 + (lane & 7);
+    int col = col0 + 4 * cg;
+    col = col + 4 <= ncols ? col : ncols - 4;  // clamped columns feed output rows / columns that are never stored
+    p = src + col;
+    ld = ld_;
+  }
+  // rows m0 + 4 mg + i; rows at or past m_end contribute zero (the loads stay unconditional: clamped row, then masked)
+  __device__ __forceinline__ void load(int64_t m0, int64_t m_end) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + 4 * mg + i;
+      const bool live = m < m_end;
+      const float4 x = ld4(p + (live ? m : m_end - 1) * ld);
+      v[i] = live ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(char* __restrict__ hi_plane, char* __restrict__ lo_plane) const {
+    const float col[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x},
+                             {v[0].y, v[1].y, v[2].y, v[3].y},
+                             {v[0].z, v[1].z, v[2].z, v[3].z},
+                             {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)col[j][i];
+        lo[i] = (__bf16)(col[j][i] - (float)hi[i]);
+      }
+      const int off = lds_off(4 * cg + j, mg >> 1) + ((mg & 1) << 3);
+      *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
+      *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+    }
+  }
+};
+
+// grid: x = output tile (n-tile major), y = slice of the reduction
+__global__ void __launch_bounds__(THREADS, 1)
+    k_gemm_tn_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+                     float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, int64_t rows_per_slice, int k_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n0 = (blockIdx.x / k_tiles) * TILE, k0 = (blockIdx.x % k_tiles) * TILE;
+  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
+  const int64_t m_end = m_begin + rows_per_slice < M ? m_begin + rows_per_slice : M;
+  const int nkb = (int)((m_end - m_begin + BK - 1) / BK);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, wave tile 128 (n) x 64 (k)
+  const int r = lane & 15, c = lane >> 4;
+  constexpr int MI = 8, NI = 4;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
+
+  TransposeStager sa, sb;
+  sa.init(A, lda, n0, N);
+  sb.init(Bm, ldb, k0, K);
+  sa.load(m_begin, m_end);
+  sb.load(m_begin, m_end);
+  sa.store(smem, smem + PLANE);
+  sb.store(smem + 2 * PLANE, smem + 3 * PLANE);
+  if (nkb > 1) {
+    sa.load(m_begin + BK, m_end);
+    sb.load(m_begin + BK, m_end);
+  }
+  __syncthreads();
+
+  bf16x8 bh[NI], bl[NI];
+  auto load_b = [&](const char* buf) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int off = lds_off(wn * 64 + j * 16 + r, c);
+      bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * PLANE + off);
+      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE + off);
+    }
+  };
+  auto row_tiles = [&](const char* buf, int i0, int i1) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (i < i0 || i >= i1) continue;
+      const int off = lds_off(wm * 128 + i * 16 + r, c);
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + PLANE + off);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // Same software pipeline as k_gemm_bf16x3: stage kb in LDS buffer kb & 1, stage kb + 1 in the staging
+  // registers; between the two halves of the MFMA work the staged tile goes to the other buffer and the loads
+  // of stage kb + 2 are issued.
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    const char* buf = smem + cur * BUF_BYTES;
+    char* nb = smem + (cur ^ 1) * BUF_BYTES;
+    const bool more = kb + 1 < nkb;
+    load_b(buf);
+    row_tiles(buf, 0, MI / 2);
+    if (more) {
+      sa.store(nb, nb + PLANE);
+      sb.store(nb + 2 * PLANE, nb + 3 * PLANE);
+      if (kb + 2 < nkb) {
+        sa.load(m_begin + (int64_t)(kb + 2) * BK, m_end);
+        sb.load(m_begin + (int64_t)(kb + 2) * BK, m_end);
+      }
+    }
+    row_tiles(buf, MI / 2, MI);
+    __syncthreads();
+  }
+
+  // C / D of a 16 x 16 tile: column lane & 15, rows 4 (lane >> 4) + v
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int kcol = k0 + wn * 64 + j * 16 + r;
+      if (kcol >= K) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int nrow = n0 + wm * 128 + i * 16 + c * 4 + v;
+        if (nrow < N) unsafeAtomicAdd(Y + (int64_t)nrow * ldy + kcol, acc[i][j][v]);
+      }
+    }
+}
+
+}  // namespace x3tn
+
+bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, const void* a, const void* b) {
+  return M >= 1024 && N >= 128 && K >= 128 && (N % 4) == 0 && (K % 4) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 &&
+         aligned16(a) && aligned16(b);
+}
+
+int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
+                          int N, int K, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
+  if (!gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b)) {
+    set_error("gemm_tn_bf16x3: shape M=%lld N=%d K=%d / alignment outside the kernel's contract", (long long)M, N, K);
+    return DRIN_E_SHAPE;
+  }
+  const int n_tiles = (int)cdiv(N, x3tn::TILE), k_tiles = (int)cdiv(K, x3tn::TILE);
+  const int tiles = n_tiles * k_tiles;
+  // One workgroup per CU in all (the 128 KiB tile buffers allow one per CU at a time): every extra slice adds
+  // 65 536 fp32 atomics per tile and a pipeline fill, which at M ~ 10^4 cost more than the MFMA work itself
+  // (measured at M = 12 928: 86 slices 162 us, 28 slices see DESIGN.md).  A slice is a whole number of 32-row stages.
+  int64_t slices = tiles >= 256 ? 1 : 256 / tiles;
+  int64_t rows = cdiv(cdiv(M, slices), x3tn::BK) * x3tn::BK;
+  if (rows < 4 * x3tn::BK) rows = 4 * x3tn::BK;
+  slices = cdiv(M, rows);
+  if (slices > 65535) {
+    set_error("gemm_tn_bf16x3: %lld reduction slices exceed the grid limit", (long long)slices);
+    return DRIN_E_SHAPE;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3tn::LDS_BYTES);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_tn_bf16x3)");
+    attr_done = true;
+  }
+  KernelTimer timer(DRIN_KC_GEMM_X3, st);
+  hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS), x3tn::LDS_BYTES,
+                     st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles);
+  DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
+  return DRIN_OK;
+}
+
+}  // namespace drin

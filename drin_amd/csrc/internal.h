@@ -61,7 +61,12 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 // (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi = nullptr,
-                          const void* w_lo = nullptr);
+                          const void* w_lo = nullptr, bool accumulate = false);
+// (accumulate: y += ... instead of y = ...)
+// weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
+bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, const void* a, const void* b);
+int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
+                          int N, int K, hipStream_t st);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
@@ -93,10 +98,11 @@ int launch_edge_update(const float* fu, const float* fv, const float* e, float* 
 // d cos(x[b], y[p]) : dx [B, D], dy [B*N, D]; scratch3 holds 3 * B*N floats
 int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx, float* dy, float* scratch3, int B,
                       int N, int D, float eps, hipStream_t st);
-// in place: g (dL/dy) -> dL/dh for y = gelu(LN(h)); accumulates dgamma, dbeta and dbias (= column sum of dL/dh)
+// in place: g (dL/dy) -> dL/dh for y = gelu(LN(h)); accumulates dgamma, dbeta and dbias (= column sum of dL/dh);
+// partial: 1024 * 3 * D floats of scratch for the per-block column sums
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, int64_t rows,
-                              int D, hipStream_t st);
+                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
+                              int64_t rows, int D, hipStream_t st);
 // out[c] += sum_rows x[row, c]
 int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st);
 // dpre = g * e' * (1 - e')

@@ -171,6 +171,15 @@ DRIN_API int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, floa
 DRIN_API int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t rows,
                     int32_t n_out, int32_t k, int32_t precision, void* stream);
 
+/* Backward of the same Linear (what autograd does for every nn.Linear of the path under train.py:33-34):
+ *   dx[m, k]  = sum_n dy[m, n] w[n, k]      (written; dx may be NULL)
+ *   dw[n, k] += sum_m dy[m, n] x[m, k]      (accumulated; dw may be NULL)
+ *   db[n]    += sum_m dy[m, n]              (accumulated; db may be NULL)
+ * `scratch`: n_out * k floats for the transposed weight the split-bf16 dx product runs against; NULL keeps
+ * dx on the exact fp32 kernel.  Small problems take the exact fp32 kernels in every precision. */
+DRIN_API int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                             int64_t rows, int32_t n_out, int32_t k, int32_t precision, float* scratch, void* stream);
+
 /* Model.forward (drin/model.py:164-209): scores[B, N] = cos(mt'', et'').
  * `keep_for_backward` != 0 lays the intermediates backward needs out in `workspace`, which must
  * then stay untouched until drin_backward returns.  `trace` may be NULL. */
@@ -252,16 +261,17 @@ typedef enum {
   DRIN_KC_POOL = 1,   /* input pooling: span / region / token means                               */
   DRIN_KC_EDGE = 2,   /* static edge builders: cosine rows, miei, scaling                          */
   DRIN_KC_GCN = 3,    /* aggregation, LayerNorm+GELU, edge update, their backward                  */
-  DRIN_KC_STREAM = 4, /* k_entity_stream: the single pass over the entity-side bytes (fused path)  */
+  DRIN_KC_STREAM = 4, /* k_entity_stream / k_cached_pairs: the single HBM-bound pass over entity bytes  */
   DRIN_KC_GEMM_X3 = 5,     /* k_gemm_bf16x3: split-bf16 contraction, fp32 operands split on the fly */
   DRIN_KC_GEMM_PLANES = 6, /* k_gemm_x3_planes: split-bf16 contraction on pre-split planes (LDS-DMA) */
   DRIN_KC_COUNT = 7
 } drin_kernel_class;
 
-/* While a profile is open on the calling thread, every launch made from that thread is bracketed by
- * hipEvents on its stream.  drin_profile_end synchronises those events, returns per-class GPU
- * milliseconds and launch counts (arrays of DRIN_KC_COUNT) and closes the profile.  State is
- * thread-local; launches from other threads are not affected. */
+/* While a profile is open, every launch the library makes - from any thread, e.g. drin_backward on
+ * autograd's thread - is bracketed by hipEvents on its stream.  drin_profile_end synchronises those
+ * events, returns per-class GPU milliseconds and launch counts (arrays of DRIN_KC_COUNT) and closes the
+ * profile.  One profile per process at a time; this is the library's only process-wide state and it is
+ * inert unless a profile is open.  The loss kernels (drin_triplet_topk) count under DRIN_KC_EDGE. */
 DRIN_API int drin_profile_begin(int max_launches);
 DRIN_API int drin_profile_end(double* ms_by_class, int64_t* launches_by_class);
 DRIN_API const char* drin_kernel_class_name(int kernel_class);

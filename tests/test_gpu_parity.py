@@ -98,6 +98,36 @@ def test_linear_planes_fwd(rows, n_out, k):
     assert rel <= 2e-5
 
 
+@pytest.mark.parametrize("rows,n_out,k", [(70, 64, 64), (1500, 768, 768), (4133, 768, 2048), (2048, 384, 768), (3000, 200, 96),
+                                          (1024, 128, 128), (9000, 768, 768)])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_linear_bwd(rows, n_out, k, precision):
+    """dx = dy W, dW += dy^T x, db += colsum(dy) - exact fp32 MFMA and split-bf16 (transposing-stager kernel of
+    gemm_tn_bf16x3.hip; NT kernel against W^T) - against float64 on the host; dW / db accumulate."""
+    g = torch.Generator().manual_seed(rows + n_out + k)
+    x, w, dy = torch.randn(rows, k, generator=g), torch.randn(n_out, k, generator=g) / k ** 0.5, torch.randn(rows, n_out, generator=g)
+    dw0, db0 = torch.randn(n_out, k, generator=g), torch.randn(n_out, generator=g)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    dx, dw, db = torch.empty(rows, k, device=DEV), dw0.to(DEV), db0.to(DEV)
+    scratch = torch.empty(n_out * k, device=DEV)
+    prec = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3}[precision]
+    lib = _lib.load()
+    _lib.profile_begin()
+    _lib.check(lib.drin_linear_bwd(xd.data_ptr(), wd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                   rows, n_out, k, prec, scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    prof = _lib.profile_end()
+    big = precision == "bf16x3" and rows >= 1024 and n_out >= 128 and k >= 128
+    assert (prof["gemm_x3"][1] > 0) == big, prof
+    ref_dx = (dy.double() @ w.double())
+    ref_dw = dw0.double() + dy.double().t() @ x.double()
+    ref_db = db0.double() + dy.double().sum(0)
+    tol = 2e-5 if precision == "bf16x3" else 5e-6
+    for got, ref, scale in ((dx, ref_dx, (dy.abs().double() @ w.abs().double())), (dw, ref_dw, dy.abs().double().t() @ x.abs().double()),
+                            (db, ref_db, dy.abs().double().sum(0))):
+        err = ((got.cpu().double() - ref).abs() / (scale + 1e-30)).max().item()
+        assert err <= tol, (precision, err)
+
+
 def test_linear_fwd_errors():
     lib = _lib.load()
     x = torch.zeros(4, 6, device=DEV)
@@ -459,6 +489,35 @@ def test_vector_edges_vs_oracle(maker, B, edge_type):
         if r is not None:
             rel = (got - r).norm().item() / (r.norm().item() + 1e-12)
             assert rel <= 2e-3, (k, rel)
+
+
+def test_backward_bf16x3_vs_oracle_autograd():
+    """Training in split-bf16 precision (forward, dX and dW contractions on the bf16 matrix cores): every
+    parameter gradient of a WikiMEL-shaped batch against autograd through the fp32 oracle."""
+    from drin_amd.metrics import TripletLoss
+    cfg = wikimel_config(max_entity_attr_token_len=8, max_mention_sentence_len=16, resnet_num_region=4)
+    sd = synth.make_state_dict(cfg, 7)
+    batch = synth.make_batch(cfg, 16, 44)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss = O.triplet_loss(batch[-1], O.forward(p, batch), cfg.triplet_margin)
+    ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
+    model = Model(cfg, precision="bf16x3").to(DEV)
+    model.load_state_dict(sd)
+    dbatch = _to_dev(batch)
+    _lib.profile_begin()
+    loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
+    grads = _grads_of(model, loss)
+    prof = _lib.profile_end()
+    assert prof["gemm_x3"][1] >= 10, "forward and backward pair-sized contractions should run split-bf16"
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5
+    worst = 0.0
+    for (k, got), r in zip(grads.items(), ref):
+        assert (got is None) == (r is None), k
+        if r is not None:
+            rel = (got - r).norm().item() / (r.norm().item() + 1e-12)
+            worst = max(worst, rel)
+            assert rel <= 2e-4, (k, rel)
+    print(f"bf16x3 training: worst relative gradient error {worst:.2e}")
 
 
 def test_training_loop_on_device_tracks_cpu_oracle_loop(tmp_path):

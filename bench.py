@@ -193,7 +193,7 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
             "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)" + (" [hipGraph replay]" if args.graph else ""),
             "value": B * N * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)",
                        "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},

@@ -210,24 +210,37 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restr
   }
 }
 
-// dst_q[c] += sum_blocks partial[block][q][c]   (q: dgamma, dbeta, dbias; a NULL dst is skipped)
-__global__ void __launch_bounds__(256) k_add_block_partials(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ dbias, int blocks,
-                                                            int D) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int q = blockIdx.y;
-  float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
-  if (c >= D || dst == nullptr) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains, fixed association
-  int b = 0;
-  for (; b + 4 <= blocks; b += 4) {
-    s0 += partial[((int64_t)(b + 0) * 3 + q) * D + c];
-    s1 += partial[((int64_t)(b + 1) * 3 + q) * D + c];
-    s2 += partial[((int64_t)(b + 2) * 3 + q) * D + c];
-    s3 += partial[((int64_t)(b + 3) * 3 + q) * D + c];
+// Sum of per-block partial rows, in two levels so that every load is independent of the others:
+//   level 1 (out_partial != NULL): out_partial[z][q][c] = sum of the 64 rows z*64 .. of partial[.][q][c]
+//   level 2 (out_partial == NULL): dst_q[c] += sum of all `blocks` (<= 64) rows      (q: dgamma, dbeta, dbias)
+// Block = 4 waves x 64 columns; wave w takes rows w, w + 4, ... of its slice (at most 16, all in flight at once);
+// the waves are combined through LDS in order.
+__global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ partial, int blocks, int D,
+                                                      float* __restrict__ out_partial, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, float* __restrict__ dbias) {
+  __shared__ float comb[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lane, q = blockIdx.y;
+  const int b0 = blockIdx.z * 64, b1 = min(blocks, b0 + 64);
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int b = b0 + wave + 4 * i;
+    v[i] = (b < b1 && c < D) ? partial[((int64_t)b * 3 + q) * D + c] : 0.f;
   }
-  for (; b < blocks; ++b) s0 += partial[((int64_t)b * 3 + q) * D + c];
-  dst[c] += (s0 + s1) + (s2 + s3);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += v[i];
+  comb[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || c >= D) return;
+  s = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
+  if (out_partial != nullptr) {
+    out_partial[((int64_t)blockIdx.z * 3 + q) * D + c] = s;
+  } else {
+    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
+    if (dst != nullptr) dst[c] += s;
+  }
 }
 
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
@@ -243,9 +256,15 @@ int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rs
   hipLaunchKernelGGL(k_layernorm_gelu_bwd, dim3((unsigned)blocks), dim3(256), 0, st, h, mean, rstd, gamma, beta, g,
                      partial, rows, D / 4);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
-  hipLaunchKernelGGL(k_add_block_partials, dim3((unsigned)cdiv(D, 256), 3), dim3(256), 0, st, partial, dgamma, dbeta, dbias,
-                     (int)blocks, D);
-  DRIN_CHECK_LAUNCH("k_add_block_partials");
+  // partial: [kLnBwdMaxBlocks][3][D] block rows, then [kLnBwdMaxBlocks / 64][3][D] for the first reduction level
+  float* level1 = partial + (int64_t)kLnBwdMaxBlocks * 3 * D;
+  const int z = (int)cdiv(blocks, 64);
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)cdiv(D, 64), 3, (unsigned)z), dim3(256), 0, st, partial, (int)blocks, D,
+                     level1, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  DRIN_CHECK_LAUNCH("k_sum_partials");
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)cdiv(D, 64), 3, 1), dim3(256), 0, st, level1, z, D, (float*)nullptr, dgamma,
+                     dbeta, dbias);
+  DRIN_CHECK_LAUNCH("k_sum_partials");
   return DRIN_OK;
 }
 

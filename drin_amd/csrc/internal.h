@@ -99,7 +99,7 @@ int launch_edge_update(const float* fu, const float* fv, const float* e, float* 
 int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx, float* dy, float* scratch3, int B,
                       int N, int D, float eps, hipStream_t st);
 // in place: g (dL/dy) -> dL/dh for y = gelu(LN(h)); accumulates dgamma, dbeta and dbias (= column sum of dL/dh);
-// partial: 1024 * 3 * D floats of scratch for the per-block column sums
+// partial: (1024 + 16) * 3 * D floats of scratch for the per-block column sums
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
                               int64_t rows, int D, hipStream_t st);

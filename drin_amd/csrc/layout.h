@@ -40,7 +40,7 @@ struct Layout {
   size_t fv[DRIN_MAX_LAYERS] = {};          // [2][M][D]  W_v(et), W_v(ei)
   size_t edges_scalar = 0;                  // [4][M]     scalar static edges before model.py:202 expands them (vector edges)
   size_t pre[DRIN_MAX_LAYERS] = {};         // [4][M][D]  W_m input cat(fu, fv) + e (vector edges)
-  size_t ln_part = 0;                       // [1024][3][D] per-block column sums of the LayerNorm backward
+  size_t ln_part = 0;                       // [1024 + 16][3][D] per-block column sums of the LayerNorm backward and their first reduction level
   size_t wt = 0;                            // [D][D] transposed weight of the backward product in flight (split-bf16 dX = dY W)
   size_t bwd_scratch = 0;                   // backward temporaries (training only)
   size_t bwd_scratch_floats = 0;
@@ -85,7 +85,7 @@ struct Layout {
       }
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
       wt = take(D * D);
-      ln_part = take(1024 * 3 * D);
+      ln_part = take((1024 + 16) * 3 * D);
       bwd_scratch_floats = 4 * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
       bwd_scratch = take(bwd_scratch_floats);
     } else {

@@ -12,6 +12,7 @@ namespace drin {
 struct Prepared {  // offsets in floats
   size_t wcat1, bcat1, ecat, etmp, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
   size_t p_ctxt, p_cimg, p_wh2;  // bf16 (hi, lo) planes of the three pair-sized GEMM weights; lo follows hi
+  size_t p_wmt, p_wmi, p_wcat1, p_ecat, p_wet, p_wei, p_wh1;  // the same for the mention-sized GEMM weights
   void build(const drin_config& c) {
     const size_t D = c.embed_dim, R = c.image_dim;
     size_t off = 0;
@@ -33,6 +34,13 @@ struct Prepared {  // offsets in floats
     p_ctxt = take(D * D);         // hi plane D*D bf16 (= D*D/2 floats) then lo plane
     p_cimg = take(D * R);
     p_wh2 = take(D * D);
+    p_wmt = take(D * D);          // W_mt
+    p_wmi = take(D * R);          // W_mi
+    p_wcat1 = take(2 * D * D);    // [W_h1; W_u1]
+    p_ecat = take(D * (D + R));   // ([W_v1 W_et | W_v1 W_ei])^T
+    p_wet = take(D * D);          // W_et
+    p_wei = take(D * R);          // W_ei
+    p_wh1 = take(D * D);          // W_h1
     total = off;
   }
 };
@@ -68,6 +76,9 @@ struct StreamArgs {
   float* e0m;                        // [4][M] layer-1 edges (already multiplied by the edge switch)
   float* e1m;                        // [4][M] layer-2 edges (ditto)
   float* s_part;                     // [B][chunks][2 D + 2 R + 4]
+  float* s_text;                     // chunks == 1 only: [2][B][D] (S_tt, S_it), [2][B][R] (S_ti, S_ii), [4][B] edge sums,
+  float* s_img;                      //   written directly in the layout k_reduce_stream_partials would produce
+  float* sig;
   int B, N, D4, R4, T, Km, Ke, chunks, ldq, ldfu, dynamic;
   float mask[4];
   float cos_eps, miei_eps, clip;

@@ -187,6 +187,17 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
     DRIN_TRY(launch_split_planes(pb + P.c_img, q, q + dr, dr, st));
     q = reinterpret_cast<__bf16*>(pb + P.p_wh2);
     DRIN_TRY(launch_split_planes(params->layer[1].w_h, q, q + dd, dd, st));
+    // mention-sized GEMM weights (they matter for short candidate lists: at N = 11 the mention side is a third
+    // of the contraction work)
+    struct { size_t off; const float* w; size_t n; } extra[] = {
+        {P.p_wmt, params->w_mention_text, dd},  {P.p_wmi, params->w_mention_image, dr},
+        {P.p_wcat1, pb + P.wcat1, 2 * dd},      {P.p_ecat, pb + P.ecat, dd + dr},
+        {P.p_wet, params->w_entity_text, dd},   {P.p_wei, params->w_entity_image, dr},
+        {P.p_wh1, L1.w_h, dd}};
+    for (const auto& e : extra) {
+      q = reinterpret_cast<__bf16*>(pb + e.off);
+      DRIN_TRY(launch_split_planes(e.w, q, q + e.n, e.n, st));
+    }
   }
   return DRIN_OK;
 }
@@ -242,6 +253,17 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   const drin_layer_params& L1 = params->layer[0];
   const drin_layer_params& L2 = params->layer[1];
 
+  // Mention-sized contractions: the configured precision; in split-bf16 precision problems of >= 256 rows stream
+  // the pre-split weight planes by LDS-DMA, smaller ones (latency-bound) stay on the exact fp32 kernel
+  auto lin = [&](const float* x, int64_t ldx, const float* w, int64_t ldw, size_t plane_off, size_t plane_elems,
+                 const float* bias, float* y, int64_t ldy, int64_t rows, int n_out, int k) -> int {
+    if (planes && (rows >= 256 || prec == DRIN_PREC_BF16X3_ALL) && (k % 32) == 0 && (ldw % 8) == 0) {
+      const __bf16* hi = reinterpret_cast<const __bf16*>(pb + plane_off);
+      return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, st, hi, hi + plane_elems);
+    }
+    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, false, prec, st);
+  };
+  const size_t DD = (size_t)D * D, DR = (size_t)D * R;
   // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears
   DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
                             cfg->mention_tokens, D, st));
@@ -249,13 +271,13 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   float* vm0 = ws + L.vm0;
   // mention-sized contractions take the configured precision too: launch_gemm_nt keeps problems of fewer
   // than 1024 rows on the fp32 kernel (latency-bound), larger ones (WikiDiverse batches) go split-bf16
-  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, prec, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, prec, st));
+  DRIN_TRY(lin(ws + L.span_mean, D, params->w_mention_text, D, P.p_wmt, DD, params->b_mention_text, vm0, D, B, D, D));
+  DRIN_TRY(lin(ws + L.mimg, R, params->w_mention_image, R, P.p_wmi, DR, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R));
   // (2) [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1], then q = fu [W_v1 W_et | W_v1 W_ei]
   float* hmfu = ws + L.hmfu;
-  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st));
+  DRIN_TRY(lin(vm0, D, pb + P.wcat1, D, P.p_wcat1, 2 * DD, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D));
   if (dyn)
-    DRIN_TRY(launch_gemm_nt(hmfu + D, 2 * D, pb + P.ecat, D, nullptr, ws + L.q, D + R, 2 * (int64_t)B, D + R, D, false, prec, st));
+    DRIN_TRY(lin(hmfu + D, 2 * D, pb + P.ecat, D, P.p_ecat, DD + DR, nullptr, ws + L.q, D + R, 2 * (int64_t)B, D + R, D));
   // (3) one pass over the entity-side bytes
   StreamArgs sa;
   memset(&sa, 0, sizeof(sa));
@@ -302,16 +324,20 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.cos_eps = cfg->cosine_eps;
   sa.miei_eps = cfg->miei_eps;
   sa.clip = cfg->clip_scale;
+  sa.s_text = ws + L.s_text;
+  sa.s_img = ws + L.s_img;
+  sa.sig = ws + L.sig;
   DRIN_TRY(launch_entity_stream(sa, st));
-  DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
+  if (L.chunks > 1)
+    DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
   // (4) layer-1 mention vertices: T = S_text W_et^T + S_img W_ei^T, then the W_h input, W_h, LN, GELU
-  DRIN_TRY(launch_gemm_nt(ws + L.s_text, D, params->w_entity_text, D, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D, false, prec, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.s_img, R, params->w_entity_image, R, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R, false, prec, st));
+  DRIN_TRY(lin(ws + L.s_text, D, params->w_entity_text, D, P.p_wet, DD, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D));
+  DRIN_TRY(lin(ws + L.s_img, R, params->w_entity_image, R, P.p_wei, DR, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R));
   DRIN_TRY(launch_mention_input1(ws + L.tm, ws + L.tm2, ws + L.sig, params->b_entity_text, params->b_entity_image, vm0, ws + L.agg1, B, D, N, st));
   float* vm1 = ws + L.vm1;
-  DRIN_TRY(launch_gemm_nt(ws + L.agg1, D, L1.w_h, D, L1.b_h, vm1, D, 2 * (int64_t)B, D, D, false, prec, st));
+  DRIN_TRY(lin(ws + L.agg1, D, L1.w_h, D, P.p_wh1, DD, L1.b_h, vm1, D, 2 * (int64_t)B, D, D));
   DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
-  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, prec, st));
+  DRIN_TRY(lin(vm1, D, L2.w_h, D, P.p_wh2, DD, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D));
   // (5) the two pair-sized layer-1 contractions on the folded weights
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
@@ -354,7 +380,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_pair_layer1(pa, st));
   // (7) layer-2 mention-text vertex
   DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, prec, st));
+  DRIN_TRY(lin(ws + L.agg2, D, L2.w_h, D, P.p_wh2, DD, L2.b_h, ws + L.mt2, D, B, D, D));
   DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
   // (8) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h_text;

@@ -214,6 +214,20 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     }
   }
   __syncthreads();
+  if (a.chunks == 1) {
+    // short candidate lists (N <= 16, WikiDiverse): the workgroup holds the whole mention - write the layout
+    // the mention-side GEMMs read and skip the partial buffer and its reduction pass
+    for (int i = threadIdx.x; i < 2 * D4; i += 256) {
+      const int which = i / D4, c4 = i - which * D4;
+      st4(a.s_text + ((int64_t)which * a.B + b) * D + c4 * 4, ld4(l_red + i * 4));
+    }
+    for (int i = threadIdx.x; i < 2 * R4; i += 256) {
+      const int which = i / R4, c4 = i - which * R4;
+      st4(a.s_img + ((int64_t)which * a.B + b) * R + c4 * 4, ld4(l_red + 2 * D + i * 4));
+    }
+    if (threadIdx.x < 4) a.sig[(int64_t)threadIdx.x * a.B + b] = l_small[a.Km + threadIdx.x];
+    return;
+  }
   float* out = a.s_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D + 2 * R + 4);
   for (int i = threadIdx.x; i < (2 * D + 2 * R) / 4; i += 256) st4(out + i * 4, ld4(l_red + i * 4));
   if (threadIdx.x < 4) out[2 * D + 2 * R + threadIdx.x] = l_small[a.Km + threadIdx.x];

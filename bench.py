@@ -68,23 +68,24 @@ def algorithmic_bytes_per_pair(cfg, batch):
         return 8 + D * 4 + R * 4 + cfg.object_topk_entity * (R + 1) * 4 + 8 + men / N + 4
     B, N = batch[0].shape[0], cfg.num_candidates_model
     D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
+    es = batch[0].element_size()                         # feature storage: 4 (fp32) or 2 (bf16) bytes
     if cfg.token_level_entities:
         ntok = batch[8].sum(-1).float()
         rows = (ntok - 2).clamp(min=0) + 1              # pooled tokens 1..ntok-2 plus the CLS row
-        ent_text = float(rows.mean()) * D * 4 + batch[8].shape[-1] * 8
+        ent_text = float(rows.mean()) * D * es + batch[8].shape[-1] * 8
     else:
-        ent_text = D * 4
-    ent = ent_text + R * 4 + cfg.object_topk_entity * R * 4 + (cfg.object_topk_entity + 2) * 4
+        ent_text = D * es
+    ent = ent_text + R * es + cfg.object_topk_entity * R * es + (cfg.object_topk_entity + 2) * 4
     span = float((batch[3] - batch[2]).float().mean())
-    men = span * D * 4 + cfg.resnet_num_region * R * 4 + cfg.object_topk_mention * (R + 1) * 4 + 16
+    men = span * D * es + cfg.resnet_num_region * R * es + cfg.object_topk_mention * (R * es + 4) + 16
     return ent + men / N + 4
 
 
-def measured_traffic(kernel_prefix, B, precision, fused):
+def measured_traffic(kernel_prefix, B, precision, fused, features="f32"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.py),
     valid only for the configuration they were taken on (default workload); None otherwise."""
     path = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
-    if not (os.path.exists(path) and B == 4096 and precision == "bf16x3" and fused):
+    if not (os.path.exists(path) and B == 4096 and precision == "bf16x3" and fused and features == "f32"):
         return None
     try:
         for k, v in json.load(open(path))["kernels"].items():
@@ -219,6 +220,10 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
                          "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
+    ap.add_argument("--features", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the six feature tensors (BASELINE configs 2-3 name bf16): bf16 halves the bytes "
+                         "of the HBM-bound pass; arithmetic stays fp32-equivalent and the scores equal the reference "
+                         "forward on the same features widened to fp32 (tests/test_gpu_parity.py::test_bf16_stored_features)")
     ap.add_argument("--generic", action="store_true", help="use the layer-by-layer path instead of the fused one")
     ap.add_argument("--mode", default="score", choices=["score", "train"],
                     help="score: the scoring forward (headline metric); train: forward + TripletLoss + backward + "
@@ -268,7 +273,8 @@ def main():
         if args.entity_cache:
             table.enable_cache()
     else:
-        batch = synth.make_device_batch(cfg, B, 100 + rank, dev)[:14]
+        batch = synth.make_device_batch(cfg, B, 100 + rank, dev,
+                                        dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)[:14]
     pairs_per_step = B * N
 
     def barrier():
@@ -329,7 +335,7 @@ def main():
             achieved = work / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": None if cached else measured_traffic("k_entity_stream", B, args.precision, fused),
+                    "traffic": None if cached else measured_traffic("k_entity_stream", B, args.precision, fused, args.features),
                     "launches": int(launches), "avg_launch_ms": per_launch_ms}
         else:
             # algorithmic FLOPs the kernel's launches cover in one step / their summed time.  In split-bf16
@@ -362,7 +368,8 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "hbm_fraction_whole_path": bytes_pair * value / world / (PEAK_HBM_GBS * 1e9),
-            "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + args.precision,
+            "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + args.precision
+                    + (", features stored as bf16" if args.features == "bf16" else ""),
             "algorithmic": {"bytes_per_pair": bytes_pair, "dominant_kernel_bytes_per_pair": stream_bytes_pair, "flops_per_pair_executed": flops_pair,
                             "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
         }

@@ -17,7 +17,9 @@ MAX_LAYERS = 8
 ABI_VERSION = 1
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+FEAT_F32, FEAT_BF16 = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
+FEAT_F32, FEAT_BF16 = 0, 1
 
 fp = C.POINTER(C.c_float)
 ip = C.POINTER(C.c_int64)
@@ -31,7 +33,7 @@ class DrinConfigC(C.Structure):
         ("entity_image_inner", C.c_int32), ("entity_object_inner", C.c_int32), ("num_layers", C.c_int32),
         ("dynamic_edges", C.c_int32), ("edge_enabled", C.c_float * 4), ("layer_norm_eps", C.c_float),
         ("cosine_eps", C.c_float), ("miei_eps", C.c_float), ("clip_scale", C.c_float), ("precision", C.c_int32),
-        ("num_entities", C.c_int32), ("vector_edges", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("num_entities", C.c_int32), ("vector_edges", C.c_int32), ("feature_dtype", C.c_int32),
     ]
 
 

@@ -30,6 +30,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// features stored as bf16 (drin_config.feature_dtype): four values in 8 bytes, widened exactly
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) {

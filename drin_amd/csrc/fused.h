@@ -50,10 +50,10 @@ int fused_supported(const drin_config* c);
 
 struct StreamArgs {
   // batch (entity side) - device pointers into the caller's tensors
-  const float* entity_text;          // TOKENS: [M, T, D]   else [M, D]
+  const void* entity_text;           // TOKENS: [M, T, D]   else [M, D]     (fp32, or bf16 when bf16_features)
   const int64_t* entity_mask;        // TOKENS: [M, T]
-  const float* entity_image;         // [M, R]
-  const float* entity_object;        // [M, Ke, R]
+  const void* entity_image;          // [M, R]
+  const void* entity_object;         // [M, Ke, R]
   const float* entity_object_score;  // [M, Ke]
   const int64_t* entity_index;       // optional [M]: entity_* above are tables, pair p reads row entity_index[p]
   int64_t num_entities;
@@ -61,7 +61,7 @@ struct StreamArgs {
   const float* mtei;                 // [M]
   // mention side
   const float* span_mean;            // [B, D]
-  const float* mobj;                 // [B, Km, R]
+  const void* mobj;                  // [B, Km, R]   (fp32 / bf16 like the entity features)
   const float* mscore;               // [B, Km]
   const float* fu;                   // rows b and B + b, row stride ldfu: W_u(mt0), W_u(mi0)  (dynamic edges only)
   const float* q;                    // [2 B][ldq]  fu * [W_v W_et | W_v W_ei]     (dynamic edges only)
@@ -79,7 +79,7 @@ struct StreamArgs {
   float* s_text;                     // chunks == 1 only: [2][B][D] (S_tt, S_it), [2][B][R] (S_ti, S_ii), [4][B] edge sums,
   float* s_img;                      //   written directly in the layout k_reduce_stream_partials would produce
   float* sig;
-  int B, N, D4, R4, T, Km, Ke, chunks, ldq, ldfu, dynamic;
+  int B, N, D4, R4, T, Km, Ke, chunks, ldq, ldfu, dynamic, bf16_features;
   float mask[4];
   float cos_eps, miei_eps, clip;
 };

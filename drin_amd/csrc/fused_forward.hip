@@ -109,7 +109,7 @@ int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* strea
 
 int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                            float* y, int64_t rows, int32_t n_out, int32_t k, void* stream) {
-  if (!x_hi || !x_lo || !w_hi || !w_lo || !y) {
+  if (!x_hi || !w_hi || !w_lo || !y) {
     set_error("drin_linear_planes_fwd: NULL argument");
     return DRIN_E_NULL;
   }
@@ -246,6 +246,11 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
               "GEMM operands as planes); gather on the caller side for DRIN_PREC_F32");
     return DRIN_E_UNSUPPORTED;
   }
+  const bool bf16_feat = cfg->feature_dtype == DRIN_FEAT_BF16;
+  if (bf16_feat && !planes) {
+    set_error("drin_forward_prepared: bf16 features need the split-bf16 precision (DRIN_PREC_BF16X3) and D, R multiples of 32");
+    return DRIN_E_UNSUPPORTED;
+  }
   __bf16* xt_hi = reinterpret_cast<__bf16*>(ws + L.p_xt);
   __bf16* xi_hi = reinterpret_cast<__bf16*>(ws + L.p_xi);
   __bf16* e1_hi = reinterpret_cast<__bf16*>(ws + L.p_et1);
@@ -265,9 +270,15 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   };
   const size_t DD = (size_t)D * D, DR = (size_t)D * R;
   // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears
-  DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
-                            cfg->mention_tokens, D, st));
-  DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
+  if (bf16_feat) {
+    DRIN_TRY(launch_span_mean_bf16(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
+                                   cfg->mention_tokens, D, st));
+    DRIN_TRY(launch_axis_mean_bf16(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
+  } else {
+    DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
+                              cfg->mention_tokens, D, st));
+    DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
+  }
   float* vm0 = ws + L.vm0;
   // mention-sized contractions take the configured precision too: launch_gemm_nt keeps problems of fewer
   // than 1024 rows on the fp32 kernel (latency-bound), larger ones (WikiDiverse batches) go split-bf16
@@ -300,12 +311,14 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.k_t = pb + P.k_t;
   sa.k_i = pb + P.k_i;
   sa.xt_out = planes ? nullptr : ws + L.xt;
+  // pooled entity text stored as bf16 is exact in its hi plane: no lo plane, two MFMAs per tile pair
+  const bool xt_exact = bf16_feat && !tokens;
   if (planes) {
     sa.xt_hi = xt_hi;
-    sa.xt_lo = xt_hi + MD;
+    sa.xt_lo = xt_exact ? nullptr : xt_hi + MD;
     if (xi_planes) {
       sa.xi_hi = xi_hi;
-      sa.xi_lo = xi_hi + MR;
+      sa.xi_lo = bf16_feat ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
     }
   }
   sa.e0m = ws + L.e0m;
@@ -320,6 +333,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.Ke = cfg->entity_objects;
   sa.chunks = L.chunks;
   sa.dynamic = dyn ? 1 : 0;
+  sa.bf16_features = bf16_feat ? 1 : 0;
   for (int k = 0; k < 4; ++k) sa.mask[k] = cfg->edge_enabled[k];
   sa.cos_eps = cfg->cosine_eps;
   sa.miei_eps = cfg->miei_eps;
@@ -342,9 +356,14 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
-    DRIN_TRY(launch_gemm_x3_planes(xt_hi, xt_hi + MD, D, ct, ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st));
+    DRIN_TRY(launch_gemm_x3_planes(xt_hi, xt_exact ? nullptr : xt_hi + MD, D, ct, ct + (size_t)D * D, D, nullptr,
+                                   ws + L.h_text, D, M, D, D, st));
     if (xi_planes)
-      DRIN_TRY(launch_gemm_x3_planes(xi_hi, xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
+      DRIN_TRY(launch_gemm_x3_planes(xi_hi, bf16_feat ? nullptr : xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr,
+                                     ws + L.h_image, D, M, D, R, st));
+    else if (bf16_feat)  // the bf16 image rows are read in place as the (only) plane of the A operand
+      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M,
+                                     D, R, st));
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
                                      ci + (size_t)D * R));

@@ -16,9 +16,15 @@ namespace drin {
 // ------------------------------------------------------------------------------------------------
 // grid (chunks, B), 256 threads.  Wave w of the workgroup takes candidates c0 + w, c0 + w + 4, ...
 // EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048): the column guards of the row helpers fold away
-template <int DV, int RV, bool TOKENS, bool EXACT>
+// FT: storage type of the feature tensors (float, or __bf16 with drin_config.feature_dtype = DRIN_FEAT_BF16 - half
+// the bytes of this HBM-bound pass; all arithmetic stays fp32)
+template <int DV, int RV, bool TOKENS, bool EXACT, typename FT>
 __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const FT* const f_text = static_cast<const FT*>(a.entity_text);
+  const FT* const f_image = static_cast<const FT*>(a.entity_image);
+  const FT* const f_object = static_cast<const FT*>(a.entity_object);
+  const FT* const f_mobj = static_cast<const FT*>(a.mobj);
   const int D4 = EXACT ? DV * 64 : a.D4, R4 = EXACT ? RV * 64 : a.R4, D = D4 * 4, R = R4 * 4;
   float* l_mobj = lds;                          // [Km][R]
   float* l_q = l_mobj + a.Km * R;               // [2][R]   q_ti, q_ii
@@ -32,7 +38,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   const bool dyn = a.dynamic != 0;
 
   // ---- per-workgroup prologue: mention-side vectors into LDS / registers -----------------------------
-  for (int i = threadIdx.x; i < a.Km * R4; i += 256) st4(l_mobj + i * 4, ld4(a.mobj + (b * a.Km) * R + i * 4));
+  for (int i = threadIdx.x; i < a.Km * R4; i += 256) st4(l_mobj + i * 4, ld4(f_mobj + (b * a.Km) * R + i * 4));
   for (int i = threadIdx.x; i < D4; i += 256) st4(l_mt + i * 4, ld4(a.span_mean + b * D + i * 4));
   if (dyn) {
     for (int i = threadIdx.x; i < 2 * R4; i += 256) {
@@ -95,10 +101,23 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       int stop = cnt - 1;
       if (stop < 0) stop += T;
       stop = stop < 0 ? 0 : (stop > T ? T : stop);
-      const float* base = a.entity_text + e * (int64_t)T * D;
+      const FT* base = f_text + e * (int64_t)T * D;
       const Row<DV> cls = load_row<DV>(base, lane, D4);
       Row<DV> acc = zero_row<DV>();
       int t = 1;
+      if constexpr (sizeof(FT) == 2) {
+        // bf16 rows are half the bytes: twice as many of them in flight keeps the same bytes in flight per wave
+        // (the pass is bound by per-CU memory latency, not by instruction issue); same left-to-right sum
+        for (; t + 8 <= stop; t += 8) {
+          Row<DV> r[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r[u] = load_row<DV>(base + (int64_t)(t + u) * D, lane, D4);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < DV; ++j) acc.v[j] = acc.v[j] + r[u].v[j];
+        }
+      }
       for (; t + 4 <= stop; t += 4) {  // 4 token rows (12 KB at D = 768) in flight per wave
         const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
         const Row<DV> r1 = load_row<DV>(base + (int64_t)(t + 1) * D, lane, D4);
@@ -120,7 +139,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       const float xy = wave_sum(dot_row_lds<DV>(cls, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(cls, cls));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     } else {
-      xt = load_row<DV>(a.entity_text + e * D, lane, D4);
+      xt = load_row<DV>(f_text + e * D, lane, D4);
       const float xy = wave_sum(dot_row_lds<DV>(xt, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(xt, xt));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     }
@@ -128,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // ---- objects: weighted pair similarity (model.py:84-92) ------------------------------------------
     float sim = 0.f, wsum = 0.f;
     for (int j = 0; j < a.Ke; ++j) {
-      const Row<RV> eo = load_row<RV>(a.entity_object + (e * a.Ke + j) * R, lane, R4);
+      const Row<RV> eo = load_row<RV>(f_object + (e * a.Ke + j) * R, lane, R4);
       const float ny = fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps);
       const float es = a.entity_object_score[e * a.Ke + j];
       for (int i = 0; i < a.Km; ++i) {
@@ -141,7 +160,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // the reference sums i-major, j-minor; with Ke = 1 (both datasets) the orders coincide
     const float ii = sim / (wsum + a.miei_eps);
     // ---- image row + edges ----------------------------------------------------------------------------
-    const Row<RV> xi = load_row<RV>(a.entity_image + e * R, lane, R4);
+    const Row<RV> xi = load_row<RV>(f_image + e * R, lane, R4);
     if (a.xi_hi) store_row_planes<RV>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
@@ -238,10 +257,10 @@ size_t entity_stream_lds_bytes(const StreamArgs& a) {
   return sizeof(float) * (a.Km * R + 2 * R + 2 * D + 2 * R + 3 * D + a.Km + 4);
 }
 
-template <int DV, int RV, bool TOKENS, bool EXACT>
-static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
+template <int DV, int RV, bool TOKENS, bool EXACT, typename FT>
+static int launch_stream_ft(const StreamArgs& a, hipStream_t st) {
   const size_t lds = entity_stream_lds_bytes(a);
-  auto kern = k_entity_stream<DV, RV, TOKENS, EXACT>;
+  auto kern = k_entity_stream<DV, RV, TOKENS, EXACT, FT>;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -253,6 +272,12 @@ static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), lds, st, a);
   DRIN_CHECK_LAUNCH("k_entity_stream");
   return DRIN_OK;
+}
+
+template <int DV, int RV, bool TOKENS, bool EXACT>
+static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
+  return a.bf16_features ? launch_stream_ft<DV, RV, TOKENS, EXACT, __bf16>(a, st)
+                         : launch_stream_ft<DV, RV, TOKENS, EXACT, float>(a, st);
 }
 
 int launch_entity_stream(const StreamArgs& a, hipStream_t st) {

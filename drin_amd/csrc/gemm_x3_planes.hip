@@ -47,14 +47,19 @@ struct Pieces {
   const char* src[8];  // per-lane source of each piece at k-block 0
 };
 
+// A_LO = false: the A operand is exact in bf16 (features stored as bf16) - no lo plane is fetched (waves 2 and 3
+// issue nothing) and the lo x hi MFMA is dropped: two MFMAs per tile pair instead of three.
+template <bool A_LO>
 __device__ __forceinline__ void issue_piece(const Pieces& p, char* buf, int kb, int i) {
   const int wave = threadIdx.x >> 6;
+  if (!A_LO && (wave >> 1) == 1) return;
   char* plane_base = buf + (wave >> 1) * PLANE_BYTES + (wave & 1) * 128 * 64;
   __builtin_amdgcn_global_load_lds((gptr_t)(p.src[i] + (int64_t)kb * (BK * 2)), (lptr_t)(plane_base + i * 1024), 16, 0, 0);
 }
+template <bool A_LO>
 __device__ __forceinline__ void issue_tile(const Pieces& p, char* buf, int kb) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) issue_piece(p, buf, kb, i);
+  for (int i = 0; i < 8; ++i) issue_piece<A_LO>(p, buf, kb, i);
 }
 
 // MFMA shape: v_mfma_f32_16x16x32_bf16.  The wave tile 128 x 64 is 8 x 4 tiles of 16 x 16 and a whole K-block
@@ -90,6 +95,7 @@ __device__ __forceinline__ Pieces make_pieces(const __bf16* a_hi, const __bf16* 
   return p;
 }
 
+template <bool A_LO>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                        const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
@@ -113,8 +119,8 @@ __global__ void __launch_bounds__(THREADS, 2)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
-  const Pieces pieces = make_pieces(a_hi, a_lo, lda, m0, M, b_hi, b_lo, ldb, n0, N);
-  issue_tile(pieces, smem, 0);
+  const Pieces pieces = make_pieces(a_hi, A_LO ? a_lo : a_hi, lda, m0, M, b_hi, b_lo, ldb, n0, N);
+  issue_tile<A_LO>(pieces, smem, 0);
   __syncthreads();
 
   for (int kb = 0; kb < nkb; ++kb) {
@@ -132,19 +138,19 @@ __global__ void __launch_bounds__(THREADS, 2)
     {
       const int off = swz16(wm * 128 + r, c);
       ah[0] = *reinterpret_cast<const bf16x8*>(buf + off);
-      al[0] = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
+      if (A_LO) al[0] = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {  // eight row tiles; the next one's fragments are read one stage ahead
-      if (more) issue_piece(pieces, nbuf, kb + 1, t);
+      if (more) issue_piece<A_LO>(pieces, nbuf, kb + 1, t);
       if (t + 1 < 8) {
         const int off = swz16(wm * 128 + (t + 1) * 16 + r, c);
         ah[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + off);
-        al[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
+        if (A_LO) al[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1], bh[j], acc[t][j], 0, 0, 0);
+        if (A_LO) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1], bh[j], acc[t][j], 0, 0, 0);
         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bl[j], acc[t][j], 0, 0, 0);
         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bh[j], acc[t][j], 0, 0, 0);
       }
@@ -207,6 +213,7 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
                           hipStream_t st) {
   if (M <= 0 || N <= 0) return DRIN_OK;
+  const bool a_lo_plane = a_lo != nullptr;  // NULL: A is exact in bf16 (one plane, two MFMAs per tile pair)
   if (K <= 0 || (K % x3p::BK) || (lda % 8) || (ldb % 8) || !aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) ||
       !aligned16(b_lo)) {
     set_error("gemm_x3_planes: K=%d must be a multiple of 32, leading dimensions multiples of 8, planes 16-byte aligned", K);
@@ -219,15 +226,22 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
   }
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3p::k_gemm_x3_planes),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, x3p::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, x3p::LDS_BYTES);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_x3_planes)");
     attr_done = true;
   }
   dim3 grid((unsigned)cdiv(N, x3p::BN), (unsigned)mt);
   KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
-  hipLaunchKernelGGL(x3p::k_gemm_x3_planes, grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, (const __bf16*)a_hi,
-                     (const __bf16*)a_lo, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K);
+  if (a_lo_plane)
+    hipLaunchKernelGGL(x3p::k_gemm_x3_planes<true>, grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, (const __bf16*)a_hi,
+                       (const __bf16*)a_lo, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K);
+  else
+    hipLaunchKernelGGL(x3p::k_gemm_x3_planes<false>, grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, (const __bf16*)a_hi,
+                       (const __bf16*)nullptr, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K);
   DRIN_CHECK_LAUNCH("k_gemm_x3_planes");
   return DRIN_OK;
 }

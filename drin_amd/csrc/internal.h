@@ -41,6 +41,10 @@ int launch_axis_mean(const float* in, float* out, int64_t groups, int inner, int
 // Avg.avg (ghmfc.py:54-60): out[b, :] = mean(seq[b, start[b]:end[b], :])
 int launch_span_mean(const float* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
                      hipStream_t st);
+// the same two for features stored as bf16 (drin_config.feature_dtype = DRIN_FEAT_BF16)
+int launch_axis_mean_bf16(const void* in, float* out, int64_t groups, int inner, int cols, hipStream_t st);
+int launch_span_mean_bf16(const void* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
+                          hipStream_t st);
 // ghmfc.py:245-249: out[p, :] = mean(feat[p, 1:ntok-1, :]), ntok = sum(mask[p, :])
 int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
                              hipStream_t st);

@@ -10,8 +10,8 @@ struct Row {
   float4 v[V];
 };
 
-template <int V>
-__device__ __forceinline__ Row<V> load_row(const float* __restrict__ p, int lane, int n4) {
+template <int V, typename T = float>
+__device__ __forceinline__ Row<V> load_row(const T* __restrict__ p, int lane, int n4) {
   Row<V> r;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void store_row_planes(void* __restrict__ hi, void* __
       l[2] = (__bf16)(v.z - (float)h[2]);
       l[3] = (__bf16)(v.w - (float)h[3]);
       *reinterpret_cast<bf16x4*>(ph + c4 * 4) = h;
-      *reinterpret_cast<bf16x4*>(pl + c4 * 4) = l;
+      if (lo != nullptr) *reinterpret_cast<bf16x4*>(pl + c4 * 4) = l;  // no lo plane: the values are exact in bf16
     }
   }
 }

@@ -10,12 +10,13 @@ namespace drin {
 // ------------------------------------------------------------------------------------------------
 // out[g, c] = mean_s in[g, s, c]      (region mean over P, "inner" means of model.py:43-44,78-83)
 // grid: (ceil(cols/4 / 256), groups); each thread owns one float4 column and walks the inner axis.
-__global__ void __launch_bounds__(256) k_axis_mean(const float* __restrict__ in, float* __restrict__ out, int inner,
+template <typename T>
+__global__ void __launch_bounds__(256) k_axis_mean(const T* __restrict__ in, float* __restrict__ out, int inner,
                                                    int cols4) {
   const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
   if (c4 >= cols4) return;
   const int64_t g = blockIdx.y;
-  const float* p = in + (g * inner) * (int64_t)cols4 * 4 + (int64_t)c4 * 4;
+  const T* p = in + (g * inner) * (int64_t)cols4 * 4 + (int64_t)c4 * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int s = 0;
   for (; s + 7 <= inner; s += 7) {  // 7 independent 16-B loads in flight (P = 49 = 7 * 7)
@@ -30,7 +31,8 @@ __global__ void __launch_bounds__(256) k_axis_mean(const float* __restrict__ in,
   st4(out + g * (int64_t)cols4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt));
 }
 
-int launch_axis_mean(const float* in, float* out, int64_t groups, int inner, int cols, hipStream_t st) {
+template <typename T>
+static int launch_axis_mean_t(const T* in, float* out, int64_t groups, int inner, int cols, hipStream_t st) {
   if (groups <= 0) return DRIN_OK;
   if (cols % 4 != 0 || inner <= 0) {
     set_error("axis_mean: cols=%d must be a multiple of 4 and inner=%d positive", cols, inner);
@@ -39,22 +41,30 @@ int launch_axis_mean(const float* in, float* out, int64_t groups, int inner, int
   if (groups > 65535) {  // grid.y limit: fold in chunks
     for (int64_t g0 = 0; g0 < groups; g0 += 65535) {
       const int64_t n = groups - g0 < 65535 ? groups - g0 : 65535;
-      DRIN_TRY(launch_axis_mean(in + g0 * inner * cols, out + g0 * cols, n, inner, cols, st));
+      DRIN_TRY(launch_axis_mean_t<T>(in + g0 * inner * cols, out + g0 * cols, n, inner, cols, st));
     }
     return DRIN_OK;
   }
   const int cols4 = cols / 4;
   dim3 grid((unsigned)cdiv(cols4, 256), (unsigned)groups);
   KernelTimer timer(DRIN_KC_POOL, st);
-  hipLaunchKernelGGL(k_axis_mean, grid, dim3(256), 0, st, in, out, inner, cols4);
+  hipLaunchKernelGGL(k_axis_mean<T>, grid, dim3(256), 0, st, in, out, inner, cols4);
   DRIN_CHECK_LAUNCH("k_axis_mean");
   return DRIN_OK;
+}
+
+int launch_axis_mean(const float* in, float* out, int64_t groups, int inner, int cols, hipStream_t st) {
+  return launch_axis_mean_t<float>(in, out, groups, inner, cols, st);
+}
+int launch_axis_mean_bf16(const void* in, float* out, int64_t groups, int inner, int cols, hipStream_t st) {
+  return launch_axis_mean_t<__bf16>(static_cast<const __bf16*>(in), out, groups, inner, cols, st);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Avg.avg (baselines/ghmfc.py:54-60).  Python slice semantics: the range is clipped to [0, L]; an
 // empty range gives 0/0 = NaN like torch.mean of an empty slice.  grid: (ceil(D/4/256), B).
-__global__ void __launch_bounds__(256) k_span_mean(const float* __restrict__ seq, const int64_t* __restrict__ start,
+template <typename T>
+__global__ void __launch_bounds__(256) k_span_mean(const T* __restrict__ seq, const int64_t* __restrict__ start,
                                                    const int64_t* __restrict__ end, float* __restrict__ out, int L,
                                                    int D4) {
   const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,15 +75,16 @@ __global__ void __launch_bounds__(256) k_span_mean(const float* __restrict__ seq
   if (e < 0) e = e + L < 0 ? 0 : e + L;
   if (e > L) e = L;
   if (s > L) s = L;
-  const float* p = seq + ((int64_t)b * L) * D4 * 4 + (int64_t)c4 * 4;
+  const T* p = seq + ((int64_t)b * L) * D4 * 4 + (int64_t)c4 * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t t = s; t < e; ++t) acc = acc + ld4(p + t * D4 * 4);
   const float cnt = e > s ? (float)(e - s) : 0.0f;  // empty span: 0 / 0 = NaN, as the reference
   st4(out + (int64_t)b * D4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt));
 }
 
-int launch_span_mean(const float* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
-                     hipStream_t st) {
+template <typename T>
+static int launch_span_mean_t(const T* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
+                              hipStream_t st) {
   if (B <= 0) return DRIN_OK;
   if (D % 4 != 0) {
     set_error("span_mean: D=%d must be a multiple of 4", D);
@@ -83,11 +94,20 @@ int launch_span_mean(const float* seq, const int64_t* start, const int64_t* end,
     const int nb = B - b0 < 65535 ? B - b0 : 65535;
     dim3 grid((unsigned)cdiv(D / 4, 256), (unsigned)nb);
     KernelTimer timer(DRIN_KC_POOL, st);
-    hipLaunchKernelGGL(k_span_mean, grid, dim3(256), 0, st, seq + (int64_t)b0 * L * D, start + b0, end + b0,
+    hipLaunchKernelGGL(k_span_mean<T>, grid, dim3(256), 0, st, seq + (int64_t)b0 * L * D, start + b0, end + b0,
                        out + (int64_t)b0 * D, L, D / 4);
     DRIN_CHECK_LAUNCH("k_span_mean");
   }
   return DRIN_OK;
+}
+
+int launch_span_mean(const float* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
+                     hipStream_t st) {
+  return launch_span_mean_t<float>(seq, start, end, out, B, L, D, st);
+}
+int launch_span_mean_bf16(const void* seq, const int64_t* start, const int64_t* end, float* out, int B, int L, int D,
+                          hipStream_t st) {
+  return launch_span_mean_t<__bf16>(static_cast<const __bf16*>(seq), start, end, out, B, L, D, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -165,7 +165,9 @@ class _Call:
     """One forward's C structs; keeps the tensors they point into alive."""
 
     def __init__(self, cfg: DrinConfig, batch: Sequence[torch.Tensor], precision: int,
-                 entity_index: Optional[torch.Tensor] = None):
+                 entity_index: Optional[torch.Tensor] = None, keep_bf16: bool = False):
+        """`keep_bf16`: the caller will take a path that reads bf16-stored features in place (fused inference);
+        otherwise bf16 features are widened to fp32 here (exact) - e.g. for training."""
         if len(batch) not in (14, 15):
             raise ValueError(f"batch must be the 14-sequence of drin/data.py:110-126 (got {len(batch)} items)")
         (mtf, _mask, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei) = batch[:14]
@@ -178,11 +180,24 @@ class _Call:
                 raise RuntimeError("all batch tensors must be on the same device")
             return t.to(torch.float32).contiguous()
 
+        # bf16 feature storage (BASELINE configs 2-3): all six feature tensors, or none
+        feats = (mtf, mimg, mobj, etf, eimg, eobj)
+        n_bf16 = sum(t.dtype == torch.bfloat16 for t in feats)
+        bf16 = keep_bf16 and n_bf16 == len(feats)
+        if keep_bf16 and 0 < n_bf16 < len(feats):
+            raise ValueError("bf16 feature storage: give all six feature tensors (mention text / image / object, entity "
+                             "text / image / object) as bfloat16, or none")
+
+        def feat(t):
+            if t.device != dev:
+                raise RuntimeError("all batch tensors must be on the same device")
+            return t.contiguous() if bf16 else t.to(torch.float32).contiguous()
+
         def i64(t):
             return t.to(device=dev, dtype=torch.int64).contiguous()
 
-        mtf, mimg, mobj, mscore, etf, eimg, eobj, escore, miet, mtei = map(
-            f32, (mtf, mimg, mobj, mscore, etf, eimg, eobj, escore, miet, mtei))
+        mtf, mimg, mobj, etf, eimg, eobj = map(feat, feats)
+        mscore, escore, miet, mtei = map(f32, (mscore, escore, miet, mtei))
         start, end = i64(start), i64(end)
         B, L, D = mtf.shape
         N = cfg.num_candidates_model
@@ -249,6 +264,7 @@ class _Call:
         c.precision = precision
         c.num_entities = etf.shape[0] if table else 0
         c.vector_edges = 1 if cfg.gcn_edge_feature == "vector" else 0
+        c.feature_dtype = _lib.FEAT_BF16 if bf16 else _lib.FEAT_F32
         self.per_layer = 10 if c.vector_edges else 8
         self.cfg = c
         b = _lib.DrinBatchC()
@@ -361,19 +377,28 @@ class Model(nn.Module):
             if inference and self._prepared is not None and self.cfg.num_gcn_layers == 2 and (planes or t.cache_enabled):
                 seq = batch.mention + [t.text, t.mask, t.image, t.object, t.object_score,
                                        batch.miet_similarity, batch.mtei_similarity]
-                call = _Call(self.cfg, seq, self.precision, entity_index=batch.candidates)
+                if t.cache_enabled and t.text.dtype == torch.bfloat16:
+                    raise ValueError("the per-entity cache is built from fp32 tables; give EntityTable fp32 features")
+                # bf16-stored features are read in place by the fused path (never widened: the table is large)
+                call = _Call(self.cfg, seq, self.precision, entity_index=batch.candidates, keep_bf16=planes and not t.cache_enabled)
                 if _lib.load().drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
                     if t.cache_enabled:                                # per-entity precompute cache
                         return self._forward_cached(call, t, params)
                     if planes:
                         return _DrinScore.apply(call, self._prepared, False, *params)
             batch = batch.gathered()
-        call = _Call(self.cfg, batch, self.precision)
-        if call.B == 0:
-            return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         # grad mode is already off inside Function.forward (and needs_input_grad ignores no_grad), so the
         # caller's mode is read here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        # features stored as bf16 are read in place by the fused inference path in split-bf16 precision; every
+        # other path (training, exact fp32, geometries off the fused path) gets them widened to fp32 - exact
+        in_place = (not training and self._prepared is not None and self.cfg.num_gcn_layers == 2
+                    and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL))
+        call = _Call(self.cfg, batch, self.precision, keep_bf16=in_place)
+        if call.cfg.feature_dtype != _lib.FEAT_F32 and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK:
+            call = _Call(self.cfg, batch, self.precision)
+        if call.B == 0:
+            return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         return _DrinScore.apply(call, self._prepared, training, *params)
 
     @torch.no_grad()

@@ -77,8 +77,19 @@ typedef struct {
   int32_t num_entities;     /* rows of the entity TABLES when drin_batch.entity_index is set, else 0    */
   int32_t vector_edges;     /* gcn_edge_feature == "vector" (args.py:33): edges are [B, N, D], w_m is a Linear,
                                w_u / w_v map D -> D/2 (model.py:112-116,151-152).  Layer-by-layer path only. */
-  int32_t reserved[1];
+  int32_t feature_dtype;    /* drin_feature_dtype: storage type of the six FEATURE tensors of drin_batch (mention_text,
+                               mention_image, mention_object, entity_text, entity_image, entity_object).  With
+                               DRIN_FEAT_BF16 those pointers address bf16 arrays of the same shapes - half the bytes
+                               of the HBM-bound pass; scores, similarities, masks, weights and ALL arithmetic stay
+                               fp32 (a bf16 value is exact in fp32, so the result equals the reference forward on
+                               the same features widened to fp32).  drin_forward_prepared only; the other paths
+                               return DRIN_E_UNSUPPORTED (widen the features on the caller side). */
 } drin_config;
+
+typedef enum {
+  DRIN_FEAT_F32 = 0,
+  DRIN_FEAT_BF16 = 1
+} drin_feature_dtype;
 
 /* The 14 tensors `Model.forward` unpacks (drin/model.py:165-180), device pointers.
  * mention_text_mask is carried by the reference but never read by the DRIN compute, so it is absent. */
@@ -232,7 +243,8 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* batch
 
 /* Building blocks of the split-bf16 precision: x = hi + lo with hi, lo bf16 planes (n % 4 == 0), and the
  * contraction y = x w^T (+ bias) on such planes by LDS-DMA + bf16 MFMA (k % 32 == 0).  Plane pointers are
- * device pointers to bf16 arrays with the row strides of the fp32 originals. */
+ * device pointers to bf16 arrays with the row strides of the fp32 originals.  x_lo may be NULL when x is
+ * exact in bf16 (then two MFMAs per tile pair instead of three). */
 DRIN_API int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
 DRIN_API int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                     const float* bias, float* y, int64_t rows, int32_t n_out, int32_t k,

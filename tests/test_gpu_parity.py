@@ -655,6 +655,87 @@ def test_inner_feature_dims_take_the_pooled_path():
     assert (got - ref).abs().max().item() <= 2e-5
 
 
+# ---- features stored as bf16 (BASELINE configs 2-3) -----------------------------------------------------------
+FEATURE_SLOTS = (0, 4, 5, 7, 9, 10)   # mention text / image / object, entity text / image / object
+
+
+def _bf16_features(batch):
+    return [t.to(torch.bfloat16) if i in FEATURE_SLOTS else t for i, t in enumerate(batch)]
+
+
+@pytest.mark.parametrize("kw,B", [
+    (dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16,
+          resnet_num_region=4), 5),
+    (dict(max_mention_sentence_len=16, resnet_num_region=4), 40),
+    (dict(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY), 6),
+    (dict(num_candidates_data=7, gcn_edge_type="static", **TINY), 9),
+], ids=["wikimel_dims", "wikidiverse_dims", "tiny_tokens", "tiny_pooled_static"])
+def test_bf16_stored_features(kw, B):
+    """Features stored as bf16 and read in place by the fused path (half the bytes of the HBM-bound pass): the scores
+    equal the reference forward on the SAME features widened to fp32 (oracle, 1e-5) and the library's own fp32-feature
+    run on the widened tensors (fp32 re-association only); every other path widens them first, exactly."""
+    cfg = DrinConfig(**kw)
+    sd = synth.make_state_dict(cfg, 9)
+    stored = _bf16_features(synth.make_batch(cfg, B, 31)[:14])
+    widened = [t.float() if t.dtype == torch.bfloat16 else t for t in stored]
+    ref = O.forward(sd, widened, dynamic=cfg.gcn_edge_type == "dynamic")
+    model = Model(cfg, precision="bf16x3_all").to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        _lib.profile_begin()
+        s_bf16 = model(_to_dev(stored))
+        prof = _lib.profile_end()
+        s_f32 = model(_to_dev(widened))
+    assert prof["stream"][1] == 1, "the fused path reads the bf16 features in place"
+    err = (s_bf16.cpu() - ref).abs().max().item()
+    print(f"bf16-stored features: max |score - oracle(widened)| = {err:.3e}, vs fp32-feature run {(s_bf16 - s_f32).abs().max().item():.3e}")
+    assert err <= 1e-5 and (s_bf16 - s_f32).abs().max().item() <= 4e-6
+    # exact-fp32 precision and training widen the features (exactly): same bits as the widened tensors
+    exact = Model(cfg, precision="f32").to(DEV).eval()
+    exact.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(exact(_to_dev(stored)), exact(_to_dev(widened)))
+    model.train()
+    model(_to_dev(stored)).sum().backward()
+    g1 = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    model.zero_grad()
+    model(_to_dev(widened)).sum().backward()
+    g2 = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(g1) == len(g2) and all((a - b).abs().max().item() <= 1e-6 * (b.abs().max().item() + 1e-12) + 1e-9 for a, b in zip(g1, g2))
+    # all six or none
+    mixed = list(stored)
+    mixed[9] = mixed[9].float()
+    with pytest.raises(ValueError, match="all six"):
+        with torch.no_grad():
+            model.eval()(_to_dev(mixed))
+
+
+def test_bf16_stored_entity_table():
+    """Table form with bf16 tables: gathered inside the stream kernel, equal to the gathered bf16 batch."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    E, B, N = 57, 6, cfg.num_candidates_model
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 71)
+    bf = torch.bfloat16
+    table = EntityTable(tab[7][0].to(bf), tab[8][0], tab[9][0].to(bf), tab[10][0].to(bf), tab[11][0]).to(DEV)
+    men = _to_dev(_bf16_features(synth.make_batch(cfg, B, 72)))
+    cand = torch.randint(0, E, (B, N), generator=torch.Generator().manual_seed(3)).to(DEV)
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    model = Model(cfg, precision="bf16x3_all").to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        a, b = model(ib), model(ib.gathered())
+    assert torch.equal(a, b)
+    ref = O.forward(sd, [t.float().cpu() if t.dtype == bf else t.cpu() for t in ib.gathered()])
+    assert (a.cpu() - ref).abs().max().item() <= 1e-5
+    with pytest.raises(ValueError, match="fp32 tables"):
+        table.enable_cache()
+        with torch.no_grad():
+            model(ib)
+    table.enable_cache(False)
+
+
 # ---- per-entity precompute cache (SURVEY.md 8f-2) ----------------------------------------------------------
 @pytest.mark.parametrize("kw", [
     dict(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY),

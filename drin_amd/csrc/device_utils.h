@@ -30,10 +30,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// once-read streaming loads (entity rows of k_entity_stream): non-temporal cache policy
+#ifdef DRIN_NO_NT_LOADS
+__device__ __forceinline__ float4 ld4_stream(const float* p) { return ld4(p); }
+#else
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+#endif
 // features stored as bf16 (drin_config.feature_dtype): four values in 8 bytes, widened exactly
 __device__ __forceinline__ float4 ld4(const __bf16* p) {
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
   const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ float4 ld4_stream(const __bf16* p) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#ifdef DRIN_NO_NT_LOADS
+  const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+#else
+  const bf16x4_t v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_t*>(p));
+#endif
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

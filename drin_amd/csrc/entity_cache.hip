@@ -198,12 +198,12 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
   };
   auto fetch = [&](PairRow& r, int64_t e, int64_t p) {
     const float* row = a.cache + e * a.ldc;
-    r.chat = load_row<DV>(row + 4 * D, lane, D4);
-    r.ohat = load_row<RV>(row + 5 * D, lane, R4);
+    r.chat = load_row_stream<DV>(row + 4 * D, lane, D4);
+    r.ohat = load_row_stream<RV>(row + 5 * D, lane, R4);
     r.sg = row[5 * D + R];
     if (dyn) {
-      r.fvt = load_row<DV>(row + 2 * D, lane, D4);
-      r.fvi = load_row<DV>(row + 3 * D, lane, D4);
+      r.fvt = load_row_stream<DV>(row + 2 * D, lane, D4);
+      r.fvi = load_row_stream<DV>(row + 3 * D, lane, D4);
     }
     r.mtei = a.mtei[p];
     r.miet = a.miet[p];
@@ -265,8 +265,8 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     const PairRow& r = cur;
     __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later pairs' loads into this one (spills)
     // the vertex-phase operands of THIS pair: requested now, needed after the edge phase
-    const Row<DV> ht = load_row<DV>(a.cache + e_cur * a.ldc, lane, D4);
-    const Row<DV> hi = load_row<DV>(a.cache + e_cur * a.ldc + D, lane, D4);
+    const Row<DV> ht = load_row_stream<DV>(a.cache + e_cur * a.ldc, lane, D4);
+    const Row<DV> hi = load_row_stream<DV>(a.cache + e_cur * a.ldc + D, lane, D4);
     // ---- static edges (model.py:71-92, 201-204) ------------------------------------------------------------
     const float e_tt = wave_sum(dot_row_lds<DV>(r.chat, l_s, lane, D4)) * a.mask[0];
     const float e_ti = (r.mtei / a.clip) * a.mask[1];

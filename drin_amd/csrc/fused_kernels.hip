@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       if (stop < 0) stop += T;
       stop = stop < 0 ? 0 : (stop > T ? T : stop);
       const FT* base = f_text + e * (int64_t)T * D;
-      const Row<DV> cls = load_row<DV>(base, lane, D4);
+      const Row<DV> cls = load_row_stream<DV>(base, lane, D4);
       Row<DV> acc = zero_row<DV>();
       int t = 1;
       if constexpr (sizeof(FT) == 2) {
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
         for (; t + 8 <= stop; t += 8) {
           Row<DV> r[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) r[u] = load_row<DV>(base + (int64_t)(t + u) * D, lane, D4);
+          for (int u = 0; u < 8; ++u) r[u] = load_row_stream<DV>(base + (int64_t)(t + u) * D, lane, D4);
 #pragma unroll
           for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -119,15 +119,15 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
         }
       }
       for (; t + 4 <= stop; t += 4) {  // 4 token rows (12 KB at D = 768) in flight per wave
-        const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
-        const Row<DV> r1 = load_row<DV>(base + (int64_t)(t + 1) * D, lane, D4);
-        const Row<DV> r2 = load_row<DV>(base + (int64_t)(t + 2) * D, lane, D4);
-        const Row<DV> r3 = load_row<DV>(base + (int64_t)(t + 3) * D, lane, D4);
+        const Row<DV> r0 = load_row_stream<DV>(base + (int64_t)t * D, lane, D4);
+        const Row<DV> r1 = load_row_stream<DV>(base + (int64_t)(t + 1) * D, lane, D4);
+        const Row<DV> r2 = load_row_stream<DV>(base + (int64_t)(t + 2) * D, lane, D4);
+        const Row<DV> r3 = load_row_stream<DV>(base + (int64_t)(t + 3) * D, lane, D4);
 #pragma unroll
         for (int j = 0; j < DV; ++j) acc.v[j] = (((acc.v[j] + r0.v[j]) + r1.v[j]) + r2.v[j]) + r3.v[j];
       }
       for (; t < stop; ++t) {
-        const Row<DV> r0 = load_row<DV>(base + (int64_t)t * D, lane, D4);
+        const Row<DV> r0 = load_row_stream<DV>(base + (int64_t)t * D, lane, D4);
 #pragma unroll
         for (int j = 0; j < DV; ++j) acc.v[j] = acc.v[j] + r0.v[j];
       }
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       const float xy = wave_sum(dot_row_lds<DV>(cls, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(cls, cls));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     } else {
-      xt = load_row<DV>(f_text + e * D, lane, D4);
+      xt = load_row_stream<DV>(f_text + e * D, lane, D4);
       const float xy = wave_sum(dot_row_lds<DV>(xt, l_mt, lane, D4)), yy = wave_sum(dot_rows<DV>(xt, xt));
       tt = xy / (m_t_norm * fmaxf(sqrtf(yy), a.cos_eps));
     }
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // ---- objects: weighted pair similarity (model.py:84-92) ------------------------------------------
     float sim = 0.f, wsum = 0.f;
     for (int j = 0; j < a.Ke; ++j) {
-      const Row<RV> eo = load_row<RV>(f_object + (e * a.Ke + j) * R, lane, R4);
+      const Row<RV> eo = load_row_stream<RV>(f_object + (e * a.Ke + j) * R, lane, R4);
       const float ny = fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps);
       const float es = a.entity_object_score[e * a.Ke + j];
       for (int i = 0; i < a.Km; ++i) {
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // the reference sums i-major, j-minor; with Ke = 1 (both datasets) the orders coincide
     const float ii = sim / (wsum + a.miei_eps);
     // ---- image row + edges ----------------------------------------------------------------------------
-    const Row<RV> xi = load_row<RV>(f_image + e * R, lane, R4);
+    const Row<RV> xi = load_row_stream<RV>(f_image + e * R, lane, R4);
     if (a.xi_hi) store_row_planes<RV>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
   Row<DV> S_t = zero_row<DV>(), S_i = zero_row<DV>();
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
-    const Row<DV> ht = load_row<DV>(a.h_text + p * D, lane, D4);
-    const Row<DV> hi = load_row<DV>(a.h_image + p * D, lane, D4);
+    const Row<DV> ht = load_row_stream<DV>(a.h_text + p * D, lane, D4);  // read once: streaming cache policy
+    const Row<DV> hi = load_row_stream<DV>(a.h_image + p * D, lane, D4);
     const float e_tt = a.e0m[p], e_ti = a.e0m[M + p], e_it = a.e0m[2 * M + p], e_ii = a.e0m[3 * M + p];
     const Row<DV> et1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4), l_gamma,
                                             l_beta, lane, D4, a.ln_eps);
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
   const float xx = wave_sum(dot_rows<DV>(mt2, mt2));
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
-    const Row<DV> h = load_row<DV>(a.h2 + p * D, lane, D4);
+    const Row<DV> h = load_row_stream<DV>(a.h2 + p * D, lane, D4);
     const Row<DV> et2 = ln_gelu_row_lds<DV>(
         combine_rows_lds<DV>(h, a.e1m[p], l_const, a.e1m[2 * M + p], l_const + LD, l_const + 2 * LD, lane, D4),
         l_const + 3 * LD, l_const + 4 * LD, lane, D4, a.ln_eps);

@@ -20,6 +20,17 @@ __device__ __forceinline__ Row<V> load_row(const T* __restrict__ p, int lane, in
   }
   return r;
 }
+// the same with the streaming (non-temporal) cache policy: rows that are read exactly once
+template <int V, typename T = float>
+__device__ __forceinline__ Row<V> load_row_stream(const T* __restrict__ p, int lane, int n4) {
+  Row<V> r;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c4 = lane + 64 * j;
+    r.v[j] = c4 < n4 ? ld4_stream(p + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  return r;
+}
 template <int V>
 __device__ __forceinline__ void store_row(float* __restrict__ p, const Row<V>& r, int lane, int n4) {
 #pragma unroll

@@ -22,11 +22,11 @@ __global__ void __launch_bounds__(256) k_axis_mean(const T* __restrict__ in, flo
   for (; s + 7 <= inner; s += 7) {  // 7 independent 16-B loads in flight (P = 49 = 7 * 7)
     float4 v[7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) v[j] = ld4(p + (int64_t)(s + j) * cols4 * 4);
+    for (int j = 0; j < 7; ++j) v[j] = ld4_stream(p + (int64_t)(s + j) * cols4 * 4);  // read once
 #pragma unroll
     for (int j = 0; j < 7; ++j) acc = acc + v[j];
   }
-  for (; s < inner; ++s) acc = acc + ld4(p + (int64_t)s * cols4 * 4);
+  for (; s < inner; ++s) acc = acc + ld4_stream(p + (int64_t)s * cols4 * 4);
   const float cnt = (float)inner;  // sum / count like torch.mean (a true division, not a reciprocal multiply)
   st4(out + g * (int64_t)cols4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / cnt, acc.y / cnt, acc.z / cnt, acc.w / cnt));
 }
@@ -135,11 +135,11 @@ __global__ void __launch_bounds__(256) k_entity_token_mean(const float* __restri
     for (; t + 8 <= stop; t += 8) {
       float4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = ld4(col + (int64_t)(t + j) * D4 * 4);
+      for (int j = 0; j < 8; ++j) v[j] = ld4_stream(col + (int64_t)(t + j) * D4 * 4);  // read once
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc = acc + v[j];
     }
-    for (; t < stop; ++t) acc = acc + ld4(col + (int64_t)t * D4 * 4);
+    for (; t < stop; ++t) acc = acc + ld4_stream(col + (int64_t)t * D4 * 4);
     const float den = n > 0 ? (float)n : 0.0f;  // empty slice: 0 / 0 = NaN, as the reference
     st4(out + p * (int64_t)D4 * 4 + (int64_t)c4 * 4, make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den));
   }

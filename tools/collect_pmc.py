@@ -28,4 +28,4 @@ for k in sorted(set(fetch) | set(write)):
 json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean per launch",
            "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (defaults: wikimel B=4096 bf16x3 fused)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out.get("void drin::k_entity_stream<3, 8, true>", {}), indent=1))
+print(json.dumps({k: v for k, v in out.items() if "k_entity_stream" in k or "k_cached_pairs" in k}, indent=1))

@@ -133,8 +133,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
                   int64_t ldc, int64_t M, int N, int K, int accumulate) {
   using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware tile order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with
+  // its own L2; the column tiles of one row tile stream the same A rows, so XCD x takes a contiguous range of the
+  // tile sequence (column index fastest) and A comes from HBM once instead of once per column tile.
+  int64_t m0;
+  int n0;
+  {
+    const unsigned nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = id & 7, k = id >> 3, q = nwg >> 3, rem = nwg & 7;
+    const unsigned t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;  // measured: -1.4 % on x_i C_i^T
+    n0 = (int)(t % gridDim.x) * BN;
+    m0 = (int64_t)(t / gridDim.x) * BM;
+  }
   const int nkb = K / BK;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;

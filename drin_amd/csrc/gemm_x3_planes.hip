@@ -42,19 +42,23 @@ __device__ __forceinline__ void tile_of_block(int& tile_x, int64_t& tile_y, int 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Wave w fills plane (w >> 1) of the tile, rows (w & 1) * 128 .. + 127: eight 16-row pieces.
+// Wave w fills plane (w >> 1) of the tile, rows (w & 1) * 128 .. + 127: eight 16-row pieces.  The per-lane source of
+// piece i is recomputed when it is issued (a handful of integer ops) instead of living in 16 VGPRs.
 struct Pieces {
-  const char* src[8];  // per-lane source of each piece at k-block 0
+  const char* base;   // plane base + this lane's logical 16-byte chunk
+  int64_t ld_bytes;   // row stride of the plane in bytes
+  int64_t row0, lim;  // first row of this lane's piece 0, number of valid rows
 };
 
-// A_LO = false: the A operand is exact in bf16 (features stored as bf16) - no lo plane is fetched (waves 2 and 3
-// issue nothing) and the lo x hi MFMA is dropped: two MFMAs per tile pair instead of three.
 template <bool A_LO>
 __device__ __forceinline__ void issue_piece(const Pieces& p, char* buf, int kb, int i) {
   const int wave = threadIdx.x >> 6;
   if (!A_LO && (wave >> 1) == 1) return;
   char* plane_base = buf + (wave >> 1) * PLANE_BYTES + (wave & 1) * 128 * 64;
-  __builtin_amdgcn_global_load_lds((gptr_t)(p.src[i] + (int64_t)kb * (BK * 2)), (lptr_t)(plane_base + i * 1024), 16, 0, 0);
+  int64_t g = p.row0 + 16 * i;
+  g = g < p.lim ? g : p.lim - 1;  // rows past the end re-read the last row: their products are never stored
+  __builtin_amdgcn_global_load_lds((gptr_t)(p.base + g * p.ld_bytes + (int64_t)kb * (BK * 2)), (lptr_t)(plane_base + i * 1024),
+                                   16, 0, 0);
 }
 template <bool A_LO>
 __device__ __forceinline__ void issue_tile(const Pieces& p, char* buf, int kb) {
@@ -82,19 +86,20 @@ __device__ __forceinline__ Pieces make_pieces(const __bf16* a_hi, const __bf16* 
   const int plane = wave >> 1;
   const __bf16* base = plane == 0 ? a_hi : plane == 1 ? a_lo : plane == 2 ? b_hi : b_lo;
   const int64_t ld = plane < 2 ? lda : ldb, r0 = plane < 2 ? m0 : n0, lim = plane < 2 ? M : N;
+  // the swizzle of row r is f((r >> 2) & 3); pieces are 16 rows apart, so it is the same for all eight: f(lane >> 4)
+  const int f = (0x78 >> (((lane >> 4) & 3) << 1)) & 3;
+  const int chunk = (lane & 3) ^ f;  // logical chunk whose bytes land in physical chunk lane & 3
   Pieces p;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (wave & 1) * 128 + i * 16 + (lane >> 2);
-    const int f = (0x78 >> (((row >> 2) & 3) << 1)) & 3;
-    const int chunk = (lane & 3) ^ f;  // logical chunk whose bytes land in physical chunk lane & 3
-    int64_t g = r0 + row;
-    g = g < lim ? g : lim - 1;
-    p.src[i] = reinterpret_cast<const char*>(base + g * ld) + chunk * 16;
-  }
+  p.base = reinterpret_cast<const char*>(base) + chunk * 16;
+  p.ld_bytes = ld * 2;
+  p.row0 = r0 + (wave & 1) * 128 + (lane >> 2);
+  p.lim = lim;
   return p;
 }
 
+// (Tried: weight fragments fetched straight into registers by global_load_dwordx4 - a lane's fragment of the
+// K-contiguous planes is 16 contiguous bytes - so that the weights never touch LDS: 291 vs 346 TF/s on the same box.
+// The K-loop is not LDS-bound; the extra vector-memory traffic costs more than the LDS traffic it removes.)
 template <bool A_LO>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,

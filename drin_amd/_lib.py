@@ -17,7 +17,6 @@ MAX_LAYERS = 8
 ABI_VERSION = 1
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
-FEAT_F32, FEAT_BF16 = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
 FEAT_F32, FEAT_BF16 = 0, 1
 

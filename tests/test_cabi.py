@@ -87,3 +87,11 @@ def test_loss_entry_point_validates_on_host():
     ks[1] = 5
     assert lib.drin_triplet_topk(None, one, 4, 11, 0.25, ks, 2, one, None, one, one, 4096, None) == _lib.E_NULL
     assert lib.drin_triplet_topk(one, one, 4, 11, 0.25, ks, 2, one, None, one, one, 8, None) == _lib.E_WORKSPACE
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU / eager fallback: without the built .so the binding raises and names the build command."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libdrin_hip.so"))
+    with pytest.raises(ImportError, match="no fallback"):
+        _lib.load()

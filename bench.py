@@ -134,13 +134,16 @@ def cpu_baseline(cfg, sd, seconds=12.0):
 def bench_train(args, cfg, model, dev, world, rank, B, barrier):
     """One optimisation step of train.py:30-56 per "step": forward (intermediates kept), TripletLoss, backward
     through the HIP kernels, one RCCL all-reduce of the flat gradient bucket (world > 1), Adam."""
-    from drin_amd.metrics import TripletLoss
+    from drin_amd.metrics import DeviceLossMetric
     from drin_amd.train import GradBucket
 
     model.train()
     full = synth.make_device_batch(cfg, B, 200 + rank, dev)
     batch, y = full[:14], full[14]
-    loss_fn = TripletLoss(cfg.triplet_margin)
+    loss_fn = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk, dev)   # loss + top-k counters in one library call, as MELRunner
+    if args.torch_loss:
+        from drin_amd.metrics import TripletLoss
+        loss_fn = TripletLoss(cfg.triplet_margin)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=args.graph)
     bucket = GradBucket(list(model.parameters()))
 
@@ -230,6 +233,7 @@ def main():
                          "gradient all-reduce + Adam step (BASELINE configs 3-4), reported under the same unit")
     ap.add_argument("--graph", action="store_true",
                     help="train mode: capture the whole step (forward, loss, backward, Adam) in one hipGraph and replay it")
+    ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -449,10 +449,12 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   // VertexEncoder (model.py:26-46): four Linears
   float* vm0 = ws + L.vm[0];
   float* ve0 = ws + L.ve[0];
+  float* const sk = L.splitk_floats ? ws + L.splitk : nullptr;  // split-K scratch of the mention-sized products
+  const size_t skf = L.splitk_floats;
   DRIN_TRY(launch_gemm_nt(P.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false,
-                          prec, st));
+                          prec, st, sk, skf));
   DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
-                          D, B, D, R, false, prec, st));
+                          D, B, D, R, false, prec, st, sk, skf));
   DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
                           prec, st));
   DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
@@ -501,7 +503,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     // shared W_h + LayerNorm + GELU for all vertex types of the layer (model.py:128)
     float* h_m = ws + L.h_m[l];
     float* h_e = ws + L.h_e[l];
-    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st));
+    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, sk, skf));
     DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st));
     float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
     float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
@@ -517,7 +519,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
       float* fv = ws + L.fv[l];
       float* pre = ws + L.pre[l];
       const int H = D / 2;
-      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, H, 2 * (int64_t)B, H, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, H, 2 * (int64_t)B, H, D, false, prec, st, sk, skf));
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, H, 2 * M, H, D, false, prec, st));
       DRIN_TRY(launch_edge_pre_vec(fu, fv, e, pre, B, N, D, st));
       DRIN_TRY(launch_gemm_nt(pre, D, W.w_m, D, W.b_m, e_next, D, 4 * M, D, D, false, prec, st));
@@ -525,7 +527,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
-      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, sk, skf));
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st));
       for (int k = 0; k < 4; ++k) {
         const float* fuk = fu + (size_t)(k >> 1) * B * D;
@@ -679,7 +681,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));
       return launch_gemm_nt_bf16x3(dy, lddy, wt, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate);
     }
-    return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st);
+    return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st,
+                          L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
   };
 
   // score = cos(mt_L, et_L) (model.py:207-209)

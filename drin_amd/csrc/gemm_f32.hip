@@ -96,14 +96,14 @@ __device__ __forceinline__ float4 read_frag(const float* __restrict__ lds, int r
   }
 }
 
-enum : int { GEMM_ACCUMULATE = 1, GEMM_ATOMIC = 2 };
+enum : int { GEMM_ACCUMULATE = 1, GEMM_ATOMIC = 2, GEMM_PARTIAL = 4 };  // PARTIAL: split z writes its tile to C + z * part_stride
 
 // BM x BN output tile (128 or 64 each): 4 waves as 2 x 2, each wave (BM/2) x (BN/2)
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
 __global__ void __launch_bounds__(256, 2)
     k_gemm_f32(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
                const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-               int k_per_split, int flags) {
+               int k_per_split, int flags, int64_t part_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TA = Tile<BM>::FLOATS, TB = Tile<BN>::FLOATS, TBUF = TA + TB;  // buffer c: A at c*TBUF, B after it
   constexpr int MI = BM / 64, NI = BN / 64;                                   // MFMA tiles per wave
@@ -185,7 +185,9 @@ __global__ void __launch_bounds__(256, 2)
         if (row >= M) continue;
         float* dst = C + row * ldc + col;
         const float val = acc[i][j][v] + bv;
-        if (flags & GEMM_ATOMIC) {
+        if (flags & GEMM_PARTIAL) {
+          dst[(int64_t)blockIdx.z * part_stride] = acc[i][j][v];  // bias is added by the reduction
+        } else if (flags & GEMM_ATOMIC) {
           atomicAdd(dst, val);
         } else if (flags & GEMM_ACCUMULATE) {
           *dst += val;
@@ -198,7 +200,8 @@ __global__ void __launch_bounds__(256, 2)
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
 static int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
-                  int64_t M, int N, int K, int splits, int flags, hipStream_t st, const char* what) {
+                  int64_t M, int N, int K, int splits, int flags, hipStream_t st, const char* what,
+                  int64_t part_stride = 0, int* splits_used = nullptr) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   const int64_t mt = cdiv(M, BM);
   if (mt > 65535) {
@@ -217,6 +220,7 @@ static int launch(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     splits = 1;
   }
   if (K <= 0) splits = 1;
+  if (splits_used) *splits_used = splits;
   const size_t lds = sizeof(float) * 2 * (Tile<BM>::FLOATS + Tile<BN>::FLOATS);
   static bool attr_done = false;  // one flag per template instantiation
   auto kern = k_gemm_f32<BM, BN, A_KMAJOR, B_KMAJOR>;
@@ -228,7 +232,7 @@ static int launch(const float* A, int64_t lda, const float* B, int64_t ldb, cons
   }
   dim3 grid((unsigned)cdiv(N, BN), (unsigned)mt, (unsigned)splits);
   KernelTimer timer(DRIN_KC_GEMM, st);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kps, flags);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kps, flags, part_stride);
   DRIN_CHECK_LAUNCH(what);
   return DRIN_OK;
 }
@@ -241,8 +245,50 @@ static int check_precision(int precision, const char* what) {
   return DRIN_OK;
 }
 
+// y[m, n] (+)= bias[n] + sum_z partial[z][m][n], slices added in order (deterministic split-K of the mention-sized
+// products: a 128-row problem has 24 output tiles and a serial K loop of 24 .. 64 stages - latency, not work)
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int splits, int64_t part_stride,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
+                                                       int64_t M, int N4, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * N4) return;
+  const int64_t m = i / N4;
+  const int c4 = (int)(i - m * N4);
+  const int64_t off = m * (int64_t)N4 * 4 + (int64_t)c4 * 4;
+  float4 s = bias != nullptr ? ld4(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < splits; ++z) s = s + ld4(partial + z * part_stride + off);
+  float* dst = y + m * ldy + c4 * 4;
+  if (accumulate) s = s + ld4(dst);
+  st4(dst, s);
+}
+
+// mention-sized fp32 products with a long reduction: split K over workgroups into `scratch`, then reduce in order
+template <bool B_KMAJOR>
+static int launch_small_splitk(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+                               int64_t ldy, int64_t M, int N, int K, bool accumulate, float* scratch, size_t scratch_floats,
+                               hipStream_t st, const char* what) {
+  int splits = K / 128;  // >= 4 stages of 32 per slice
+  if (splits > 8) splits = 8;
+  while (splits > 1 && (size_t)splits * M * N > scratch_floats) --splits;
+  const int64_t part_stride = M * (int64_t)N;
+  int used = 1;
+  DRIN_TRY((launch<64, 64, false, B_KMAJOR>(x, ldx, w, ldw, nullptr, scratch, N, M, N, K, splits, GEMM_PARTIAL, st, what,
+                                            part_stride, &used)));
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, st, scratch, used, part_stride,
+                     bias, y, ldy, M, N / 4, accumulate ? 1 : 0);
+  DRIN_CHECK_LAUNCH("k_splitk_reduce");
+  return DRIN_OK;
+}
+
+static bool small_splitk_fits(int64_t M, int N, int K, int64_t ldy, const float* y, float* scratch, size_t scratch_floats) {
+  return scratch != nullptr && M <= 512 && K >= 512 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && aligned16(scratch) &&
+         scratch_floats >= (size_t)2 * M * N;
+}
+
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
-                   int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st) {
+                   int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st, float* splitk,
+                   size_t splitk_floats) {
   // split-bf16 contraction for the pair-sized GEMMs; the mention-sized ones (a few hundred rows) stay on
   // the exact fp32 kernel: they are latency-bound, not rate-bound
   if (!accumulate && ((precision == DRIN_PREC_BF16X3 && M >= 256) || precision == DRIN_PREC_BF16X3_ALL))
@@ -253,6 +299,8 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
     set_error("gemm_nt: K=%d must be a multiple of 4", K);
     return DRIN_E_SHAPE;
   }
+  if (small_splitk_fits(M, N, K, ldy, y, splitk, splitk_floats))
+    return launch_small_splitk<false>(x, ldx, w, ldw, bias, y, ldy, M, N, K, accumulate, splitk, splitk_floats, st, "gemm_nt");
   // mention-sized problems (a few hundred rows): 64 x 64 tiles give 4x the workgroups of 128 x 128 and
   // keep more of the chip busy on what is a latency-bound launch
   if (M <= 2048)
@@ -263,7 +311,7 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 }
 
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
-                   int K, bool accumulate, int precision, hipStream_t st) {
+                   int K, bool accumulate, int precision, hipStream_t st, float* splitk, size_t splitk_floats) {
   // y[m, n] = sum_k x[m, k] * w[k, n]: b(n, k) = w[k * ldw + n] is k-major
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) precision = DRIN_PREC_F32;  // backward stays exact fp32
   DRIN_TRY(check_precision(precision, "gemm_nn"));
@@ -271,6 +319,8 @@ int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, flo
     set_error("gemm_nn: K=%d and N=%d must be multiples of 4", K, N);
     return DRIN_E_SHAPE;
   }
+  if (small_splitk_fits(M, N, K, ldy, y, splitk, splitk_floats))
+    return launch_small_splitk<true>(x, ldx, w, ldw, nullptr, y, ldy, M, N, K, accumulate, splitk, splitk_floats, st, "gemm_nn");
   if (M <= 2048)
     return launch<64, 64, false, true>(x, ldx, w, ldw, nullptr, y, ldy, M, N, K, 1, accumulate ? GEMM_ACCUMULATE : 0, st,
                                        "gemm_nn");
@@ -296,6 +346,14 @@ int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, flo
   if (M > 0x7fffffff) {
     set_error("gemm_tn: reduction length %lld too large", (long long)M);
     return DRIN_E_SHAPE;
+  }
+  if (M <= 2048) {
+    // mention-sized reductions (a few hundred rows): the work is the epilogue; 64 x 64 tiles spread its atomics
+    // over 4x the workgroups
+    int s64 = (int)cdiv(M, 4 * BK);
+    if (s64 > 4) s64 = 4;
+    return launch<64, 64, true, true>(a, lda, b, ldb, nullptr, y, ldy, /*M=*/N, /*N=*/K, /*K=*/(int)M, s64 < 1 ? 1 : s64,
+                                      GEMM_ATOMIC, st, "gemm_tn");
   }
   const int64_t tiles = cdiv(N, 128) * cdiv(K, 128);
   int splits = (int)cdiv(1024, tiles);                 // aim at ~4 workgroups per CU

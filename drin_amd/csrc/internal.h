@@ -59,8 +59,11 @@ int launch_scale_div(const float* in, float* out, int64_t n, float mul, float di
 
 // ---- GEMM (gemm_f32.hip) ------------------------------------------------------------------------
 // y[m, n] (+)= sum_k x[m, k] * w[n, k] + bias[n];  x row stride ldx, w row stride ldw, y row stride ldy
+// (splitk: optional scratch; mention-sized exact-fp32 products with K >= 512 then split K over workgroups into it
+//  and reduce in order - deterministic - instead of walking K serially in 24 tiles)
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
-                   int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st);
+                   int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st, float* splitk = nullptr,
+                   size_t splitk_floats = 0);
 // same contraction, operands split into bf16 hi + lo, three bf16 MFMAs, fp32 accumulate (gemm_bf16x3.hip)
 // (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
@@ -79,7 +82,7 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
 int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream_t st);
 // y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
-                   int K, bool accumulate, int precision, hipStream_t st);
+                   int K, bool accumulate, int precision, hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
 // y[n, k] += sum_m a[m, n] * b[m, k]          (used by backward: dW = dY^T * X), split over m
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
                    int K, int precision, hipStream_t st);

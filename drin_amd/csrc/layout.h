@@ -40,6 +40,7 @@ struct Layout {
   size_t fv[DRIN_MAX_LAYERS] = {};          // [2][M][D]  W_v(et), W_v(ei)
   size_t edges_scalar = 0;                  // [4][M]     scalar static edges before model.py:202 expands them (vector edges)
   size_t pre[DRIN_MAX_LAYERS] = {};         // [4][M][D]  W_m input cat(fu, fv) + e (vector edges)
+  size_t splitk = 0, splitk_floats = 0;     // split-K partials of the mention-sized exact-fp32 products (small batches only)
   size_t ln_part = 0;                       // [1024 + 16][3][D] per-block column sums of the LayerNorm backward and their first reduction level
   size_t wt = 0;                            // [D][D] transposed weight of the backward product in flight (split-bf16 dX = dY W)
   size_t bwd_scratch = 0;                   // backward temporaries (training only)
@@ -65,6 +66,8 @@ struct Layout {
     eobj_pool = take(c.entity_object_inner > 1 ? M * c.entity_objects * R : 0);
     eimg_pool = take(c.entity_image_inner > 1 ? M * R : 0);
     xet_pool = take(c.entity_tokens > 0 ? M * D : 0);
+    splitk_floats = 2 * B <= 512 ? 8 * 2 * B * D : 0;
+    splitk = take(splitk_floats);
     if (train) {
       for (int l = 0; l <= nl; ++l) {
         edges[l] = take(4 * M * EW);

@@ -212,7 +212,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps (default 3; 30 in train mode: a 10 ms step needs ~0.3 s before the clocks have ramped - "
+                         "the first run after an idle or lightly loaded GPU otherwise measures 15 instead of 9.3 ms at batch 512)")
     ap.add_argument("--workload", default="wikimel", choices=["wikimel", "wikidiverse", "table"],
                     help="wikimel: 100-cand token-level (headline); wikidiverse: 10-cand pooled; table: BASELINE config 5 - "
                          "1000 candidates per mention gathered on the device from a table of --entities random entities")
@@ -236,6 +238,8 @@ def main():
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.warmup is None:
+        args.warmup = 30 if args.mode == "train" else 3
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -76,7 +76,7 @@ EXPORTS = {
     "drin_pool_fwd": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drin_linear_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "drin_linear_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_forward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                C.c_size_t, C.c_void_p, C.c_int, C.POINTER(DrinTraceC), C.c_void_p]),
     "drin_backward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,

@@ -374,7 +374,7 @@ int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 }
 
 int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t rows,
-                    int32_t n_out, int32_t k, int32_t precision, float* scratch, void* stream) {
+                    int32_t n_out, int32_t k, int32_t precision, float* scratch, size_t scratch_floats, void* stream) {
   if (!dy || (dx && !w) || (dw && !x)) {
     set_error("drin_linear_bwd: NULL operand");
     return DRIN_E_NULL;
@@ -388,14 +388,14 @@ int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, 
   const bool x3 = precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL;
   if (dx) {
     // the contraction index of dx = dy W is n: the NT kernel needs W^T [k][n_out]
-    if (x3 && scratch && rows >= 1024 && (n_out % 32) == 0 && (k % 4) == 0) {
+    if (x3 && scratch && scratch_floats >= (size_t)n_out * k && rows >= 1024 && (n_out % 32) == 0 && (k % 4) == 0) {
       DRIN_TRY(launch_transpose(w, scratch, n_out, k, st));
       DRIN_TRY(launch_gemm_nt_bf16x3(dy, n_out, scratch, n_out, nullptr, dx, k, rows, k, n_out, st));
     } else {
       DRIN_TRY(launch_gemm_nn(dy, n_out, w, k, dx, k, rows, k, n_out, false, precision, st));
     }
   }
-  if (dw) DRIN_TRY(launch_gemm_tn(dy, n_out, x, k, dw, k, rows, n_out, k, precision, st));
+  if (dw) DRIN_TRY(launch_gemm_tn(dy, n_out, x, k, dw, k, rows, n_out, k, precision, st, scratch, scratch ? scratch_floats : 0));
   if (db) DRIN_TRY(launch_colsum(dy, db, rows, n_out, st));
   return DRIN_OK;
 }
@@ -669,6 +669,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   bool all_enabled = true;
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
 
+  float* const tnp = L.tn_part_floats ? ws + L.tn_part : nullptr;  // partial tiles of the split-bf16 dW products
+  const size_t tnf = L.tn_part_floats;
   // dX (+)= dY W.  Pair-sized products in split-bf16 precision run on the NT kernel against W^T, transposed into
   // workspace scratch right before use (a D x D transpose is ~3 us; the product it feeds is 2.5x faster than
   // the exact-fp32 MFMA one); everything else takes the exact fp32 NN kernel.
@@ -708,8 +710,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
                                        G.ln_bias, G.b_h, ws + L.ln_part, (int64_t)types * M, D, st));
     // (b) dW_h += dH^T A
     if (G.w_h) {
-      DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st));
-      DRIN_TRY(launch_gemm_tn(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D, prec, st));
+      DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st, tnp, tnf));
+      DRIN_TRY(launch_gemm_tn(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D, prec, st, tnp, tnf));
     }
     // (c) dA = dH W_h
     DRIN_TRY(gemm_nn(gm, D, W.w_h, dA_m, D, (int64_t)types * B, D, D, false));
@@ -730,13 +732,13 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       // (d, vector edges) e' = sigmoid(W_m(cat(W_u(u), W_v(v)) + e) + b_m)  (model.py:150-152,133)
       const int H = D / 2;
       DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st));         // dz
-      if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st));
+      if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st));
       DRIN_TRY(gemm_nn(dpre, D, W.w_m, g_e[cur], D, 4 * (int64_t)M, D, D, false));  // d(cat + e)
       DRIN_TRY(launch_edge_pre_vec_bwd(g_e[cur], dfu, dfv, B, N, D, st));
-      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, H, et, D, G.w_v, D, 2 * (int64_t)M, H, D, prec, st));
+      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, H, et, D, G.w_v, D, 2 * (int64_t)M, H, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, H, st));
-      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, H, mt, D, G.w_u, D, 2 * (int64_t)B, H, D, prec, st));
+      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, H, mt, D, G.w_u, D, 2 * (int64_t)B, H, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, H, st));
       de_extra = g_e[cur];
     } else if (edge_update) {
@@ -751,9 +753,9 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
       DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
       DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
-      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, prec, st));
+      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, D, st));
-      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st));
+      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, D, st));
       de_extra = dpre;
     } else if (!cfg->dynamic_edges && have_edge) {
@@ -789,14 +791,14 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   const float* g_mi = g_vm[cur] + BD;
   const float* g_et = g_ve[cur];
   const float* g_ei = g_ve[cur] + MD;
-  if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st));
+  if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st, tnp, tnf));
   DRIN_TRY(launch_colsum(g_mt, grads->b_mention_text, B, D, st));
-  if (grads->w_entity_text) DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st));
+  if (grads->w_entity_text) DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st, tnp, tnf));
   DRIN_TRY(launch_colsum(g_et, grads->b_entity_text, (int64_t)M, D, st));
   if (have_image) {
-    if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st));
+    if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st, tnp, tnf));
     DRIN_TRY(launch_colsum(g_mi, grads->b_mention_image, B, D, st));
-    if (grads->w_entity_image) DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st));
+    if (grads->w_entity_image) DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st, tnp, tnf));
     DRIN_TRY(launch_colsum(g_ei, grads->b_entity_image, (int64_t)M, D, st));
   }
   return DRIN_OK;

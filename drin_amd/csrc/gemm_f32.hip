@@ -329,13 +329,14 @@ int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, flo
 }
 
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
-                   int K, int precision, hipStream_t st) {
+                   int K, int precision, hipStream_t st, float* scratch, size_t scratch_floats) {
   // y[n, k] += sum_m a[m, n] * b[m, k]: both operands k-major over the reduction index m.
   // The reduction runs over all B*N pairs while the output is one weight matrix, so it is split over
   // m and the slices are combined with fp32 atomics (the caller's gradient buffer is the accumulator).
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) {
     // pair-sized weight gradients: split-bf16 MFMA (gemm_tn_bf16x3.hip); mention-sized ones stay exact fp32
-    if (gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b)) return launch_gemm_tn_bf16x3(a, lda, b, ldb, y, ldy, M, N, K, st);
+    if (gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b))
+      return launch_gemm_tn_bf16x3(a, lda, b, ldb, y, ldy, M, N, K, st, scratch, scratch_floats);
     precision = DRIN_PREC_F32;
   }
   DRIN_TRY(check_precision(precision, "gemm_tn"));

@@ -14,8 +14,11 @@
 // 16-byte chunk index is XORed with (p & 3) so that the 16 rows of a fragment read (4 row residues x 4
 // physical neighbours) fall on 16 distinct bank quads.
 //
-// The reduction is split over workgroups (M is 10^4 .. 10^5, the output has 9 .. 24 tiles of 256 x 256); partial
-// tiles are added to y with fp32 atomics, like the exact-fp32 kernel of gemm_f32.hip.
+// The reduction is split over workgroups (M is 10^4 .. 10^5, the output has 9 .. 24 tiles of 256 x 256).  With
+// caller scratch each slice stores its partial tile plainly and k_tn_reduce adds the slices to y in order
+// (deterministic); without it the tiles are added to y with fp32 atomics like the exact-fp32 kernel of
+// gemm_f32.hip - 65 536 atomics per workgroup cost ~50 us whatever the slice length (MI355X_MICROARCH.md: one
+// 256-byte atomic wave-instruction per ~50 ns per CU), more than the MFMA work at M ~ 10^4.
 #include "device_utils.h"
 #include "internal.h"
 
@@ -88,7 +91,8 @@ struct TransposeStager {
 // grid: x = output tile (n-tile major), y = slice of the reduction
 __global__ void __launch_bounds__(THREADS, 1)
     k_gemm_tn_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
-                     float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, int64_t rows_per_slice, int k_tiles) {
+                     float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, int64_t rows_per_slice, int k_tiles,
+                     float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n0 = (blockIdx.x / k_tiles) * TILE, k0 = (blockIdx.x % k_tiles) * TILE;
   const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
@@ -177,9 +181,32 @@ __global__ void __launch_bounds__(THREADS, 1)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int nrow = n0 + wm * 128 + i * 16 + c * 4 + v;
-        if (nrow < N) unsafeAtomicAdd(Y + (int64_t)nrow * ldy + kcol, acc[i][j][v]);
+        if (nrow >= N) continue;
+        if (partial != nullptr)
+          partial[((int64_t)blockIdx.y * N + nrow) * K + kcol] = acc[i][j][v];
+        else
+          unsafeAtomicAdd(Y + (int64_t)nrow * ldy + kcol, acc[i][j][v]);
       }
     }
+}
+
+// y[n, k] += sum_slices partial[slice][n][k], slices in order
+__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ partial, int slices, float* __restrict__ Y,
+                                                   int64_t ldy, int N, int K4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * K4) return;
+  const int n = (int)(i / K4), c4 = (int)(i - (int64_t)n * K4);
+  const int64_t stride = (int64_t)N * K4 * 4;
+  const float* p = partial + (int64_t)n * K4 * 4 + (int64_t)c4 * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  int z = 0;
+  for (; z + 2 <= slices; z += 2) {  // two chains, fixed association
+    s0 = s0 + ld4(p + z * stride);
+    s1 = s1 + ld4(p + (z + 1) * stride);
+  }
+  if (z < slices) s0 = s0 + ld4(p + z * stride);
+  float* dst = Y + (int64_t)n * ldy + c4 * 4;
+  st4(dst, ld4(dst) + (s0 + s1));
 }
 
 }  // namespace x3tn
@@ -190,7 +217,7 @@ bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, cons
 }
 
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
-                          int N, int K, hipStream_t st) {
+                          int N, int K, hipStream_t st, float* scratch, size_t scratch_floats) {
   if (M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
   if (!gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b)) {
     set_error("gemm_tn_bf16x3: shape M=%lld N=%d K=%d / alignment outside the kernel's contract", (long long)M, N, K);
@@ -216,10 +243,17 @@ int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t l
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_tn_bf16x3)");
     attr_done = true;
   }
+  const bool two_stage = scratch != nullptr && slices > 1 && (size_t)slices * N * K <= scratch_floats && (ldy % 4) == 0 &&
+                         aligned16(y) && aligned16(scratch);
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS), x3tn::LDS_BYTES,
-                     st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles);
+                     st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles, two_stage ? scratch : (float*)nullptr);
   DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
+  if (two_stage) {
+    hipLaunchKernelGGL(x3tn::k_tn_reduce, dim3((unsigned)cdiv((int64_t)N * (K / 4), 256)), dim3(256), 0, st, scratch, (int)slices,
+                       y, ldy, N, K / 4);
+    DRIN_CHECK_LAUNCH("k_tn_reduce");
+  }
   return DRIN_OK;
 }
 

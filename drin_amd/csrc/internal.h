@@ -72,8 +72,10 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
 bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, const void* a, const void* b);
+// (scratch: optional [slices][N][K] floats - the slices then store plainly and are reduced in order instead of
+//  adding to y with atomics)
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
-                          int N, int K, hipStream_t st);
+                          int N, int K, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
@@ -85,7 +87,7 @@ int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, flo
                    int K, bool accumulate, int precision, hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
 // y[n, k] += sum_m a[m, n] * b[m, k]          (used by backward: dW = dY^T * X), split over m
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
-                   int K, int precision, hipStream_t st);
+                   int K, int precision, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
 
 // ---- GCN elementwise / reduction kernels (gcn_kernels.hip) --------------------------------------
 // model.py:143-144 + :128 input: out[b,:] = mean_n(e1[b,n] v1[b,n,:]) + mean_n(e2[b,n] v2[b,n,:]) + u[b,:]

@@ -41,6 +41,7 @@ struct Layout {
   size_t edges_scalar = 0;                  // [4][M]     scalar static edges before model.py:202 expands them (vector edges)
   size_t pre[DRIN_MAX_LAYERS] = {};         // [4][M][D]  W_m input cat(fu, fv) + e (vector edges)
   size_t splitk = 0, splitk_floats = 0;     // split-K partials of the mention-sized exact-fp32 products (small batches only)
+  size_t tn_part = 0, tn_part_floats = 0;   // [slices][N][K] partial tiles of the split-bf16 weight-gradient products
   size_t ln_part = 0;                       // [1024 + 16][3][D] per-block column sums of the LayerNorm backward and their first reduction level
   size_t wt = 0;                            // [D][D] transposed weight of the backward product in flight (split-bf16 dX = dY W)
   size_t bwd_scratch = 0;                   // backward temporaries (training only)
@@ -89,6 +90,12 @@ struct Layout {
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
       wt = take(D * D);
       ln_part = take((1024 + 16) * 3 * D);
+      {  // one workgroup per CU: 256 / tiles slices of the largest product (D x D: 9 tiles at 768; D x R: 24)
+        const size_t t_dd = ((D + 255) / 256) * ((D + 255) / 256), t_dr = ((D + 255) / 256) * ((R + 255) / 256);
+        const size_t s_dd = t_dd >= 256 ? 1 : 256 / t_dd, s_dr = t_dr >= 256 ? 1 : 256 / t_dr;
+        tn_part_floats = s_dd * D * D > s_dr * D * R ? s_dd * D * D : s_dr * D * R;
+        tn_part = take(tn_part_floats);
+      }
       bwd_scratch_floats = 4 * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
       bwd_scratch = take(bwd_scratch_floats);
     } else {

@@ -186,10 +186,13 @@ DRIN_API int drin_linear_fwd(const float* x, const float* w, const float* bias, 
  *   dx[m, k]  = sum_n dy[m, n] w[n, k]      (written; dx may be NULL)
  *   dw[n, k] += sum_m dy[m, n] x[m, k]      (accumulated; dw may be NULL)
  *   db[n]    += sum_m dy[m, n]              (accumulated; db may be NULL)
- * `scratch`: n_out * k floats for the transposed weight the split-bf16 dx product runs against; NULL keeps
- * dx on the exact fp32 kernel.  Small problems take the exact fp32 kernels in every precision. */
+ * `scratch` (`scratch_floats` floats, may be NULL / 0): n_out * k floats hold the transposed weight the split-bf16 dx
+ * product runs against (without them dx stays on the exact fp32 kernel); with at least 28 * n_out * k floats the
+ * split-bf16 dw product stores its reduction slices there and adds them in order (bit-reproducible) instead of
+ * using fp32 atomics.  Small problems take the exact fp32 kernels in every precision. */
 DRIN_API int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                             int64_t rows, int32_t n_out, int32_t k, int32_t precision, float* scratch, void* stream);
+                             int64_t rows, int32_t n_out, int32_t k, int32_t precision, float* scratch,
+                             size_t scratch_floats, void* stream);
 
 /* Model.forward (drin/model.py:164-209): scores[B, N] = cos(mt'', et'').
  * `keep_for_backward` != 0 lays the intermediates backward needs out in `workspace`, which must

@@ -100,7 +100,7 @@ def test_linear_planes_fwd(rows, n_out, k):
 
 @pytest.mark.parametrize("rows,n_out,k", [(70, 64, 64), (1500, 768, 768), (4133, 768, 2048), (2048, 384, 768), (3000, 200, 96),
                                           (1024, 128, 128), (9000, 768, 768)])
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_two_stage"])
 def test_linear_bwd(rows, n_out, k, precision):
     """dx = dy W, dW += dy^T x, db += colsum(dy) - exact fp32 MFMA and split-bf16 (transposing-stager kernel of
     gemm_tn_bf16x3.hip; NT kernel against W^T) - against float64 on the host; dW / db accumulate."""
@@ -109,19 +109,30 @@ def test_linear_bwd(rows, n_out, k, precision):
     dw0, db0 = torch.randn(n_out, k, generator=g), torch.randn(n_out, generator=g)
     xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
     dx, dw, db = torch.empty(rows, k, device=DEV), dw0.to(DEV), db0.to(DEV)
-    scratch = torch.empty(n_out * k, device=DEV)
-    prec = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3}[precision]
+    two_stage = precision == "bf16x3_two_stage"   # slices stored to scratch and added in order instead of atomics
+    scratch = torch.empty(n_out * k * (28 if two_stage else 1), device=DEV)
+    prec = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_two_stage": _lib.PREC_BF16X3}[precision]
     lib = _lib.load()
+
+    def run():
+        dw.copy_(dw0)
+        db.copy_(db0)
+        _lib.check(lib.drin_linear_bwd(xd.data_ptr(), wd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                       rows, n_out, k, prec, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream))
+
     _lib.profile_begin()
-    _lib.check(lib.drin_linear_bwd(xd.data_ptr(), wd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
-                                   rows, n_out, k, prec, scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    run()
     prof = _lib.profile_end()
-    big = precision == "bf16x3" and rows >= 1024 and n_out >= 128 and k >= 128
+    big = precision != "f32" and rows >= 1024 and n_out >= 128 and k >= 128
+    if two_stage and big:
+        first = dw.clone()
+        run()
+        assert torch.equal(first, dw), "the two-stage reduction is bit-reproducible"
     assert (prof["gemm_x3"][1] > 0) == big, prof
     ref_dx = (dy.double() @ w.double())
     ref_dw = dw0.double() + dy.double().t() @ x.double()
     ref_db = db0.double() + dy.double().sum(0)
-    tol = 2e-5 if precision == "bf16x3" else 5e-6
+    tol = 2e-5 if precision != "f32" else 5e-6
     for got, ref, scale in ((dx, ref_dx, (dy.abs().double() @ w.abs().double())), (dw, ref_dw, dy.abs().double().t() @ x.abs().double()),
                             (db, ref_db, dy.abs().double().sum(0))):
         err = ((got.cpu().double() - ref).abs() / (scale + 1e-30)).max().item()

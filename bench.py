@@ -108,13 +108,28 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("DRIN_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg, sd, seconds=12.0):
+def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None):
+    """The CPU oracle timed on the host cores this process may use; with `model`, the same sample batches are also
+    scored by the HIP path and compared (max |score error|, top-1 agreement) - the checker, never the thing measured."""
     from oracle import drin_oracle as O
 
     cores = host_cores()
     torch.set_num_threads(cores)
     B = 8 if cfg.token_level_entities else 64
     batch = synth.make_batch(cfg, B, 3)
+    parity = None
+    if model is not None:
+        err, agree, total = 0.0, 0, 0
+        with torch.no_grad():
+            for seed in range(3, 3 + (8 if cfg.token_level_entities else 2)):   # 64 / 128 mentions
+                b = synth.make_batch(cfg, B, seed)
+                ref = O.forward(sd, b)
+                got = model([t.to(dev) for t in b[:14]]).cpu()
+                err = max(err, (got - ref).abs().max().item())
+                agree += int((got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).sum())
+                total += B
+        parity = {"max_abs_score_err": err, "top1_agreement": agree / total, "mentions": total,
+                  "against": "CPU oracle (pinned to the reference by tests/golden), same synthetic inputs"}
     with torch.no_grad():
         O.forward(sd, batch)  # warm-up
         t0 = time.perf_counter()
@@ -126,9 +141,10 @@ def cpu_baseline(cfg, sd, seconds=12.0):
             if el >= seconds or it >= 2000:
                 break
     pairs = it * B * cfg.num_candidates_model
-    return {"value": pairs / el, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={cfg.num_candidates_model} fp32, "
-                      f"torch {torch.get_num_threads()} threads, {el:.1f} s"}
+    out = {"value": pairs / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={cfg.num_candidates_model} fp32, "
+                     f"torch {torch.get_num_threads()} threads, {el:.1f} s"}
+    return out, parity
 
 
 def bench_train(args, cfg, model, dev, world, rank, B, barrier):
@@ -382,7 +398,9 @@ def main():
                             "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(cfg, sd, model=model if args.workload != "table" else None, dev=dev)
+            if line["parity"] is None:
+                del line["parity"]
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) k_mention_layer1_cached(const float* __re
 }
 
 struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats
-  size_t span_mean, mimg, vm0, hmfu, e1m, c_part, s2_part, vm1, hm2, agg2, mt2, et1, p_et1, h2, total;
+  size_t span_mean, mimg, vm0, hmfu, e1m, c_part, s2_part, vm1, hm2, agg2, mt2, et1, p_et1, h2, splitk, splitk_floats, total;
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
@@ -397,6 +397,8 @@ struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats
     et1 = take(planes ? 0 : M * D);
     p_et1 = take(planes ? M * D : 0);  // hi plane (M*D bf16) then lo plane
     h2 = take(M * D);
+    splitk_floats = 2 * B <= 512 ? 8 * 2 * B * 2 * D : 0;  // split-K partials of the mention-sized fp32 products
+    splitk = take(splitk_floats);
     total = off;
   }
 };
@@ -577,14 +579,16 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
     return DRIN_E_UNSUPPORTED;
   }
 
+  float* const sk = L.splitk_floats ? ws + L.splitk : nullptr;
+  const size_t skf = L.splitk_floats;
   // (1) mention-side pooling and vertex-encoder Linears, [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1]
   DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B, cfg->mention_tokens, D, st));
   DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
   float* vm0 = ws + L.vm0;
-  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, prec, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, prec, st, sk, skf));
+  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, prec, st, sk, skf));
   float* hmfu = ws + L.hmfu;
-  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st, sk, skf));
 
   // (2) one gathered pass over the cache rows: edges, layer-1 entity vertices, all cross-candidate sums
   CachedArgs a;
@@ -640,10 +644,10 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
     DRIN_CHECK_LAUNCH("k_mention_layer1_cached");
   }
   DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
-  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, prec, st, sk, skf));
   // (4) layer-2 mention-text vertex
   DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
-  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, prec, st));
+  DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, prec, st, sk, skf));
   DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
   // (5) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h2;

@@ -27,7 +27,7 @@ namespace drin {
 
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
-      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, total;
+      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, splitk, splitk_floats, total;
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
@@ -67,6 +67,9 @@ struct FusedLayout {  // workspace offsets in floats
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
     p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
+    // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
+    splitk_floats = 2 * B <= 512 ? 8 * 2 * B * (D + R) : 0;
+    splitk = take(splitk_floats);
     total = off;
   }
 };
@@ -266,7 +269,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
       const __bf16* hi = reinterpret_cast<const __bf16*>(pb + plane_off);
       return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, st, hi, hi + plane_elems);
     }
-    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, false, prec, st);
+    return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, false, prec, st,
+                          L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
   };
   const size_t DD = (size_t)D * D, DR = (size_t)D * R;
   // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears

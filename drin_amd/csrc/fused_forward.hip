@@ -236,8 +236,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   const bool planes = (prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL) && (D % 32 == 0) && (R % 32 == 0);
   const bool indexed = b->entity_index != nullptr;
   // The image rows are read in place by their contraction (fp32, split on the fly): writing 8 KB/pair of
-  // planes from the stream kernel costs it more (measured +0.3 ms at B = 1024) than the LDS-DMA kernel
-  // gains on that GEMM (-0.15 ms).  Only the table form, which has to gather the rows anyway, writes them.
+  // planes from the stream kernel costs it more (measured twice on one box: +1.0 ms at B = 4096) than the LDS-DMA
+  // kernel gains on that GEMM (-0.35 ms).  Only the table form, which has to gather the rows anyway, writes them.
   const bool xi_planes = planes && indexed;
   if (indexed && cfg->num_entities <= 0) {
     set_error("drin_forward_prepared: entity_index given but cfg.num_entities = %d", cfg->num_entities);

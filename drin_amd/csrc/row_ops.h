@@ -96,43 +96,7 @@ __device__ __forceinline__ float dot_row_lds(const Row<V>& a, const float* lds, 
   return s;
 }
 
-// LayerNorm + GELU of one row held in registers (model.py:128)
-template <int DV>
-__device__ __forceinline__ Row<DV> ln_gelu_row(const Row<DV>& h, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, int lane, int D4, float eps) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
-  const float inv_d = 1.0f / (float)(D4 * 4);
-  const float mu = wave_sum(s) * inv_d;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4) {
-      const float dx = h.v[j].x - mu, dy = h.v[j].y - mu, dz = h.v[j].z - mu, dw = h.v[j].w - mu;
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
-  Row<DV> y;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    const int c4 = lane + 64 * j;
-    if (c4 < D4) {
-      const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
-      y.v[j].x = gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
-      y.v[j].y = gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
-      y.v[j].z = gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
-      y.v[j].w = gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
-    } else {
-      y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  return y;
-}
-
-// The same with gamma / beta held in LDS (per-workgroup constants of the pair kernels)
+// LayerNorm + GELU of one row held in registers (model.py:128), gamma / beta in LDS (per-workgroup constants)
 template <int DV>
 __device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float* gamma, const float* beta, int lane,
                                                    int D4, float eps) {
@@ -183,16 +147,5 @@ __device__ __forceinline__ Row<DV> combine_rows_lds(const Row<DV>& base, float w
   }
   return r;
 }
-
-// out = base + w1 u1 + w2 u2 + c
-template <int DV>
-__device__ __forceinline__ Row<DV> combine_rows(const Row<DV>& base, float w1, const Row<DV>& u1, float w2,
-                                                const Row<DV>& u2, const Row<DV>& c) {
-  Row<DV> r;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) r.v[j] = fma4(w1, u1.v[j], fma4(w2, u2.v[j], base.v[j] + c.v[j]));
-  return r;
-}
-
 
 }  // namespace drin

@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--entity-cache", action="store_true",
                     help="table workload: score from the per-entity precompute cache (SURVEY.md 8f-2; built during warm-up)")
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 4096 wikimel / 16384 wikidiverse / 512 table)")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
                          "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
     ap.add_argument("--features", default="f32", choices=["f32", "bf16"],
@@ -340,7 +340,7 @@ def main():
         ms, launches = prof[dom]
         per_launch_ms = ms / max(launches, 1)
         fused = not args.generic and cfg.num_gcn_layers == 2
-        x3 = args.precision == "bf16x3"
+        x3 = args.precision in ("bf16x3", "bf16")
         flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
         bytes_pair = algorithmic_bytes_per_pair(cfg, batch)
         cached = args.workload == "table" and args.entity_cache
@@ -376,14 +376,15 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(launches),
                     "avg_launch_ms": per_launch_ms}
             if dom != "gemm":
-                roof["executed_bf16_tflops"] = 3 * achieved
-                roof["executed_frac"] = 3 * achieved / peak
+                passes = 1 if args.precision == "bf16" else 3
+                roof["executed_bf16_tflops"] = passes * achieved
+                roof["executed_frac"] = passes * achieved / peak
         value = pairs_per_step * world * args.steps / elapsed
         line = {
             "metric": "mention x candidate pairs scored/sec",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3" if x3 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{cfg.dataset_name}-shaped scoring forward: {N - 1}-cand (+1 answer slot), D={D}, R={R}, "
                                    f"L={cfg.max_mention_sentence_len}, P={cfg.resnet_num_region}"
                                    + (f", T={cfg.max_entity_attr_token_len} token-level entity text" if cfg.token_level_entities else ""),

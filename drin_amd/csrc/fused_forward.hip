@@ -63,7 +63,7 @@ struct FusedLayout {  // workspace offsets in floats
     s2_part = take(B * chunks * 2 * D);
     agg2 = take(B * D);
     mt2 = take(B * D);
-    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL;
+    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16;
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
     p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
@@ -228,7 +228,10 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
   const int64_t M = (int64_t)B * N;
   if (B == 0) return DRIN_OK;
-  const int prec = cfg->precision;
+  // DRIN_PREC_BF16: the three pair-sized contractions run one bf16 MFMA pass (operands rounded to bf16, no lo planes);
+  // everything mention-sized keeps the split-bf16 / exact-fp32 arithmetic of DRIN_PREC_BF16X3
+  const bool one_pass = cfg->precision == DRIN_PREC_BF16;
+  const int prec = one_pass ? (int)DRIN_PREC_BF16X3 : cfg->precision;
   const bool dyn = cfg->dynamic_edges != 0;
   const bool tokens = cfg->entity_tokens > 0;
   // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
@@ -319,10 +322,10 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   const bool xt_exact = bf16_feat && !tokens;
   if (planes) {
     sa.xt_hi = xt_hi;
-    sa.xt_lo = xt_exact ? nullptr : xt_hi + MD;
+    sa.xt_lo = (xt_exact || one_pass) ? nullptr : xt_hi + MD;
     if (xi_planes) {
       sa.xi_hi = xi_hi;
-      sa.xi_lo = bf16_feat ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
+      sa.xi_lo = (bf16_feat || one_pass) ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
     }
   }
   sa.e0m = ws + L.e0m;
@@ -360,17 +363,17 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
-    DRIN_TRY(launch_gemm_x3_planes(xt_hi, xt_exact ? nullptr : xt_hi + MD, D, ct, ct + (size_t)D * D, D, nullptr,
-                                   ws + L.h_text, D, M, D, D, st));
+    DRIN_TRY(launch_gemm_x3_planes(xt_hi, (xt_exact || one_pass) ? nullptr : xt_hi + MD, D, ct,
+                                   one_pass ? nullptr : ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st));
     if (xi_planes)
-      DRIN_TRY(launch_gemm_x3_planes(xi_hi, bf16_feat ? nullptr : xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr,
-                                     ws + L.h_image, D, M, D, R, st));
+      DRIN_TRY(launch_gemm_x3_planes(xi_hi, (bf16_feat || one_pass) ? nullptr : xi_hi + MR, R, ci,
+                                     one_pass ? nullptr : ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
     else if (bf16_feat)  // the bf16 image rows are read in place as the (only) plane of the A operand
-      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M,
-                                     D, R, st));
+      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, one_pass ? nullptr : ci + (size_t)D * R, R, nullptr,
+                                     ws + L.h_image, D, M, D, R, st));
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
-                                     ci + (size_t)D * R));
+                                     ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
@@ -392,7 +395,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   pa.et1 = planes ? nullptr : ws + L.et1;
   if (planes) {
     pa.et1_hi = e1_hi;
-    pa.et1_lo = e1_hi + MD;
+    pa.et1_lo = one_pass ? nullptr : e1_hi + MD;
   }
   pa.s2_part = ws + L.s2_part;
   pa.B = B;
@@ -409,7 +412,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   float* h2 = ws + L.h_text;
   if (planes) {
     const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
-    DRIN_TRY(launch_gemm_x3_planes(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, nullptr, h2, D, M, D, D, st));
+    DRIN_TRY(launch_gemm_x3_planes(e1_hi, one_pass ? nullptr : e1_hi + MD, D, w2, one_pass ? nullptr : w2 + (size_t)D * D, D,
+                                   nullptr, h2, D, M, D, D, st));
   } else {
     DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
   }

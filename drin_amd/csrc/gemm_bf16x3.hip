@@ -72,6 +72,7 @@ struct Stager {
     for (int i = 0; i < PASSES; ++i) v[i] = ld4(p[i] + k0);
   }
   // registers -> (hi plane, lo plane): float4 #c4 of a row is the 8-byte half (c4 & 1) of chunk c4 >> 1
+  template <bool WITH_LO = true>
   __device__ __forceinline__ void store(char* __restrict__ hi_plane, char* __restrict__ lo_plane) const {
     const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
 #pragma unroll
@@ -80,7 +81,7 @@ struct Stager {
       split4(v[i], hi, lo);
       const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
       *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
-      *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+      if (WITH_LO) *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
     }
   }
 };
@@ -109,11 +110,15 @@ struct PlaneDma {
       lds_off[i] = plane * ROWS * 64 + pr * 1024;
     }
   }
+  template <bool WITH_LO = true>
   __device__ __forceinline__ void issue(char* planes_base, int kb) const {
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i)
+    for (int i = 0; i < PIECES; ++i) {
+      if (!WITH_LO && (wave * PIECES + i) >= ROWS / 16) continue;  // second half of the pieces is the lo plane
       __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)kb * (BK * 2)), (lptr_t)(planes_base + lds_off[i]), 16,
                                        0, 0);
+    }
   }
 };
 
@@ -126,7 +131,8 @@ struct Cfg {
   static constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 16 x 16 MFMA tiles per wave
 };
 
-template <int BM, int BN, int WM, int WN, bool W_PLANES>
+// ONE_PASS (DRIN_PREC_BF16): operands rounded to bf16, hi x hi only - a third of the MFMAs, no lo planes staged.
+template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
 __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
                   const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
@@ -169,10 +175,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 
   sa.load(0);
   if (W_PLANES)
-    dma.issue(smem + 2 * G::A_PLANE, 0);
+    dma.template issue<!ONE_PASS>(smem + 2 * G::A_PLANE, 0);
   else
     sb.load(0);
-  sa.store(smem, smem + G::A_PLANE);
+  sa.template store<!ONE_PASS>(smem, smem + G::A_PLANE);
   if (!W_PLANES) sb.store(smem + 2 * G::A_PLANE, smem + 2 * G::A_PLANE + G::B_PLANE);
   if (nkb > 1) {  // tile 1 is in flight while tile 0 is computed
     sa.load(BK);
@@ -187,7 +193,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     for (int j = 0; j < G::NI; ++j) {
       const int off = swz(wn * (BN / WN) + j * 16 + r, c);
       bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + off);
-      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
+      if (!ONE_PASS) bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
     }
   };
   auto row_tiles = [&](const char* buf, int i0, int i1) {
@@ -196,11 +202,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
       if (i < i0 || i >= i1) continue;
       const int off = swz(wm * (BM / WM) + i * 16 + r, c);
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
+      bf16x8 al;
+      if (!ONE_PASS) al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
 #pragma unroll
       for (int j = 0; j < G::NI; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        if (!ONE_PASS) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
       }
     }
@@ -216,11 +225,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     const char* buf = smem + cur * G::BUF_BYTES;
     char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
     const bool more = kb + 1 < nkb;
-    if (W_PLANES && more) dma.issue(nb + 2 * G::A_PLANE, kb + 1);
+    if (W_PLANES && more) dma.template issue<!ONE_PASS>(nb + 2 * G::A_PLANE, kb + 1);
     load_b(buf);
     row_tiles(buf, 0, G::MI / 2);
     if (more) {
-      sa.store(nb, nb + G::A_PLANE);
+      sa.template store<!ONE_PASS>(nb, nb + G::A_PLANE);
       if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
       if (kb + 2 < nkb) {
         sa.load((kb + 2) * BK);
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool W_PLANES>
+template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
 static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
                   const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate) {
   using G = Cfg<BM, BN, WM, WN>;
@@ -258,7 +267,7 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
     set_error("gemm_bf16x3: %lld row tiles exceed the grid limit; split the batch", (long long)mt);
     return DRIN_E_SHAPE;
   }
-  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES>;
+  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES, ONE_PASS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -279,7 +288,7 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
 // w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo,
-                          bool accumulate) {
+                          bool accumulate, bool one_pass) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   if ((K % x3::BK) || K <= 0) {  // odd reduction lengths take the exact fp32 kernel (guarded loads)
     if (!w) {
@@ -296,6 +305,13 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   }
   // pair-sized problems: 256 x 256 tiles; anything that would not fill the chip with them: 64 x 128 tiles
   const bool big = cdiv(M, 256) * cdiv(N, 256) >= 192;
+  if (one_pass) {  // DRIN_PREC_BF16: pair-sized products on pre-split weight planes only
+    if (!planes || !big) {
+      set_error("gemm_bf16x3: the one-pass (plain bf16) variant is built for pair-sized problems on weight planes");
+      return DRIN_E_UNSUPPORTED;
+    }
+    return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
+  }
   if (big)
     return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate)
                   : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);

@@ -50,20 +50,22 @@ struct Pieces {
   int64_t row0, lim;  // first row of this lane's piece 0, number of valid rows
 };
 
-template <bool A_LO>
+// B_LO = false as well (DRIN_PREC_BF16): operands rounded to bf16, hi x hi only - one MFMA per tile pair.
+template <bool A_LO, bool B_LO>
 __device__ __forceinline__ void issue_piece(const Pieces& p, char* buf, int kb, int i) {
   const int wave = threadIdx.x >> 6;
   if (!A_LO && (wave >> 1) == 1) return;
+  if (!B_LO && (wave >> 1) == 3) return;
   char* plane_base = buf + (wave >> 1) * PLANE_BYTES + (wave & 1) * 128 * 64;
   int64_t g = p.row0 + 16 * i;
   g = g < p.lim ? g : p.lim - 1;  // rows past the end re-read the last row: their products are never stored
   __builtin_amdgcn_global_load_lds((gptr_t)(p.base + g * p.ld_bytes + (int64_t)kb * (BK * 2)), (lptr_t)(plane_base + i * 1024),
                                    16, 0, 0);
 }
-template <bool A_LO>
+template <bool A_LO, bool B_LO>
 __device__ __forceinline__ void issue_tile(const Pieces& p, char* buf, int kb) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) issue_piece<A_LO>(p, buf, kb, i);
+  for (int i = 0; i < 8; ++i) issue_piece<A_LO, B_LO>(p, buf, kb, i);
 }
 
 // MFMA shape: v_mfma_f32_16x16x32_bf16.  The wave tile 128 x 64 is 8 x 4 tiles of 16 x 16 and a whole K-block
@@ -100,7 +102,7 @@ __device__ __forceinline__ Pieces make_pieces(const __bf16* a_hi, const __bf16* 
 // (Tried: weight fragments fetched straight into registers by global_load_dwordx4 - a lane's fragment of the
 // K-contiguous planes is 16 contiguous bytes - so that the weights never touch LDS: 291 vs 346 TF/s on the same box.
 // The K-loop is not LDS-bound; the extra vector-memory traffic costs more than the LDS traffic it removes.)
-template <bool A_LO>
+template <bool A_LO, bool B_LO>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                        const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
@@ -124,8 +126,8 @@ __global__ void __launch_bounds__(THREADS, 2)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
-  const Pieces pieces = make_pieces(a_hi, A_LO ? a_lo : a_hi, lda, m0, M, b_hi, b_lo, ldb, n0, N);
-  issue_tile<A_LO>(pieces, smem, 0);
+  const Pieces pieces = make_pieces(a_hi, A_LO ? a_lo : a_hi, lda, m0, M, b_hi, B_LO ? b_lo : b_hi, ldb, n0, N);
+  issue_tile<A_LO, B_LO>(pieces, smem, 0);
   __syncthreads();
 
   for (int kb = 0; kb < nkb; ++kb) {
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     for (int j = 0; j < 4; ++j) {
       const int off = swz16(wn * 64 + j * 16 + r, c);
       bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * PLANE_BYTES + off);
-      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE_BYTES + off);
+      if (B_LO) bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE_BYTES + off);
     }
     {
       const int off = swz16(wm * 128 + r, c);
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {  // eight row tiles; the next one's fragments are read one stage ahead
-      if (more) issue_piece<A_LO>(pieces, nbuf, kb + 1, t);
+      if (more) issue_piece<A_LO, B_LO>(pieces, nbuf, kb + 1, t);
       if (t + 1 < 8) {
         const int off = swz16(wm * 128 + (t + 1) * 16 + r, c);
         ah[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + off);
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(THREADS, 2)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (A_LO) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1], bh[j], acc[t][j], 0, 0, 0);
-        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bl[j], acc[t][j], 0, 0, 0);
+        if (B_LO) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bl[j], acc[t][j], 0, 0, 0);
         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bh[j], acc[t][j], 0, 0, 0);
       }
     }
@@ -219,6 +221,11 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
                           hipStream_t st) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   const bool a_lo_plane = a_lo != nullptr;  // NULL: A is exact in bf16 (one plane, two MFMAs per tile pair)
+  const bool b_lo_plane = b_lo != nullptr;  // NULL too: plain bf16 contraction (DRIN_PREC_BF16), one MFMA
+  if (!b_lo_plane && a_lo_plane) {
+    set_error("gemm_x3_planes: a weight lo plane may only be dropped together with the activation lo plane");
+    return DRIN_E_UNSUPPORTED;
+  }
   if (K <= 0 || (K % x3p::BK) || (lda % 8) || (ldb % 8) || !aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) ||
       !aligned16(b_lo)) {
     set_error("gemm_x3_planes: K=%d must be a multiple of 32, leading dimensions multiples of 8, planes 16-byte aligned", K);
@@ -231,22 +238,27 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
   }
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3p::LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, x3p::LDS_BYTES);
+    hipError_t e = hipSuccess;
+    const void* kernels[3] = {reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<true, true>),
+                              reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, true>),
+                              reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, false>)};
+    for (const void* k : kernels)
+      if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, x3p::LDS_BYTES);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_x3_planes)");
     attr_done = true;
   }
   dim3 grid((unsigned)cdiv(N, x3p::BN), (unsigned)mt);
   KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
+  const __bf16 *ah = (const __bf16*)a_hi, *al = (const __bf16*)a_lo, *bh = (const __bf16*)b_hi, *bl = (const __bf16*)b_lo;
   if (a_lo_plane)
-    hipLaunchKernelGGL(x3p::k_gemm_x3_planes<true>, grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, (const __bf16*)a_hi,
-                       (const __bf16*)a_lo, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K);
+    hipLaunchKernelGGL((x3p::k_gemm_x3_planes<true, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh, bl,
+                       ldb, bias, y, ldy, M, N, K);
+  else if (b_lo_plane)
+    hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh, bl,
+                       ldb, bias, y, ldy, M, N, K);
   else
-    hipLaunchKernelGGL(x3p::k_gemm_x3_planes<false>, grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, (const __bf16*)a_hi,
-                       (const __bf16*)nullptr, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K);
+    hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, false>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
+                       bl, ldb, bias, y, ldy, M, N, K);
   DRIN_CHECK_LAUNCH("k_gemm_x3_planes");
   return DRIN_OK;
 }

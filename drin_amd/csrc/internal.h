@@ -68,7 +68,7 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 // (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi = nullptr,
-                          const void* w_lo = nullptr, bool accumulate = false);
+                          const void* w_lo = nullptr, bool accumulate = false, bool one_pass = false);
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
 bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, const void* a, const void* b);
@@ -77,6 +77,7 @@ bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, cons
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
                           int N, int K, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
+// (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
                           hipStream_t st);

@@ -356,13 +356,16 @@ class Model(nn.Module):
     """`model_module.Model()` of `train.py:136` (drin/model.py:156-162)."""
 
     def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "f32", fused: bool = True):
-        """`precision`: "f32" (exact fp32 MFMA) or "bf16x3" (split-bf16 MFMA, fp32-equivalent);
+        """`precision`: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16 MFMA, fp32-equivalent) or "bf16" (opt-in: the
+        pair-sized contractions of the fused inference path in ONE bf16 MFMA pass - score error ~6e-4, outside the
+        1e-4 bar; training and every other path then run "bf16x3");
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path."""
         super().__init__()
         self.cfg = cfg or DrinConfig()
         self.cfg.validate()
         self._prepared = _Prepared() if fused else None
-        self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL}[precision]
+        self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL,
+                          "bf16": _lib.PREC_BF16}[precision]
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 
@@ -372,7 +375,7 @@ class Model(nn.Module):
             # table form: inference gathers inside the stream kernel; everything else (training,
             # exact-fp32 precision, geometries off the fused path) gathers with torch indexing first
             inference = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
-            planes = self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL)
+            planes = self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16)
             t = batch.table
             if inference and self._prepared is not None and self.cfg.num_gcn_layers == 2 and (planes or t.cache_enabled):
                 seq = batch.mention + [t.text, t.mask, t.image, t.object, t.object_score,
@@ -380,7 +383,8 @@ class Model(nn.Module):
                 if t.cache_enabled and t.text.dtype == torch.bfloat16:
                     raise ValueError("the per-entity cache is built from fp32 tables; give EntityTable fp32 features")
                 # bf16-stored features are read in place by the fused path (never widened: the table is large)
-                call = _Call(self.cfg, seq, self.precision, entity_index=batch.candidates, keep_bf16=planes and not t.cache_enabled)
+                prec = _lib.PREC_BF16X3 if (t.cache_enabled and self.precision == _lib.PREC_BF16) else self.precision
+                call = _Call(self.cfg, seq, prec, entity_index=batch.candidates, keep_bf16=planes and not t.cache_enabled)
                 if _lib.load().drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
                     if t.cache_enabled:                                # per-entity precompute cache
                         return self._forward_cached(call, t, params)
@@ -393,10 +397,13 @@ class Model(nn.Module):
         # features stored as bf16 are read in place by the fused inference path in split-bf16 precision; every
         # other path (training, exact fp32, geometries off the fused path) gets them widened to fp32 - exact
         in_place = (not training and self._prepared is not None and self.cfg.num_gcn_layers == 2
-                    and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL))
-        call = _Call(self.cfg, batch, self.precision, keep_bf16=in_place)
-        if call.cfg.feature_dtype != _lib.FEAT_F32 and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK:
-            call = _Call(self.cfg, batch, self.precision)
+                    and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16))
+        # "bf16" is a mode of the fused inference path; anything else it meets runs split-bf16
+        prec = self.precision if (in_place or self.precision != _lib.PREC_BF16) else _lib.PREC_BF16X3
+        call = _Call(self.cfg, batch, prec, keep_bf16=in_place)
+        if ((call.cfg.feature_dtype != _lib.FEAT_F32 or prec == _lib.PREC_BF16)
+                and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK):
+            call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec)
         if call.B == 0:
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         return _DrinScore.apply(call, self._prepared, training, *params)
@@ -424,7 +431,7 @@ class Model(nn.Module):
     def forward_traced(self, batch: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Scores plus every stage's vertices and edges (tests / debugging)."""
         lib = _lib.load()
-        call = _Call(self.cfg, batch, self.precision)
+        call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if self.precision == _lib.PREC_BF16 else self.precision)
         params = tuple(p.detach().contiguous() for p in _param_list(self))
         pc = _lib.DrinParamsC()
         _fill_params(pc, params, call.per_layer)

@@ -46,8 +46,10 @@ typedef enum {
 typedef enum {
   DRIN_PREC_F32 = 0,    /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): k-ordered fmaf chain        */
   DRIN_PREC_BF16X3 = 1, /* operands split hi+lo bf16, 3 bf16 MFMAs, fp32 accumulate (~fp32)      */
-  DRIN_PREC_BF16 = 2,   /* operands rounded to bf16, one MFMA pass: NOT offered - measured 6e-4 on the scores,
-                           outside the 1e-4 bar of the path; the value is reserved and returns DRIN_E_UNSUPPORTED */
+  DRIN_PREC_BF16 = 2,   /* drin_forward_prepared only, opt-in: the three pair-sized contractions with operands
+                           rounded to bf16, ONE MFMA pass (BASELINE's "bf16 inference").  Measured score error
+                           ~6e-4: OUTSIDE the 1e-4 bar of the path - never a default; mention-sized work keeps the
+                           BF16X3 arithmetic.  Other entry points return DRIN_E_UNSUPPORTED for it. */
   DRIN_PREC_BF16X3_ALL = 3 /* BF16X3 also for the mention-sized contractions that BF16X3 leaves on
                               the fp32 kernel for latency reasons (used by the parity tests)      */
 } drin_precision;

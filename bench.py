@@ -81,14 +81,15 @@ def algorithmic_bytes_per_pair(cfg, batch):
     return ent + men / N + 4
 
 
-def measured_traffic(kernel_prefix, B, precision, fused, features="f32"):
+def measured_traffic(kernel_prefix, B, precision, fused, features="f32", section="kernels"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.py),
-    valid only for the configuration they were taken on (default workload); None otherwise."""
+    valid only for the configuration they were taken on (default workload, or the cached-table one); None otherwise."""
     path = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
-    if not (os.path.exists(path) and B == 4096 and precision == "bf16x3" and fused and features == "f32"):
+    want_b = 4096 if section == "kernels" else 256
+    if not (os.path.exists(path) and B == want_b and precision == "bf16x3" and fused and features == "f32"):
         return None
     try:
-        for k, v in json.load(open(path))["kernels"].items():
+        for k, v in json.load(open(path)).get(section, {}).items():
             if kernel_prefix in k:
                 return v["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
@@ -359,7 +360,9 @@ def main():
             achieved = work / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": None if cached else measured_traffic("k_entity_stream", B, args.precision, fused, args.features),
+                    "traffic": (measured_traffic("k_cached_pairs", B, args.precision, fused, args.features, "kernels_table_cache")
+                                if cached else (measured_traffic("k_entity_stream", B, args.precision, fused, args.features)
+                                                if args.workload == "wikimel" else None)),
                     "launches": int(launches), "avg_launch_ms": per_launch_ms}
         else:
             # algorithmic FLOPs the kernel's launches cover in one step / their summed time.  In split-bf16

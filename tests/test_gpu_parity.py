@@ -380,6 +380,32 @@ def test_fused_path_follows_weight_updates():
     assert (b.cpu() - ref).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_scoring_call_is_graph_capturable(precision):
+    """The library allocates nothing and never synchronises: after one eager call (weights folded, kernel attributes
+    set) a scoring call captures into a hipGraph and the replay reproduces the eager scores bit for bit."""
+    cfg = wikimel_config(max_entity_attr_token_len=8, max_mention_sentence_len=16, resnet_num_region=4)
+    model = Model(cfg, precision=precision).to(DEV).eval()
+    model.load_state_dict(synth.make_state_dict(cfg, 7))
+    batch = _to_dev(synth.make_batch(cfg, 6, 13)[:14])
+    with torch.no_grad():
+        eager = model(batch).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = model(batch)
+        for t in batch:                      # new inputs through the same static tensors
+            if t.is_floating_point():
+                t.mul_(1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
+
+
 def test_refuses_cpu_tensors():
     cfg = DrinConfig(**TINY)
     m = Model(cfg)

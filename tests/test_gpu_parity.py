@@ -665,6 +665,59 @@ def test_unusual_geometries_vs_oracle(kw, B, fused):
     assert (torch.nan_to_num(got) - torch.nan_to_num(ref)).abs().max().item() <= 2e-5
 
 
+def _random_geometry(seed):
+    g = np.random.Generator(np.random.Philox(key=[seed, 4242]))
+    pick = lambda xs: xs[int(g.integers(0, len(xs)))]  # noqa: E731
+    wm = bool(g.integers(0, 2))
+    D = pick([32, 64, 96, 128, 192])
+    kw = dict(dataset_name="wikimel" if wm else "wikidiverse", bert_embed_dim=D, gcn_embed_dim=D, resnet_embed_dim=pick([32, 64, 128, 160, 256]),
+              num_candidates_data=int(g.integers(1, 41)), max_entity_attr_token_len=int(g.integers(3, 13)),
+              max_mention_sentence_len=int(g.integers(6, 20)), resnet_num_region=int(g.integers(1, 8)),
+              object_topk_mention=int(g.integers(1, 5)), object_topk_entity=int(g.integers(1, 3)),
+              num_gcn_layers=pick([1, 2, 2, 2, 3]), gcn_edge_type=pick(["dynamic", "dynamic", "static"]),
+              gcn_edge_feature=pick(["scaler", "scaler", "scaler", "vector"]),
+              gcn_edge_enabled=tuple(float(x) for x in pick([(1, 1, 1, 1), (1, 1, 1, 1), (1, 0, 1, 1), (0, 1, 1, 0), (1, 1, 0, 1)])))
+    return DrinConfig(**kw), int(g.integers(1, 10))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometries_all_paths_vs_oracle(seed):
+    """Seeded sweep over widths / counts / switches: the folded path (both precisions), the layer-by-layer path and the
+    backward against the oracle - the corner cases no hand-written list anticipates (widths that are not multiples of
+    32, one candidate, one region, masks, 1 and 3 layers fall back to the right kernels)."""
+    from drin_amd.metrics import TripletLoss
+    cfg, B = _random_geometry(seed)
+    sd = synth.make_state_dict(cfg, 100 + seed)
+    batch = synth.make_batch(cfg, B, 200 + seed, min_tokens=3)
+    kw = dict(dynamic=cfg.gcn_edge_type == "dynamic", edge_enabled=cfg.gcn_edge_enabled, num_layers=cfg.num_gcn_layers,
+              vector=cfg.gcn_edge_feature == "vector")
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.forward(p, batch, **kw)
+    ref_loss = O.triplet_loss(batch[-1], ref, cfg.triplet_margin)
+    ref_grads = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
+    ref = ref.detach()
+    dbatch = _to_dev(batch)
+    for precision, fused in (("f32", True), ("bf16x3_all", True), ("f32", False)):
+        model = Model(cfg, precision=precision, fused=fused).to(DEV).eval()
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            got = model(dbatch[:-1]).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), (precision, fused)
+        err = (torch.nan_to_num(got) - torch.nan_to_num(ref)).abs().max().item()
+        assert err <= 2e-5, (seed, precision, fused, err, cfg)
+    if not torch.isnan(ref).any():
+        model = Model(cfg, precision="bf16x3").to(DEV)
+        model.load_state_dict(sd)
+        loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
+        assert abs(loss.item() - ref_loss.item()) <= 2e-5
+        grads = _grads_of(model, loss)
+        for (k, got), r in zip(grads.items(), ref_grads):
+            assert (got is None) == (r is None), (seed, k)
+            if r is not None and r.norm().item() > 1e-8:
+                rel = (got - r).norm().item() / r.norm().item()
+                assert rel <= 2e-3, (seed, k, rel)
+
+
 def test_empty_batch():
     cfg = DrinConfig(**TINY)
     model = Model(cfg).to(DEV).eval()

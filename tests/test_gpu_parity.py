@@ -718,6 +718,46 @@ def test_random_geometries_all_paths_vs_oracle(seed):
                 assert rel <= 2e-3, (seed, k, rel)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_table_forms(seed):
+    """Seeded sweep of the table form: in-kernel gather == gathered batch (bit-exact), the per-entity cache and the
+    bf16-stored tables within fp32 re-association of the oracle on the gathered (widened) tensors."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    g = np.random.Generator(np.random.Philox(key=[seed, 777]))
+    pick = lambda xs: xs[int(g.integers(0, len(xs)))]  # noqa: E731
+    wm = bool(g.integers(0, 2))
+    D = pick([32, 64, 128])
+    cfg = DrinConfig(dataset_name="wikimel" if wm else "wikidiverse", bert_embed_dim=D, gcn_embed_dim=D,
+                     resnet_embed_dim=pick([32, 64, 128, 256]), num_candidates_data=int(g.integers(1, 45)),
+                     max_entity_attr_token_len=int(g.integers(3, 11)), max_mention_sentence_len=12, resnet_num_region=3,
+                     object_topk_mention=int(g.integers(1, 4)), object_topk_entity=int(g.integers(1, 3)),
+                     gcn_edge_type=pick(["dynamic", "dynamic", "static"]))
+    sd = synth.make_state_dict(cfg, 300 + seed)
+    E, B, N = int(g.integers(5, 90)), int(g.integers(1, 8)), cfg.num_candidates_model
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 400 + seed)
+    men = synth.make_batch(cfg, B, 500 + seed)
+    cand = torch.from_numpy(g.integers(0, E, size=(B, N)))
+    dyn = cfg.gcn_edge_type == "dynamic"
+    for stored in (torch.float32, torch.bfloat16):
+        feat = lambda t: t.to(stored)  # noqa: E731
+        table = EntityTable(feat(tab[7][0]), tab[8][0] if wm else None, feat(tab[9][0]), feat(tab[10][0]), tab[11][0]).to(DEV)
+        mention = [feat(t) if i in (0, 4, 5) else t for i, t in enumerate(men[:7])]
+        ib = IndexedBatch(_to_dev(mention), table, cand.to(DEV), men[12].to(DEV), men[13].to(DEV))
+        gathered = ib.gathered()
+        ref = O.forward(sd, [t.float().cpu() if t.dtype == torch.bfloat16 else t.cpu() for t in gathered], dynamic=dyn)
+        model = Model(cfg, precision="bf16x3_all").to(DEV).eval()
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            a, b = model(ib), model(gathered)
+            assert torch.equal(a, b), (seed, stored)
+            assert (a.cpu() - ref).abs().max().item() <= 2e-5
+            if stored == torch.float32:
+                table.enable_cache()
+                c = model(ib)
+                assert (c - a).abs().max().item() <= 6e-6 and (c.cpu() - ref).abs().max().item() <= 2e-5, (seed, cfg)
+                table.enable_cache(False)
+
+
 def test_empty_batch():
     cfg = DrinConfig(**TINY)
     model = Model(cfg).to(DEV).eval()

@@ -155,12 +155,17 @@ __global__ void __launch_bounds__(THREADS, 2)
         ah[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + off);
         if (A_LO) al[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
       }
+      // term-major: consecutive MFMAs write different accumulators, a dependent one is four issues away (+1 %)
+      if (A_LO) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (A_LO) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1], bh[j], acc[t][j], 0, 0, 0);
-        if (B_LO) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bl[j], acc[t][j], 0, 0, 0);
-        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bh[j], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1], bh[j], acc[t][j], 0, 0, 0);
       }
+      if (B_LO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bl[j], acc[t][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bh[j], acc[t][j], 0, 0, 0);
     }
     __syncthreads();
   }

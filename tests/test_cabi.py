@@ -95,3 +95,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libdrin_hip.so"))
     with pytest.raises(ImportError, match="no fallback"):
         _lib.load()
+
+
+def test_plain_c_abi_example_builds(tmp_path):
+    """examples/score_c_abi.cpp (no torch, no Python) compiles and links against the header and the library as shipped."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "score_c_abi")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", f"-I{REPO}/include", f"{REPO}/examples/score_c_abi.cpp",
+                        f"-L{REPO}/drin_amd", "-ldrin_hip", f"-Wl,-rpath,{REPO}/drin_amd", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(exe)

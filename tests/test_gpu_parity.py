@@ -406,6 +406,46 @@ def test_scoring_call_is_graph_capturable(precision):
     assert torch.equal(captured, eager)
 
 
+@pytest.mark.parametrize("name", ["tiny_wd", "tiny_wm"])
+def test_c_abi_caller_without_torch(tmp_path, name):
+    """examples/score_c_abi.cpp - hipMalloc'ed buffers and the C ABI only, no torch anywhere - scores the same case
+    bit-identically to the Module on both forward paths: the boundary really is plain pointers and sizes."""
+    import shutil
+    import struct
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "score_c_abi")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", f"-I{repo}/include", f"{repo}/examples/score_c_abi.cpp",
+                    f"-L{repo}/drin_amd", "-ldrin_hip", f"-Wl,-rpath,{repo}/drin_amd", "-o", exe], check=True, capture_output=True)
+    cfg, sd, batch = build_case(name)
+    B, N, D, R = batch[0].shape[0], cfg.num_candidates_model, cfg.bert_embed_dim, cfg.resnet_embed_dim
+    T = cfg.max_entity_attr_token_len if cfg.token_level_entities else 0
+    blob = struct.pack("12i", B, N, D, R, cfg.max_mention_sentence_len, cfg.resnet_num_region, cfg.object_topk_mention,
+                       cfg.object_topk_entity, T, int(cfg.gcn_edge_type == "dynamic"), cfg.num_gcn_layers, 0)
+    order = [0, 2, 3, 4, 5, 6, 7] + ([8] if T else []) + [9, 10, 11, 12, 13]      # drin_batch order (mask only when token-level)
+    for i in order:
+        blob += batch[i].contiguous().numpy().tobytes()
+    for k in synth.STATE_DICT_SHAPES(D, R, cfg.num_gcn_layers):
+        blob += sd[k[0]].contiguous().numpy().tobytes()
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "scores.bin")
+    open(case, "wb").write(blob)
+    dbatch = _to_dev(batch[:14])
+    for prec_arg, prec in (("f32", "f32"), ("bf16x3", "bf16x3_all")):
+        r = subprocess.run([exe, case, out, prec_arg], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = torch.from_numpy(np.fromfile(out, dtype=np.float32).reshape(2, B, N))
+        with torch.no_grad():
+            layerwise = Model(cfg, precision=prec, fused=False).to(DEV).eval()
+            layerwise.load_state_dict(sd)
+            folded = Model(cfg, precision=prec).to(DEV).eval()
+            folded.load_state_dict(sd)
+            assert torch.equal(got[0], layerwise(dbatch).cpu()), prec
+            assert torch.equal(got[1], folded(dbatch).cpu()), prec
+
+
 def test_refuses_cpu_tensors():
     cfg = DrinConfig(**TINY)
     m = Model(cfg)

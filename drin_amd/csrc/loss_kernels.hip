@@ -113,11 +113,10 @@ __global__ void __launch_bounds__(256) k_triplet_pairs(const float* __restrict__
   if (dscores != nullptr) {
     const float pr = pos[r] + margin;
     int cnt = 0;
-    const int64_t total = (int64_t)B * N;
-    for (int64_t e = t; e < total; e += 256) {
-      const int n = (int)(e % N);
-      const float v = pr + scores[e];  // pos_r - p[b,n] + margin with p = -y_hat
-      cnt += (n < C && v >= 0.f) ? 1 : 0;
+    // rows split over the 4 waves, candidates over the lanes: no division in the B * N loop
+    for (int bb = wave; bb < B; bb += 4) {
+      const float* sr = scores + (int64_t)bb * N;
+      for (int n = lane; n < C; n += 64) cnt += (pr + sr[n] >= 0.f) ? 1 : 0;  // pos_r - p[b,n] + margin with p = -y_hat
     }
     cnt = wave_sum_int(cnt);
     if (lane == 0) l_cnt[wave] = cnt;

@@ -333,7 +333,8 @@ class _DrinScore(torch.autograd.Function):
     def backward(ctx, grad_scores: torch.Tensor):
         lib = _lib.load()
         call, params = ctx.call, ctx.params
-        grads = [torch.zeros_like(p) for p in params]
+        grads = [torch.empty_like(p) for p in params]
+        torch._foreach_zero_(grads)                                   # one multi-tensor launch instead of 24 fills
         gc = _lib.DrinParamGradsC()
         _fill_params(gc, grads, call.per_layer)
         g = grad_scores.to(torch.float32).contiguous()

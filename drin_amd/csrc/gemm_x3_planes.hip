@@ -102,15 +102,26 @@ __device__ __forceinline__ Pieces make_pieces(const __bf16* a_hi, const __bf16* 
 // (Tried: weight fragments fetched straight into registers by global_load_dwordx4 - a lane's fragment of the
 // K-contiguous planes is 16 contiguous bytes - so that the weights never touch LDS: 291 vs 346 TF/s on the same box.
 // The K-loop is not LDS-bound; the extra vector-memory traffic costs more than the LDS traffic it removes.
+// Cycle stamps (-DDRIN_STAMPS, tools/stamps_probe.py) of one tile at K = 768: prologue 6 k cycles, K-loop 109 k (4 400
+// per K-block against 3 072 of pure MFMA issue: ~300 of fragment reads before the first MFMA, ~700 of barrier skew),
+// epilogue 24 k.  Tried against that: a mid-block barrier that publishes the next block early so that its first
+// fragments are prefetched across the block boundary (-8 %: the second barrier costs more than the bubble), a
+// staggered start of the first round of workgroups to de-synchronise the epilogue bursts (-5 %).
 // Also tried: persistent workgroups (one per CU walking a tile list, the next tile's first K-block requested before
 // the epilogue of the finished one): 1411 vs 1365 us at 413 696 x 768 x 768 - the hardware's dynamic dispatch of
 // 4 848 independent tiles balances better than a static list, and the fill it would hide is small.)
+#ifdef DRIN_STAMPS
+__device__ unsigned long long g_stamps[8 * 64 * 4 + 64];  // [wave][kb][4]: loop top, first MFMA issued, last MFMA issued, after barrier
+#endif
 template <bool A_LO, bool B_LO>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                        const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
                        const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef DRIN_STAMPS
+  const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
   int tx;
   int64_t ty;
   tile_of_block(tx, ty, (int)gridDim.x);
@@ -132,8 +143,15 @@ __global__ void __launch_bounds__(THREADS, 2)
   const Pieces pieces = make_pieces(a_hi, A_LO ? a_lo : a_hi, lda, m0, M, b_hi, B_LO ? b_lo : b_hi, ldb, n0, N);
   issue_tile<A_LO, B_LO>(pieces, smem, 0);
   __syncthreads();
+#ifdef DRIN_STAMPS
+  const unsigned long long t_prologue = __builtin_readcyclecounter();
+#endif
 
   for (int kb = 0; kb < nkb; ++kb) {
+#ifdef DRIN_STAMPS
+    const bool stamp = blockIdx.x == 1 && blockIdx.y == 40 && lane == 0 && kb < 64;
+    if (stamp) g_stamps[(wave * 64 + kb) * 4 + 0] = __builtin_readcyclecounter();
+#endif
     const int cur = kb & 1;
     const char* buf = smem + cur * BUF_BYTES;
     const bool more = kb + 1 < nkb;
@@ -150,6 +168,9 @@ __global__ void __launch_bounds__(THREADS, 2)
       ah[0] = *reinterpret_cast<const bf16x8*>(buf + off);
       if (A_LO) al[0] = *reinterpret_cast<const bf16x8*>(buf + PLANE_BYTES + off);
     }
+#ifdef DRIN_STAMPS
+    if (stamp) g_stamps[(wave * 64 + kb) * 4 + 1] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) {  // eight row tiles; the next one's fragments are read one stage ahead
       if (more) issue_piece<A_LO, B_LO>(pieces, nbuf, kb + 1, t);
@@ -161,32 +182,59 @@ __global__ void __launch_bounds__(THREADS, 2)
       // term-major: consecutive MFMAs write different accumulators, a dependent one is four issues away (+1 %)
       if (A_LO) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1], bh[j], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[t & 1], acc[t][j], 0, 0, 0);
       }
       if (B_LO) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bl[j], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[t & 1], acc[t][j], 0, 0, 0);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1], bh[j], acc[t][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[t & 1], acc[t][j], 0, 0, 0);
     }
+#ifdef DRIN_STAMPS
+    if (stamp) g_stamps[(wave * 64 + kb) * 4 + 2] = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef DRIN_STAMPS
+    if (stamp) g_stamps[(wave * 64 + kb) * 4 + 3] = __builtin_readcyclecounter();
+#endif
   }
 
-  // C/D of a 16 x 16 tile: column lane & 15, row 4 (lane >> 4) + register
+  // The MFMAs take the WEIGHT fragment as their first operand, so a lane's four accumulator registers of a 16 x 16
+  // tile are four consecutive output COLUMNS of one row (row lane & 15, columns 4 (lane >> 4) + v): one 16-byte store
+  // per tile instead of four scattered 4-byte ones (32 instead of 128 store instructions per wave; the epilogue was
+  // 24 % of a tile's time at K = 768).
+  const bool vec_ok = (ldc % 4) == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row = m0 + wm * 128 + i * 16 + r;
+    if (row >= M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + r;
-      if (col >= N) continue;
-      const float bv = bias != nullptr ? bias[col] : 0.f;
+      const int col = n0 + wn * 64 + j * 16 + c * 4;
+      float* dst = C + row * ldc + col;
+      if (vec_ok && col + 3 < N) {
+        float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (bias != nullptr) o = o + ld4(bias + col);
+        st4(dst, o);
+      } else {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int64_t row = m0 + wm * 128 + i * 16 + c * 4 + v;
-        if (row < M) C[row * ldc + col] = acc[i][j][v] + bv;
+        for (int v = 0; v < 4; ++v)
+          if (col + v < N) dst[v] = acc[i][j][v] + (bias != nullptr ? bias[col + v] : 0.f);
       }
     }
+  }
+#ifdef DRIN_STAMPS
+  if (blockIdx.x == 1 && blockIdx.y == 40 && (threadIdx.x & 63) == 0) {
+    __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged
+    const int wv = threadIdx.x >> 6;
+    unsigned long long* o = g_stamps + 8 * 64 * 4 + wv * 4;
+    o[0] = t_start;
+    o[1] = t_prologue;
+    o[2] = g_stamps[(wv * 64 + (K / BK - 1 < 63 ? K / BK - 1 : 63)) * 4 + 3];
+    o[3] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // fp32 -> (hi, lo) bf16 planes, 4 values per thread
@@ -210,6 +258,12 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
 }
 
 }  // namespace x3p
+
+#ifdef DRIN_STAMPS
+extern "C" __attribute__((visibility("default"))) int drin_debug_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(x3p::g_stamps), sizeof(unsigned long long) * (8 * 64 * 4 + 64));
+}
+#endif
 
 int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream_t st) {
   if (n <= 0) return DRIN_OK;

@@ -142,7 +142,21 @@ def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None):
             if el >= seconds or it >= 2000:
                 break
     pairs = it * B * cfg.num_candidates_model
+    # the same arithmetic with the reference's own Python loops over mentions and candidates kept
+    # (baselines/ghmfc.py:58-59,246-249; model.py:86-91): its cost profile, ~5 s sample
+    with torch.no_grad():
+        O.reference_style_forward(sd, batch)  # warm-up
+        t1 = time.perf_counter()
+        it_ref = 0
+        while True:
+            O.reference_style_forward(sd, batch)
+            it_ref += 1
+            el_ref = time.perf_counter() - t1
+            if el_ref >= 5.0 or it_ref >= 500:
+                break
+    ref_style = it_ref * B * cfg.num_candidates_model / el_ref
     out = {"value": pairs / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "reference_style_loops_value": ref_style,
            "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={cfg.num_candidates_model} fp32, "
                      f"torch {torch.get_num_threads()} threads, {el:.1f} s"}
     return out, parity

@@ -202,8 +202,13 @@ class ShardSampler(torch.utils.data.Sampler):
         return len(range(self.rank, self.n, self.world))
 
 
-def write_synthetic_dataset(cfg: DrinConfig, root: str, sizes=(256, 64, 64), seed: int = 1, num_entities: int = 512) -> None:
+def write_synthetic_dataset(cfg: DrinConfig, root: str, sizes=(256, 64, 64), seed: int = 1, num_entities: int = 512,
+                            learnable: float = 0.0) -> None:
     """A directory in the reference's preprocessed layout, drawn from `synth` seeds.
+
+    `learnable` > 0 (WikiDiverse layout only) plants a signal: the gold candidate's text feature becomes the mention's
+    span mean plus `1 / learnable` times its original noise, so that a model can learn to rank it first - a stand-in
+    task for end-to-end training checks (the real datasets are not available offline).
 
     WikiDiverse stores per-split candidate tensors flattened over (mention, candidate); WikiMEL stores
     one entity table plus per-split QID lists and `qid2idx.json` (`preprocess/bert.py:100-109`,
@@ -234,6 +239,11 @@ def write_synthetic_dataset(cfg: DrinConfig, root: str, sizes=(256, 64, 64), see
             json.dump({q: i for i, q in enumerate(qids)}, f)
     for split, m in zip(SPLITS, sizes):
         b = synth.make_batch(cfg, m, seed + SPLITS.index(split), as_torch=False)
+        if learnable > 0 and not wm:
+            gold = np.where(b[14].any(1), b[14].argmax(1), -1)
+            for i in np.nonzero(gold >= 0)[0]:
+                span = b[0][i, b[2][i]: b[3][i]].mean(0)
+                b[7][i, gold[i]] = span + b[7][i, gold[i]] / learnable
         save(f"mention-text-feature_{split}.npy", b[0])
         save(f"mention-text-mask_{split}.npy", b[1])
         save(f"start-pos_{split}.npy", b[2] - 1)

@@ -497,11 +497,15 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
         DRIN_TRY(launch_entity_aggregate_vec(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
       }
     } else {
-      DRIN_TRY(launch_mention_aggregate(e_tt, et, e_ti, ei, mt, agg_m, B, N, D, st));
-      DRIN_TRY(launch_entity_aggregate(e_tt, mt, e_it, mi, et, agg_e, B, N, D, st));
-      if (live_image) {
-        DRIN_TRY(launch_mention_aggregate(e_it, et, e_ii, ei, mi, agg_m + (size_t)B * D, B, N, D, st));
-        DRIN_TRY(launch_entity_aggregate(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
+      if (B <= 65535) {
+        DRIN_TRY(launch_layer_aggregate(e, (int64_t)ES, mt, et, agg_m, agg_e, B, N, D, live_image, st));
+      } else {
+        DRIN_TRY(launch_mention_aggregate(e_tt, et, e_ti, ei, mt, agg_m, B, N, D, st));
+        DRIN_TRY(launch_entity_aggregate(e_tt, mt, e_it, mi, et, agg_e, B, N, D, st));
+        if (live_image) {
+          DRIN_TRY(launch_mention_aggregate(e_it, et, e_ii, ei, mi, agg_m + (size_t)B * D, B, N, D, st));
+          DRIN_TRY(launch_entity_aggregate(e_ti, mt, e_ii, mi, ei, agg_e + (size_t)M * D, B, N, D, st));
+        }
       }
     }
     const int types = live_image ? 2 : 1;
@@ -534,11 +538,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
       float* fv = ws + L.fv[l];
       DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, sk, skf));
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st));
-      for (int k = 0; k < 4; ++k) {
-        const float* fuk = fu + (size_t)(k >> 1) * B * D;
-        const float* fvk = fv + (size_t)(k & 1) * M * D;
-        DRIN_TRY(launch_edge_update(fuk, fvk, e + k * M, e_next + k * M, B, N, D, st));
-      }
+      DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st));
     } else if (!cfg->dynamic_edges) {
       hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);
       if (err != hipSuccess) return hip_fail(err, "hipMemcpyAsync(static edges)");
@@ -778,9 +778,10 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       if (edge_update) DRIN_TRY(gemm_nn(dfu, H, W.w_u, g_vm[nxt], D, 2 * (int64_t)B, D, H, true));
     } else {
       // (e) entity side of the aggregation backward + edge gradients
+      // (the edge update's dfv W_v goes first and the row kernel adds onto it)
+      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, D, false));
       DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
-                                      g_e[nxt], B, N, D, cfg->edge_enabled, st));
-      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, D, true));
+                                      g_e[nxt], B, N, D, cfg->edge_enabled, edge_update, st));
       // (f) mention side
       DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
       DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));

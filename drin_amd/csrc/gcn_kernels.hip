@@ -68,6 +68,113 @@ int launch_mention_aggregate(const float* e1, const float* v1, const float* e2, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Both aggregations of a scalar-edge layer in ONE pass over the entity vertices (model.py:143-146 + the self terms of
+// :128): every et / ei element is read once and feeds the mention sums and its own entity update.
+//   agg_mt[b] = mean_n(e_tt et) + mean_n(e_ti ei) + mt[b]      agg_et[b,n] = e_tt mt[b] + e_it mi[b] + et[b,n]
+//   agg_mi[b] = mean_n(e_it et) + mean_n(e_ii ei) + mi[b]      agg_ei[b,n] = e_ti mt[b] + e_ii mi[b] + ei[b,n]
+// (the image rows only when LIVE_IMAGE: the last layer's image vertices never reach the score).  Same grid, same
+// per-column summation order as k_mention_aggregate / k_entity_aggregate: bit-identical to the four separate launches,
+// at half their HBM traffic.
+template <bool LIVE_IMAGE>
+__global__ void __launch_bounds__(64) k_layer_aggregate(const float* __restrict__ e, int64_t ES,
+                                                        const float* __restrict__ vm, const float* __restrict__ ve,
+                                                        float* __restrict__ agg_m, float* __restrict__ agg_e, int B,
+                                                        int N, int D4) {
+  const int c4 = blockIdx.x * 64 + threadIdx.x;
+  if (c4 >= D4) return;
+  const int64_t b = blockIdx.y;
+  const int64_t D = (int64_t)D4 * 4, MD = (int64_t)B * N * D, BD = (int64_t)B * D;
+  const int64_t row0 = b * N * D + (int64_t)c4 * 4;
+  const float* pt = ve + row0;
+  const float* pi = ve + MD + row0;
+  float* ot = agg_e + row0;
+  float* oi = agg_e + MD + row0;
+  const float* e_tt = e + b * N;
+  const float* e_ti = e_tt + ES;
+  const float* e_it = e_tt + 2 * ES;
+  const float* e_ii = e_tt + 3 * ES;
+  const float4 mt = ld4(vm + b * D + (int64_t)c4 * 4), mi = ld4(vm + BD + b * D + (int64_t)c4 * 4);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s_tt = zero, s_ti = zero, s_it = zero, s_ii = zero;
+  auto entity_out = [&](float a1, float a2, const float4& v) {
+    float4 r;
+    r.x = (a1 * mt.x + a2 * mi.x) + v.x;
+    r.y = (a1 * mt.y + a2 * mi.y) + v.y;
+    r.z = (a1 * mt.z + a2 * mi.z) + v.z;
+    r.w = (a1 * mt.w + a2 * mi.w) + v.w;
+    return r;
+  };
+  int n = 0;
+  for (; n + 4 <= N; n += 4) {
+    float4 a[4], c[4];
+    float w_tt[4], w_ti[4], w_it[4], w_ii[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = ld4(pt + (int64_t)(n + j) * D);
+      c[j] = ld4(pi + (int64_t)(n + j) * D);
+      w_tt[j] = e_tt[n + j];
+      w_ti[j] = e_ti[n + j];
+      w_it[j] = e_it[n + j];
+      w_ii[j] = e_ii[n + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s_tt = fma4(w_tt[j], a[j], s_tt);
+      s_ti = fma4(w_ti[j], c[j], s_ti);
+      st4(ot + (int64_t)(n + j) * D, entity_out(w_tt[j], w_it[j], a[j]));
+      if (LIVE_IMAGE) {
+        s_it = fma4(w_it[j], a[j], s_it);
+        s_ii = fma4(w_ii[j], c[j], s_ii);
+        st4(oi + (int64_t)(n + j) * D, entity_out(w_ti[j], w_ii[j], c[j]));
+      }
+    }
+  }
+  for (; n < N; ++n) {
+    const float4 a = ld4(pt + (int64_t)n * D), c = ld4(pi + (int64_t)n * D);
+    s_tt = fma4(e_tt[n], a, s_tt);
+    s_ti = fma4(e_ti[n], c, s_ti);
+    st4(ot + (int64_t)n * D, entity_out(e_tt[n], e_it[n], a));
+    if (LIVE_IMAGE) {
+      s_it = fma4(e_it[n], a, s_it);
+      s_ii = fma4(e_ii[n], c, s_ii);
+      st4(oi + (int64_t)n * D, entity_out(e_ti[n], e_ii[n], c));
+    }
+  }
+  const float cnt = (float)N;
+  auto mention_out = [&](const float4& s1, const float4& s2, const float4& u) {
+    float4 r;
+    r.x = (s1.x / cnt + s2.x / cnt) + u.x;
+    r.y = (s1.y / cnt + s2.y / cnt) + u.y;
+    r.z = (s1.z / cnt + s2.z / cnt) + u.z;
+    r.w = (s1.w / cnt + s2.w / cnt) + u.w;
+    return r;
+  };
+  st4(agg_m + b * D + (int64_t)c4 * 4, mention_out(s_tt, s_ti, mt));
+  if (LIVE_IMAGE) st4(agg_m + BD + b * D + (int64_t)c4 * 4, mention_out(s_it, s_ii, mi));
+}
+
+int launch_layer_aggregate(const float* e, int64_t edge_stride, const float* vm, const float* ve, float* agg_m,
+                           float* agg_e, int B, int N, int D, bool live_image, hipStream_t st) {
+  if (B <= 0 || N <= 0) return DRIN_OK;
+  if (D % 4) {
+    set_error("layer_aggregate: D=%d must be a multiple of 4", D);
+    return DRIN_E_SHAPE;
+  }
+  if (B > 65535) {
+    set_error("layer_aggregate: batch %d exceeds the grid limit of 65535 mentions per launch", B);
+    return DRIN_E_SHAPE;
+  }
+  dim3 grid((unsigned)cdiv(D / 4, 64), (unsigned)B);
+  KernelTimer timer(DRIN_KC_GCN, st);
+  if (live_image)
+    hipLaunchKernelGGL(k_layer_aggregate<true>, grid, dim3(64), 0, st, e, edge_stride, vm, ve, agg_m, agg_e, B, N, D / 4);
+  else
+    hipLaunchKernelGGL(k_layer_aggregate<false>, grid, dim3(64), 0, st, e, edge_stride, vm, ve, agg_m, agg_e, B, N, D / 4);
+  DRIN_CHECK_LAUNCH("k_layer_aggregate");
+  return DRIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // entity <- mention (model.py:146) summed over the two neighbour types, plus the self term (:128):
 //   out[b, n, :] = e1[b,n] m1[b, :] + e2[b,n] m2[b, :] + v[b, n, :]
 __global__ void __launch_bounds__(256) k_entity_aggregate(const float* __restrict__ e1, const float* __restrict__ m1,
@@ -175,23 +282,44 @@ int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta,
 
 // ------------------------------------------------------------------------------------------------
 // dynamic edge (model.py:148-153 with w_m = Identity :112, sigmoid :133):
-//   out[b, n] = sigmoid(mean_d(fu[b, :] * fv[b, n, :]) + e[b, n])       one wave per pair
-__global__ void __launch_bounds__(256) k_edge_update(const float* __restrict__ fu, const float* __restrict__ fv,
-                                                     const float* __restrict__ e, float* __restrict__ out,
-                                                     int64_t pairs, int N, int D4) {
+//   out[b, n] = sigmoid(mean_d(fu[b, :] * fv[b, n, :]) + e[b, n])       one wave per pair,
+// all four edge types of a layer in one pass: fu = [2][B][D] (W_u of mt, mi), fv = [2][M][D] (W_v of et, ei),
+// e / out = [4][M] in the order tt, ti, it, ii.  Each fv row is read once instead of twice; the per-lane summation
+// order is fixed, so the results do not depend on the launch geometry.
+__global__ void __launch_bounds__(256) k_edge_update4(const float* __restrict__ fu, const float* __restrict__ fv,
+                                                      const float* __restrict__ e, float* __restrict__ out,
+                                                      int64_t pairs, int B, int N, int D4) {
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= pairs) return;
   const int lane = threadIdx.x & 63;
-  const float* ur = fu + (p / N) * (int64_t)D4 * 4;
-  const float* vr = fv + p * (int64_t)D4 * 4;
-  float s = 0.f;
-  for (int c4 = lane; c4 < D4; c4 += 64) s += dot4(ld4(ur + c4 * 4), ld4(vr + c4 * 4));
-  s = wave_sum(s);
-  if (lane == 0) out[p] = sigmoidf(s / (float)(D4 * 4) + e[p]);
+  const int64_t D = (int64_t)D4 * 4;
+  const float* ut = fu + (p / N) * D;
+  const float* ui = ut + (int64_t)B * D;
+  const float* vt = fv + p * D;
+  const float* vi = vt + pairs * D;
+  float s_tt = 0.f, s_ti = 0.f, s_it = 0.f, s_ii = 0.f;
+  for (int c4 = lane; c4 < D4; c4 += 64) {
+    const float4 a = ld4(ut + c4 * 4), b = ld4(ui + c4 * 4), x = ld4(vt + c4 * 4), y = ld4(vi + c4 * 4);
+    s_tt += dot4(a, x);
+    s_ti += dot4(a, y);
+    s_it += dot4(b, x);
+    s_ii += dot4(b, y);
+  }
+  s_tt = wave_sum(s_tt);
+  s_ti = wave_sum(s_ti);
+  s_it = wave_sum(s_it);
+  s_ii = wave_sum(s_ii);
+  if (lane == 0) {
+    const float d = (float)(D4 * 4);
+    out[p] = sigmoidf(s_tt / d + e[p]);
+    out[pairs + p] = sigmoidf(s_ti / d + e[pairs + p]);
+    out[2 * pairs + p] = sigmoidf(s_it / d + e[2 * pairs + p]);
+    out[3 * pairs + p] = sigmoidf(s_ii / d + e[3 * pairs + p]);
+  }
 }
 
-int launch_edge_update(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
-                       hipStream_t st) {
+int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
+                        hipStream_t st) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   if (D % 4) {
@@ -199,8 +327,8 @@ int launch_edge_update(const float* fu, const float* fv, const float* e, float* 
     return DRIN_E_SHAPE;
   }
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_edge_update, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, fu, fv, e, out, pairs, N, D / 4);
-  DRIN_CHECK_LAUNCH("k_edge_update");
+  hipLaunchKernelGGL(k_edge_update4, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4);
+  DRIN_CHECK_LAUNCH("k_edge_update4");
   return DRIN_OK;
 }
 

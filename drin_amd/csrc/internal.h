@@ -97,12 +97,15 @@ int launch_mention_aggregate(const float* e1, const float* v1, const float* e2, 
 // model.py:146 + :128 input: out[b,n,:] = e1[b,n] m1[b,:] + e2[b,n] m2[b,:] + v[b,n,:]
 int launch_entity_aggregate(const float* e1, const float* m1, const float* e2, const float* m2, const float* v,
                             float* out, int B, int N, int D, hipStream_t st);
+// both aggregations of a scalar-edge layer in one pass; e = [4][edge_stride], vm = [2][B][D], ve = [2][B*N][D]
+int launch_layer_aggregate(const float* e, int64_t edge_stride, const float* vm, const float* ve, float* agg_m,
+                           float* agg_e, int B, int N, int D, bool live_image, hipStream_t st);
 // model.py:128: y = gelu(layer_norm(h)) row-wise; optionally keeps mean / rstd for backward
 int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                           int64_t rows, int D, float eps, hipStream_t st);
 // model.py:148-153 + :133: out[b,n] = sigmoid(mean_d(fu[b,:] fv[b,n,:]) + e[b,n])
-int launch_edge_update(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
-                       hipStream_t st);
+int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
+                        hipStream_t st);
 
 // ---- backward row kernels (backward_kernels.hip) ------------------------------------------------
 // d cos(x[b], y[p]) : dx [B, D], dy [B*N, D]; scratch3 holds 3 * B*N floats
@@ -127,7 +130,7 @@ int launch_entity_combine(const float* w1, const float* m1, const float* w2, con
 int launch_entity_side_bwd(const float* dA_mt, const float* dA_mi, const float* dA_et, const float* dA_ei,
                            const float* mt, const float* mi, const float* et, const float* ei, const float* e,
                            const float* de_extra, float* d_et, float* d_ei, float* de, int B, int N, int D,
-                           const float* mask, hipStream_t st);
+                           const float* mask, bool accumulate, hipStream_t st);  // accumulate: d_et, d_ei += ...
 
 // ---- vector-edge ablation (vector_kernels.hip) --------------------------------------------------
 int launch_expand_edges(const float* es, float* out, int64_t pairs4, int D, hipStream_t st);

@@ -410,6 +410,12 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "hbm_fraction_whole_path": bytes_pair * value / world / (PEAK_HBM_GBS * 1e9),
+            # matrix-core work the path executes (split-bf16: three bf16 MFMA passes per algorithmic product) and the
+            # reference-faithful operation count at the same rate, both against the dense bf16 peak
+            "mfma_fraction_whole_path": ((1 if args.precision == "bf16" else 3) if x3 else 1) * flops_pair * value / world
+                                        / ((PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12),
+            "mfma_fraction_reference_flops": (2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D) * value / world
+                                             / ((PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12),
             "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + args.precision
                     + (", features stored as bf16" if args.features == "bf16" else ""),
             "algorithmic": {"bytes_per_pair": bytes_pair, "dominant_kernel_bytes_per_pair": stream_bytes_pair, "flops_per_pair_executed": flops_pair,

@@ -756,8 +756,12 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       DRIN_TRY(launch_entity_combine(dpre, fu, dpre + 2 * M, fu + BD, dfv, B, N, D, inv_d, st));
       DRIN_TRY(launch_entity_combine(dpre + M, fu, dpre + 3 * M, fu + BD, dfv + MD, B, N, D, inv_d, st));
       // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
-      DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
-      DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
+      if (B <= 65535) {
+        DRIN_TRY(launch_mention_reduce2(dpre, fv, fv + MD, nullptr, nullptr, dfu, dfu + BD, B, N, D, inv_d, st));
+      } else {
+        DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
+        DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
+      }
       if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, D, st));
       if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st, tnp, tnf));
@@ -783,8 +787,12 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
                                       g_e[nxt], B, N, D, cfg->edge_enabled, edge_update, st));
       // (f) mention side
-      DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
-      DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
+      if (B <= 65535) {
+        DRIN_TRY(launch_mention_reduce2(e, dA_et, dA_ei, dA_mt, dA_mi, g_vm[nxt], g_vm[nxt] + BD, B, N, D, 1.0f, st));
+      } else {
+        DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
+        DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
+      }
       if (edge_update) DRIN_TRY(gemm_nn(dfu, D, W.w_u, g_vm[nxt], D, 2 * (int64_t)B, D, D, true));
     }
     have_image = true;

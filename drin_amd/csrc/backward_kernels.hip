@@ -128,40 +128,61 @@ int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx,
 //   dh = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
 // and the three column sums  dgamma += sum_rows dz xhat,  dbeta += sum_rows dz,  dbias += sum_rows dh
 // (dbias is the W_h bias gradient: h = a W_h^T + b_h).
+// V = float4 columns per lane (3 for D = 768).  The next row's h / g are requested before the current row's
+// erf / exp chain starts: the kernel is half memory (3 rows of traffic per row), half VALU, and four resident waves
+// per SIMD did not overlap the two on their own (2 x 51 712 rows: 257 us without the prefetch).
+template <int V>
 __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restrict__ h, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* g,
                                                             float* __restrict__ partial, int64_t rows, int D4) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float4 gm[MAXV], bt[MAXV];
-  float4 a_dg[MAXV], a_db[MAXV], a_dh[MAXV];
+  float4 gm[V], bt[V];
+  float4 a_dg[V], a_db[V], a_dh[V];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int j = 0; j < MAXV; ++j) {
+  for (int j = 0; j < V; ++j) {
     const int c4 = lane + 64 * j;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    gm[j] = c4 < D4 ? ld4(gamma + c4 * 4) : z;
-    bt[j] = c4 < D4 ? ld4(beta + c4 * 4) : z;
-    a_dg[j] = a_db[j] = a_dh[j] = z;
+    gm[j] = c4 < D4 ? ld4(gamma + c4 * 4) : zero;
+    bt[j] = c4 < D4 ? ld4(beta + c4 * 4) : zero;
+    a_dg[j] = a_db[j] = a_dh[j] = zero;
   }
   const float inv_d = 1.0f / (float)(D4 * 4);
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    const float* hr = h + row * (int64_t)D4 * 4;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  float4 hv[V], gv[V];
+  float mu = 0.f, rs = 0.f;
+  auto fetch = [&](int64_t r, float4* ph, float4* pg, float& m, float& s) {
+    const float* hr = h + r * (int64_t)D4 * 4;
+    const float* gr = g + r * (int64_t)D4 * 4;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c4 = lane + 64 * j;
+      ph[j] = c4 < D4 ? ld4(hr + c4 * 4) : zero;
+      pg[j] = c4 < D4 ? ld4(gr + c4 * 4) : zero;
+    }
+    m = mean[r];
+    s = rstd[r];
+  };
+  if (row < rows) fetch(row, hv, gv, mu, rs);
+  for (; row < rows; row += stride) {
+    float4 nh[V], ng[V];
+    float nmu = 0.f, nrs = 0.f;
+    if (row + stride < rows) fetch(row + stride, nh, ng, nmu, nrs);
     float* gr = g + row * (int64_t)D4 * 4;
-    float4 xh[MAXV], dxh[MAXV];
+    float4 xh[V], dxh[V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < V; ++j) {
       const int c4 = lane + 64 * j;
       if (c4 < D4) {
-        const float4 hv = ld4(hr + c4 * 4), gv = ld4(gr + c4 * 4);
-        xh[j] = make_float4((hv.x - mu) * rs, (hv.y - mu) * rs, (hv.z - mu) * rs, (hv.w - mu) * rs);
+        xh[j] = make_float4((hv[j].x - mu) * rs, (hv[j].y - mu) * rs, (hv[j].z - mu) * rs, (hv[j].w - mu) * rs);
         float4 dz;
-        dz.x = gv.x * gelu_erf_grad(xh[j].x * gm[j].x + bt[j].x);
-        dz.y = gv.y * gelu_erf_grad(xh[j].y * gm[j].y + bt[j].y);
-        dz.z = gv.z * gelu_erf_grad(xh[j].z * gm[j].z + bt[j].z);
-        dz.w = gv.w * gelu_erf_grad(xh[j].w * gm[j].w + bt[j].w);
+        dz.x = gv[j].x * gelu_erf_grad(xh[j].x * gm[j].x + bt[j].x);
+        dz.y = gv[j].y * gelu_erf_grad(xh[j].y * gm[j].y + bt[j].y);
+        dz.z = gv[j].z * gelu_erf_grad(xh[j].z * gm[j].z + bt[j].z);
+        dz.w = gv[j].w * gelu_erf_grad(xh[j].w * gm[j].w + bt[j].w);
         a_dg[j] = make_float4(fmaf(dz.x, xh[j].x, a_dg[j].x), fmaf(dz.y, xh[j].y, a_dg[j].y),
                               fmaf(dz.z, xh[j].z, a_dg[j].z), fmaf(dz.w, xh[j].w, a_dg[j].w));
         a_db[j] = a_db[j] + dz;
@@ -169,13 +190,13 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restr
         s1 += (dxh[j].x + dxh[j].y) + (dxh[j].z + dxh[j].w);
         s2 += dot4(dxh[j], xh[j]);
       } else {
-        xh[j] = dxh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[j] = dxh[j] = zero;
       }
     }
     s1 = wave_sum(s1) * inv_d;
     s2 = wave_sum(s2) * inv_d;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < V; ++j) {
       const int c4 = lane + 64 * j;
       if (c4 < D4) {
         float4 dh;
@@ -187,22 +208,29 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restr
         st4(gr + c4 * 4, dh);
       }
     }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      hv[j] = nh[j];
+      gv[j] = ng[j];
+    }
+    mu = nmu;
+    rs = nrs;
   }
   // combine the four waves' column sums through LDS (one quantity at a time keeps LDS at 16 KiB), then ONE row of
   // partial sums per block: partial[block][q][D].  A second kernel adds the blocks in order - no atomics: a thousand
   // blocks adding to the same 2 304 addresses serialised in L2 (106 us per call at 12 928 rows), and the sums were
   // run-order dependent.
-  __shared__ float4 comb[4][MAXV][64];
+  __shared__ float4 comb[4][V][64];
   const int D = D4 * 4;
   for (int q = 0; q < 3; ++q) {
     float* dst = partial + ((int64_t)blockIdx.x * 3 + q) * D;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) comb[wave][j][lane] = q == 0 ? a_dg[j] : (q == 1 ? a_db[j] : a_dh[j]);
+    for (int j = 0; j < V; ++j) comb[wave][j][lane] = q == 0 ? a_dg[j] : (q == 1 ? a_db[j] : a_dh[j]);
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
+      for (int j = 0; j < V; ++j) {
         const int c4 = lane + 64 * j;
         if (c4 < D4) st4(dst + c4 * 4, (comb[0][j][lane] + comb[1][j][lane]) + (comb[2][j][lane] + comb[3][j][lane]));
       }
@@ -251,10 +279,14 @@ int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rs
     set_error("layernorm_gelu_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
     return DRIN_E_SHAPE;
   }
-  const int64_t blocks = cdiv(rows, 4) < kLnBwdMaxBlocks ? cdiv(rows, 4) : kLnBwdMaxBlocks;
+  // 161 VGPRs at V = 3: three workgroups per CU are resident, so 768 (of the 1024 the partial buffer holds) run as one round
+  const int64_t cap = 768;
+  const int64_t blocks = cdiv(rows, 4) < cap ? cdiv(rows, 4) : cap;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_layernorm_gelu_bwd, dim3((unsigned)blocks), dim3(256), 0, st, h, mean, rstd, gamma, beta, g,
-                     partial, rows, D / 4);
+  const int v = (int)cdiv(D / 4, 64);
+  auto kern = v <= 1 ? k_layernorm_gelu_bwd<1> : v == 2 ? k_layernorm_gelu_bwd<2> : v == 3 ? k_layernorm_gelu_bwd<3>
+                                                                                         : k_layernorm_gelu_bwd<4>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, h, mean, rstd, gamma, beta, g, partial, rows, D / 4);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
   // partial: [kLnBwdMaxBlocks][3][D] block rows, then [kLnBwdMaxBlocks / 64][3][D] for the first reduction level
   float* level1 = partial + (int64_t)kLnBwdMaxBlocks * 3 * D;
@@ -276,9 +308,17 @@ __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, flo
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c4 = blockIdx.x * 64 + lane;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c4 < C4)
-    for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < rows; row += (int64_t)gridDim.y * 4)
-      acc = acc + ld4(x + row * (int64_t)C4 * 4 + (int64_t)c4 * 4);
+  if (c4 < C4) {
+    const int64_t step = (int64_t)gridDim.y * 4;
+    const float* col = x + (int64_t)c4 * 4;
+    int64_t row = (int64_t)blockIdx.y * 4 + wave;
+    for (; row + 3 * step < rows; row += 4 * step) {  // four independent loads in flight per wave
+      const float4 v0 = ld4(col + row * (int64_t)C4 * 4), v1 = ld4(col + (row + step) * (int64_t)C4 * 4);
+      const float4 v2 = ld4(col + (row + 2 * step) * (int64_t)C4 * 4), v3 = ld4(col + (row + 3 * step) * (int64_t)C4 * 4);
+      acc = acc + ((v0 + v1) + (v2 + v3));
+    }
+    for (; row < rows; row += step) acc = acc + ld4(col + row * (int64_t)C4 * 4);
+  }
   comb[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c4 < C4) {
@@ -378,6 +418,86 @@ int launch_mention_reduce(const float* w1, const float* v1, const float* w2, con
                        out + (int64_t)b0 * D, N, D / 4, scale);
     DRIN_CHECK_LAUNCH("k_mention_reduce");
   }
+  return DRIN_OK;
+}
+
+// Two reductions over the same rows in one pass (the text and the image mention of a layer):
+//   outA[b] = scale (sum_n w[0][p] v1[p] + sum_n w[1][p] v2[p]) + uA[b]
+//   outB[b] = scale (sum_n w[2][p] v1[p] + sum_n w[3][p] v2[p]) + uB[b]         w = [4][pairs]; v2 / uA / uB may be NULL
+// Candidate split and summation order are those of k_mention_reduce: bit-identical to two launches of it, v1 / v2 read once.
+__global__ void __launch_bounds__(256) k_mention_reduce2(const float* __restrict__ w, int64_t pairs,
+                                                         const float* __restrict__ v1, const float* __restrict__ v2,
+                                                         const float* __restrict__ uA, const float* __restrict__ uB,
+                                                         float* __restrict__ outA, float* __restrict__ outB, int N,
+                                                         int D4, float scale) {
+  __shared__ float4 comb[2][4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c4 = blockIdx.x * 64 + lane;
+  const int64_t b = blockIdx.y;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 sA = zero, sB = zero;
+  if (c4 < D4) {
+    const int64_t off = (b * N) * (int64_t)D4 * 4 + (int64_t)c4 * 4, row = (int64_t)D4 * 4;
+    const float* w0 = w + b * N;
+    const float* w1 = w0 + pairs;
+    const float* w2 = w0 + 2 * pairs;
+    const float* w3 = w0 + 3 * pairs;
+    float4 tA = zero, tB = zero;
+    int n = wave;
+    for (; n + 4 < N; n += 8) {  // two candidates of this wave per trip
+      const float4 a0 = ld4(v1 + off + n * row), a1 = ld4(v1 + off + (n + 4) * row);
+      float4 c0 = zero, c1 = zero;
+      if (v2 != nullptr) {
+        c0 = ld4(v2 + off + n * row);
+        c1 = ld4(v2 + off + (n + 4) * row);
+      }
+      sA = fma4(w0[n], a0, sA);
+      tA = fma4(w0[n + 4], a1, tA);
+      sB = fma4(w2[n], a0, sB);
+      tB = fma4(w2[n + 4], a1, tB);
+      if (v2 != nullptr) {
+        sA = fma4(w1[n], c0, sA);
+        tA = fma4(w1[n + 4], c1, tA);
+        sB = fma4(w3[n], c0, sB);
+        tB = fma4(w3[n + 4], c1, tB);
+      }
+    }
+    for (; n < N; n += 4) {
+      const float4 a0 = ld4(v1 + off + n * row);
+      sA = fma4(w0[n], a0, sA);
+      sB = fma4(w2[n], a0, sB);
+      if (v2 != nullptr) {
+        const float4 c0 = ld4(v2 + off + n * row);
+        sA = fma4(w1[n], c0, sA);
+        sB = fma4(w3[n], c0, sB);
+      }
+    }
+    sA = sA + tA;
+    sB = sB + tB;
+  }
+  comb[0][wave][lane] = sA;
+  comb[1][wave][lane] = sB;
+  __syncthreads();
+  if (wave != 0 || c4 >= D4) return;
+  sA = ((comb[0][0][lane] + comb[0][1][lane]) + (comb[0][2][lane] + comb[0][3][lane])) * scale;
+  sB = ((comb[1][0][lane] + comb[1][1][lane]) + (comb[1][2][lane] + comb[1][3][lane])) * scale;
+  if (uA != nullptr) sA = sA + ld4(uA + b * (int64_t)D4 * 4 + (int64_t)c4 * 4);
+  if (uB != nullptr) sB = sB + ld4(uB + b * (int64_t)D4 * 4 + (int64_t)c4 * 4);
+  st4(outA + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, sA);
+  st4(outB + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, sB);
+}
+
+int launch_mention_reduce2(const float* w, const float* v1, const float* v2, const float* uA, const float* uB,
+                           float* outA, float* outB, int B, int N, int D, float scale, hipStream_t st) {
+  if (B <= 0) return DRIN_OK;
+  if (B > 65535) {
+    set_error("mention_reduce2: batch %d exceeds the grid limit of 65535 mentions per launch", B);
+    return DRIN_E_SHAPE;
+  }
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_mention_reduce2, dim3((unsigned)cdiv(D / 4, 64), (unsigned)B), dim3(256), 0, st, w,
+                     (int64_t)B * N, v1, v2, uA, uB, outA, outB, N, D / 4, scale);
+  DRIN_CHECK_LAUNCH("k_mention_reduce2");
   return DRIN_OK;
 }
 

@@ -123,6 +123,9 @@ int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t 
 // out[b,:] = scale (sum_n w1 v1 + sum_n w2 v2) + u      (v2, u optional)
 int launch_mention_reduce(const float* w1, const float* v1, const float* w2, const float* v2, const float* u,
                           float* out, int B, int N, int D, float scale, hipStream_t st);
+// two such reductions over the same rows in one pass: w = [4][B*N]; outA takes planes 0 / 1, outB planes 2 / 3
+int launch_mention_reduce2(const float* w, const float* v1, const float* v2, const float* uA, const float* uB,
+                           float* outA, float* outB, int B, int N, int D, float scale, hipStream_t st);
 // out[p,:] = scale (w1[p] m1[b,:] + w2[p] m2[b,:])       (m2 optional)
 int launch_entity_combine(const float* w1, const float* m1, const float* w2, const float* m2, float* out, int B, int N,
                           int D, float scale, hipStream_t st);

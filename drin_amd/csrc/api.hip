@@ -395,7 +395,11 @@ int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, 
     // the contraction index of dx = dy W is n: the NT kernel needs W^T [k][n_out]
     if (x3 && scratch && scratch_floats >= (size_t)n_out * k && rows >= 1024 && (n_out % 32) == 0 && (k % 4) == 0) {
       DRIN_TRY(launch_transpose(w, scratch, n_out, k, st));
-      DRIN_TRY(launch_gemm_nt_bf16x3(dy, n_out, scratch, n_out, nullptr, dx, k, rows, k, n_out, st));
+      // what the transposed weight leaves of the scratch lets a partly filled last round of tiles split along K
+      const size_t used = ((size_t)n_out * k + 63) & ~(size_t)63;
+      float* tail = scratch_floats > used ? scratch + used : nullptr;
+      DRIN_TRY(launch_gemm_nt_bf16x3(dy, n_out, scratch, n_out, nullptr, dx, k, rows, k, n_out, st, nullptr, nullptr, false,
+                                     false, tail, tail ? scratch_floats - used : 0));
     } else {
       DRIN_TRY(launch_gemm_nn(dy, n_out, w, k, dx, k, rows, k, n_out, false, precision, st));
     }
@@ -456,14 +460,18 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   float* ve0 = ws + L.ve[0];
   float* const sk = L.splitk_floats ? ws + L.splitk : nullptr;  // split-K scratch of the mention-sized products
   const size_t skf = L.splitk_floats;
+  // tail-split scratch of the pair-sized split-bf16 products (training layouts only: the weight-gradient partial
+  // buffer is idle during the forward pass and between the weight-gradient products of the backward pass)
+  float* const tl = L.tn_part_floats ? ws + L.tn_part : nullptr;
+  const size_t tlf = L.tn_part_floats;
   DRIN_TRY(launch_gemm_nt(P.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false,
                           prec, st, sk, skf));
   DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
                           D, B, D, R, false, prec, st, sk, skf));
   DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
-                          prec, st));
+                          prec, st, tl, tlf));
   DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
-                          M, D, R, false, prec, st));
+                          M, D, R, false, prec, st, tl, tlf));
   DRIN_TRY(tap(trace, 0, L, ws, B, M, D, st, EW));
 
   bool all_enabled = true;
@@ -513,7 +521,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     float* h_m = ws + L.h_m[l];
     float* h_e = ws + L.h_e[l];
     DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, sk, skf));
-    DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st));
+    DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st, tl, tlf));
     float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
     float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
     DRIN_TRY(launch_layernorm_gelu(h_m, W.ln_weight, W.ln_bias, ws + L.vm[l + 1], st_m, st_m ? st_m + 2 * (size_t)B : nullptr,
@@ -537,7 +545,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
       DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, sk, skf));
-      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf));
       DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st));
     } else if (!cfg->dynamic_edges) {
       hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -686,7 +694,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     if (x3 && rows >= 1024 && (k_red % 32) == 0 && (n_out % 4) == 0 && (size_t)k_red * n_out <= (size_t)D * D) {
       float* wt = ws + L.wt;
       DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));
-      return launch_gemm_nt_bf16x3(dy, lddy, wt, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate);
+      return launch_gemm_nt_bf16x3(dy, lddy, wt, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate,
+                                   false, tnp, tnf);
     }
     return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st,
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);

@@ -30,6 +30,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 namespace x3 {
 
 constexpr int BK = 32;
+constexpr unsigned kCUs = 256;  // MI355X: the tail split below only changes how the last round of tiles is dealt
 
 // MFMA shape v_mfma_f32_16x16x32_bf16 (one k-step per K-block; +5 % over 32x32x16 at the clock the chip
 // holds, see gemm_x3_planes.hip).  A lane's fragment is row (lane & 15), chunk (lane >> 4); the bank-conflict-
@@ -132,11 +133,17 @@ struct Cfg {
 };
 
 // ONE_PASS (DRIN_PREC_BF16): operands rounded to bf16, hi x hi only - a third of the MFMAs, no lo planes staged.
+// Tail split: the last, partly filled round of workgroups (tiles [full, tiles), fewer than half the CUs) is dealt as
+// `ksplit` work items per tile, each over 1 / ksplit of K.  Part 0 stores to C as usual, the others store raw
+// accumulators to `tail` ([tile - full][ksplit - 1][BM][BN]) and k_tail_add folds them in afterwards, in order.
+// (B = 512 training: 606 tiles on 256 CUs = 2.37 rounds ran as 3; with the 94 tail tiles halved, as 2.5:
+//  same-box A/B of the whole step 8.55 -> 8.44 ms.)
 template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
 __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
                   const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
-                  int64_t ldc, int64_t M, int N, int K, int accumulate) {
+                  int64_t ldc, int64_t M, int N, int K, int accumulate, unsigned col_tiles, unsigned full, int ksplit,
+                  float* __restrict__ tail) {
   using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with
@@ -144,12 +151,33 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   // tile sequence (column index fastest) and A comes from HBM once instead of once per column tile.
   int64_t m0;
   int n0;
+  int kpart = 0;
+  unsigned tail_slot = 0;
   {
-    const unsigned nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned xcd = id & 7, k = id >> 3, q = nwg >> 3, rem = nwg & 7;
-    const unsigned t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;  // measured: -1.4 % on x_i C_i^T
-    n0 = (int)(t % gridDim.x) * BN;
-    m0 = (int64_t)(t / gridDim.x) * BM;
+    const unsigned id = blockIdx.x;
+    unsigned t;
+    if (id < full) {
+      const unsigned xcd = id & 7, k = id >> 3, q = full >> 3, rem = full & 7;
+      t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;  // measured: -1.4 % on x_i C_i^T
+    } else {
+      const unsigned u = id - full;
+      t = full + u / (unsigned)ksplit;
+      kpart = (int)(u % (unsigned)ksplit);
+      tail_slot = (u / (unsigned)ksplit) * (unsigned)(ksplit - 1) + (unsigned)(kpart - 1);
+    }
+    n0 = (int)(t % col_tiles) * BN;
+    m0 = (int64_t)(t / col_tiles) * BM;
+  }
+  if (ksplit > 1 && blockIdx.x >= full) {  // this work item's slice of K
+    K /= ksplit;
+    const int64_t k0 = (int64_t)kpart * K;
+    A += k0;
+    if (W_PLANES) {
+      w_hi += k0;
+      w_lo += k0;
+    } else {
+      W += k0;
+    }
   }
   const int nkb = K / BK;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -240,6 +268,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     __syncthreads();  // also drains the LDS-DMA of this iteration (vmcnt(0))
   }
 
+  if (kpart > 0) {  // raw partial tile into the tail scratch
+    float* part = tail + (size_t)tail_slot * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < G::NI; ++j) {
+        const int col = wn * (BN / WN) + j * 16 + r;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[(wm * (BM / WM) + i * 16 + c * 4 + v) * BN + col] = acc[i][j][v];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < G::MI; ++i)
 #pragma unroll
@@ -258,13 +298,28 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     }
 }
 
+// C[tile] += sum of its ksplit - 1 partial tiles, in order.  Grid (BM rows, tail tiles), BN threads.
+template <int BM, int BN>
+__global__ void __launch_bounds__(BN) k_tail_add(const float* __restrict__ tail, float* __restrict__ C, int64_t ldc,
+                                                 int64_t M, int N, unsigned col_tiles, unsigned full, int ksplit) {
+  const unsigned t = full + blockIdx.y;
+  const int col = (int)(t % col_tiles) * BN + threadIdx.x;
+  const int64_t row = (int64_t)(t / col_tiles) * BM + blockIdx.x;
+  if (row >= M || col >= N) return;
+  const float* part = tail + (size_t)blockIdx.y * (ksplit - 1) * (BM * BN) + (size_t)blockIdx.x * BN + threadIdx.x;
+  float s = C[row * ldc + col];
+  for (int q = 0; q < ksplit - 1; ++q) s += part[(size_t)q * (BM * BN)];
+  C[row * ldc + col] = s;
+}
+
 template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
 static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
-                  const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate) {
+                  const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate,
+                  float* tail = nullptr, size_t tail_floats = 0) {
   using G = Cfg<BM, BN, WM, WN>;
-  const int64_t mt = cdiv(M, BM);
-  if (mt > 65535) {
-    set_error("gemm_bf16x3: %lld row tiles exceed the grid limit; split the batch", (long long)mt);
+  const int64_t mt = cdiv(M, BM), nt = cdiv(N, BN);
+  if (mt * nt > (int64_t)1 << 30) {
+    set_error("gemm_bf16x3: %lld tiles exceed the grid limit; split the batch", (long long)(mt * nt));
     return DRIN_E_SHAPE;
   }
   auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES, ONE_PASS>;
@@ -275,11 +330,31 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16x3)");
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(N, BN), (unsigned)mt);
+  // tail split (one workgroup per CU tiles only): the last round holds `frac` tiles; split K so that it fills the chip
+  const unsigned tiles = (unsigned)(mt * nt);
+  unsigned full = tiles;
+  int ksplit = 1;
+  if (BM == 256 && tail != nullptr && tiles <= 16 * kCUs) {
+    const unsigned frac = tiles % kCUs;
+    const int nkb = K / BK;
+    for (int s = 4; s >= 2 && frac > 0; --s)
+      if ((unsigned)s * frac <= kCUs && nkb % s == 0 && nkb / s >= 4 &&
+          (size_t)frac * (s - 1) * (BM * BN) <= tail_floats) {
+        ksplit = s;
+        full = tiles - frac;
+        break;
+      }
+  }
+  const unsigned items = full + (tiles - full) * (unsigned)ksplit;
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
-  hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi, (const __bf16*)w_lo,
-                     ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(kern, dim3(items), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
+                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
+  if (ksplit > 1) {
+    hipLaunchKernelGGL((k_tail_add<BM, BN>), dim3(BM, tiles - full), dim3(BN), 0, st, tail, y, ldy, M, N, (unsigned)nt,
+                       full, ksplit);
+    DRIN_CHECK_LAUNCH("k_tail_add");
+  }
   return DRIN_OK;
 }
 
@@ -288,7 +363,7 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
 // w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo,
-                          bool accumulate, bool one_pass) {
+                          bool accumulate, bool one_pass, float* tail, size_t tail_floats) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   if ((K % x3::BK) || K <= 0) {  // odd reduction lengths take the exact fp32 kernel (guarded loads)
     if (!w) {
@@ -312,9 +387,10 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
     }
     return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
   }
+  if (tail != nullptr && !aligned16(tail)) tail = nullptr;
   if (big)
-    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate)
-                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
+    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats)
+                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
   return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate)
                 : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
 }

@@ -292,7 +292,7 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
   // split-bf16 contraction for the pair-sized GEMMs; the mention-sized ones (a few hundred rows) stay on
   // the exact fp32 kernel: they are latency-bound, not rate-bound
   if (!accumulate && ((precision == DRIN_PREC_BF16X3 && M >= 256) || precision == DRIN_PREC_BF16X3_ALL))
-    return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, M, N, K, st);
+    return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, M, N, K, st, nullptr, nullptr, false, false, splitk, splitk_floats);
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) precision = DRIN_PREC_F32;
   DRIN_TRY(check_precision(precision, "gemm_nt"));
   if (K % 4) {

@@ -68,7 +68,9 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 // (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi = nullptr,
-                          const void* w_lo = nullptr, bool accumulate = false, bool one_pass = false);
+                          const void* w_lo = nullptr, bool accumulate = false, bool one_pass = false,
+                          float* tail = nullptr, size_t tail_floats = 0);
+// (tail: optional scratch; a partly filled last round of 256 x 256 tiles is then split along K over the idle CUs)
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
 bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, const void* a, const void* b);

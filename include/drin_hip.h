@@ -192,7 +192,9 @@ DRIN_API int drin_linear_fwd(const float* x, const float* w, const float* bias, 
  * `scratch` (`scratch_floats` floats, may be NULL / 0): n_out * k floats hold the transposed weight the split-bf16 dx
  * product runs against (without them dx stays on the exact fp32 kernel); with at least 28 * n_out * k floats the
  * split-bf16 dw product stores its reduction slices there and adds them in order (bit-reproducible) instead of
- * using fp32 atomics.  Small problems take the exact fp32 kernels in every precision. */
+ * using fp32 atomics, and a partly filled last round of 256 x 256 output tiles of the dx product is split along the
+ * reduction over the idle CUs (partial tiles in the scratch behind the transposed weight, added in order).
+ * Small problems take the exact fp32 kernels in every precision. */
 DRIN_API int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                              int64_t rows, int32_t n_out, int32_t k, int32_t precision, float* scratch,
                              size_t scratch_floats, void* stream);

@@ -84,11 +84,18 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float e = 1.0f - poly * __expf(-z * z);  // erf(|x| / sqrt 2)
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
-// d/dx gelu_erf
+// d/dx gelu_erf = Phi(x) + x phi(x).  Branch-free like gelu_fast: the Abramowitz-Stegun erf and the density share one
+// hardware exponential exp(-x^2 / 2); |error| <= 4e-7 against the library erff / expf form (~100 VALU instructions
+// with branches; the LayerNorm backward kernel was half VALU time on it).
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float poly =
+      t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float g = __expf(-0.5f * x * x);  // = exp(-z^2)
+  const float erf_abs = 1.0f - poly * g;
+  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  return fmaf(x * 0.39894228040143267794f, g, cdf);
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 

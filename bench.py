@@ -171,6 +171,21 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
     model.train()
     full = synth.make_device_batch(cfg, B, 200 + rank, dev)
     batch, y = full[:14], full[14]
+    if args.train_form != "gathered":
+        # table form: the entity tables live on the device, a step carries candidate indices.
+        # "table": the library pools every entity's tokens once and gathers pooled rows; "table-tokens": the token
+        # blocks are gathered with torch indexing every step (what the reference's loader does on the host)
+        from drin_amd.model import EntityTable, IndexedBatch
+        E = args.train_entities
+        tab = synth.make_device_batch(cfg.with_(num_candidates_data=E - 1), 1, 300 + rank, dev)
+        table = EntityTable(tab[7][0], tab[8][0] if cfg.token_level_entities else None, tab[9][0], tab[10][0], tab[11][0])
+        del tab
+        g = torch.Generator(device=dev)
+        g.manual_seed(17 + rank)
+        cand = torch.randint(0, E, (B, cfg.num_candidates_model), device=dev, generator=g)
+        ib = IndexedBatch(batch[:7], table, cand, batch[12], batch[13])
+        full = None
+        batch = ib if args.train_form == "table" else None
     loss_fn = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk, dev)   # loss + top-k counters in one library call, as MELRunner
     if args.torch_loss:
         from drin_amd.metrics import TripletLoss
@@ -180,7 +195,7 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
 
     def eager_step():
         opt.zero_grad(set_to_none=True)
-        loss = loss_fn(y, model(batch))
+        loss = loss_fn(y, model(batch if batch is not None else ib.gathered()))
         loss.backward()
         bucket.allreduce_mean()
         opt.step()
@@ -229,7 +244,9 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
             "value": B * N * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)",
+            "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)"
+                                   + ({"gathered": "", "table": f", candidates indexed into a device-resident table of {args.train_entities} entities (tokens pooled once per entity)",
+                                       "table-tokens": f", candidates gathered from a device-resident table of {args.train_entities} entities with torch indexing every step"}[args.train_form]),
                        "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "final_loss": float(loss)}))
@@ -264,6 +281,9 @@ def main():
     ap.add_argument("--mode", default="score", choices=["score", "train"],
                     help="score: the scoring forward (headline metric); train: forward + TripletLoss + backward + "
                          "gradient all-reduce + Adam step (BASELINE configs 3-4), reported under the same unit")
+    ap.add_argument("--train-form", default="gathered", choices=["gathered", "table", "table-tokens"],
+                    help="train mode: per-pair tensors as the reference's loader delivers them (default), or candidate indices into device-resident entity tables")
+    ap.add_argument("--train-entities", type=int, default=50_000, help="rows of the entity tables of --train-form table")
     ap.add_argument("--graph", action="store_true",
                     help="train mode: capture the whole step (forward, loss, backward, Adam) in one hipGraph and replay it")
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")

@@ -42,7 +42,7 @@ class DrinBatchC(C.Structure):
         ("mention_image", C.c_void_p), ("mention_object", C.c_void_p), ("mention_object_score", C.c_void_p),
         ("entity_text", C.c_void_p), ("entity_text_mask", C.c_void_p), ("entity_image", C.c_void_p),
         ("entity_object", C.c_void_p), ("entity_object_score", C.c_void_p), ("miet_similarity", C.c_void_p),
-        ("mtei_similarity", C.c_void_p), ("entity_index", C.c_void_p),
+        ("mtei_similarity", C.c_void_p), ("entity_index", C.c_void_p), ("entity_text_cls", C.c_void_p),
     ]
 
 

@@ -144,8 +144,12 @@ static int validate_batch(const drin_config* c, const drin_batch* b) {
     set_error("batch.entity_text_mask is NULL but entity_tokens=%d", c->entity_tokens);
     return DRIN_E_NULL;
   }
+  if (b->entity_text_cls && c->entity_tokens > 0) {
+    set_error("batch.entity_text_cls goes with pooled entity text (entity_tokens = 0), not with a token block");
+    return DRIN_E_UNSUPPORTED;
+  }
   const void* al[] = {b->mention_text, b->mention_image, b->mention_object, b->entity_text, b->entity_image,
-                      b->entity_object};
+                      b->entity_object, b->entity_text_cls};
   for (const void* p : al)
     if (!aligned16(p)) {
       set_error("batch: feature tensors must be 16-byte aligned");
@@ -238,8 +242,10 @@ int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P,
   const int B = c->batch, N = c->num_candidates;
   const int64_t M = (int64_t)B * N;
   // tt (model.py:71-76), ti = mtei / 100, it = miet / 100 (model.py:203), ii (model.py:78-92)
-  DRIN_TRY(launch_cosine_rows(P.span_mean, b->entity_text, P.entity_text_raw_stride, edges + 0 * M, B, N, c->embed_dim,
-                              c->cosine_eps, 1.0f, st));
+  // (entity_text_cls: the raw rows of a batch whose token means were pooled ahead of time)
+  const float* raw = b->entity_text_cls ? b->entity_text_cls : b->entity_text;
+  const int64_t raw_stride = b->entity_text_cls ? (int64_t)c->embed_dim : P.entity_text_raw_stride;
+  DRIN_TRY(launch_cosine_rows(P.span_mean, raw, raw_stride, edges + 0 * M, B, N, c->embed_dim, c->cosine_eps, 1.0f, st));
   DRIN_TRY(launch_scale_div(b->mtei_similarity, edges + 1 * M, M, 1.0f, c->clip_scale, st));
   DRIN_TRY(launch_scale_div(b->miet_similarity, edges + 2 * M, M, 1.0f, c->clip_scale, st));
   DRIN_TRY(launch_miei(P.mention_object, b->mention_object_score, P.entity_object, b->entity_object_score,
@@ -344,7 +350,25 @@ int drin_edges_fwd(const drin_config* cfg, const drin_batch* batch, float* edges
 int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled_entity_text,
                   float* pooled_mention_image, float* pooled_entity_image, void* stream) {
   DRIN_TRY(validate_config(cfg));
-  DRIN_TRY(validate_batch(cfg, batch));
+  if (!batch) {
+    set_error("batch is NULL");
+    return DRIN_E_NULL;
+  }
+  if (cfg->feature_dtype != DRIN_FEAT_F32) {
+    set_error("drin_pool_fwd: bf16 feature storage is read by drin_forward_prepared only; widen the features to fp32");
+    return DRIN_E_UNSUPPORTED;
+  }
+  // only the inputs of the requested outputs are needed (pooling an entity TABLE once passes the text alone)
+  if ((pooled_entity_text && (!batch->entity_text || !batch->entity_text_mask)) ||
+      (pooled_mention_image && !batch->mention_image) || (pooled_entity_image && !batch->entity_image)) {
+    set_error("drin_pool_fwd: a requested output's input tensor is NULL");
+    return DRIN_E_NULL;
+  }
+  if ((pooled_entity_text && !aligned16(batch->entity_text)) || (pooled_mention_image && !aligned16(batch->mention_image)) ||
+      (pooled_entity_image && !aligned16(batch->entity_image))) {
+    set_error("drin_pool_fwd: feature tensors must be 16-byte aligned");
+    return DRIN_E_ALIGN;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int64_t M = (int64_t)cfg->batch * cfg->num_candidates;
   if (pooled_entity_text) {

@@ -242,6 +242,10 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   // planes from the stream kernel costs it more (measured twice on one box: +1.0 ms at B = 4096) than the LDS-DMA
   // kernel gains on that GEMM (-0.35 ms).  Only the table form, which has to gather the rows anyway, writes them.
   const bool xi_planes = planes && indexed;
+  if (b->entity_text_cls) {
+    set_error("drin_forward_prepared: entity_text_cls (text pooled ahead of time) is a form of the training entry points");
+    return DRIN_E_UNSUPPORTED;
+  }
   if (indexed && cfg->num_entities <= 0) {
     set_error("drin_forward_prepared: entity_index given but cfg.num_entities = %d", cfg->num_entities);
     return DRIN_E_SHAPE;

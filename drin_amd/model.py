@@ -103,6 +103,7 @@ class EntityTable:
         self.cache_enabled = False
         self._cache: Optional[torch.Tensor] = None
         self._cache_key = None
+        self._pooled = None
 
     def enable_cache(self, on: bool = True) -> "EntityTable":
         """Let inference calls score from a per-entity precompute cache (`drin_build_entity_cache`):
@@ -133,6 +134,34 @@ class EntityTable:
     def num_entities(self) -> int:
         return self.text.shape[0]
 
+    @torch.no_grad()
+    def pooled_text(self, cfg: DrinConfig):
+        """`(pooled [E, D], cls [E, D])` of a token-level table: the masked token mean of `ghmfc.py:245-249` and the
+        token-0 row of `model.py:73-75`, per ENTITY.  Neither depends on the weights, so training in table form pools
+        every entity once (library kernel, same arithmetic as the per-pair pooling of a gathered batch: identical
+        values) instead of gathering and pooling 197 KB of tokens per candidate per step."""
+        if self.text.dim() != 3:
+            raise ValueError("pooled_text: the table already holds pooled text [E, D]")
+        if self._pooled is None or self._pooled[0].data_ptr() != self.text.data_ptr():
+            lib = _lib.load()
+            text = self.text.to(torch.float32).contiguous()
+            E, T, D = text.shape
+            mask = self.mask.to(torch.int64).contiguous()
+            pooled = torch.empty(E, D, dtype=torch.float32, device=text.device)
+            c = _lib.DrinConfigC()
+            _lib.check(lib.drin_default_config(C.byref(c)))
+            c.num_candidates, c.embed_dim, c.entity_tokens = 1, D, T
+            stream = torch.cuda.current_stream(text.device).cuda_stream
+            step = 1 << 20
+            for e0 in range(0, E, step):                              # one launch per 2^20 entities
+                e1 = min(E, e0 + step)
+                c.batch = e1 - e0
+                b = _lib.DrinBatchC()
+                b.entity_text, b.entity_text_mask = text[e0:e1].data_ptr(), mask[e0:e1].data_ptr()
+                _lib.check(lib.drin_pool_fwd(C.byref(c), C.byref(b), pooled[e0:e1].data_ptr(), None, None, stream))
+            self._pooled = (self.text, pooled, text[:, 0, :])
+        return self._pooled[1], self._pooled[2]
+
     def to(self, device) -> "EntityTable":
         mv = lambda t: None if t is None else t.to(device)  # noqa: E731
         moved = EntityTable(mv(self.text), mv(self.mask), mv(self.image), mv(self.object), mv(self.object_score))
@@ -160,14 +189,27 @@ class IndexedBatch:
         """The equivalent 14-sequence (entity rows materialised with torch indexing)."""
         return self.mention + self.table.gather(self.candidates) + [self.miet_similarity, self.mtei_similarity]
 
+    def gathered_pooled(self, cfg: DrinConfig):
+        """`(14-sequence with pooled entity text [B, N, D], cls rows [B, N, D])`: what a training step needs of a
+        token-level table - 22 KB per candidate instead of 219 KB, and no per-step token pooling."""
+        t, idx = self.table, self.candidates
+        pooled, cls = t.pooled_text(cfg)
+        dummy = torch.zeros(idx.shape[0], dtype=torch.int64, device=idx.device)
+        seq = self.mention + [pooled[idx], dummy, t.image[idx], t.object[idx], t.object_score[idx],
+                              self.miet_similarity, self.mtei_similarity]
+        return seq, cls[idx]
+
 
 class _Call:
     """One forward's C structs; keeps the tensors they point into alive."""
 
     def __init__(self, cfg: DrinConfig, batch: Sequence[torch.Tensor], precision: int,
-                 entity_index: Optional[torch.Tensor] = None, keep_bf16: bool = False):
+                 entity_index: Optional[torch.Tensor] = None, keep_bf16: bool = False,
+                 entity_text_cls: Optional[torch.Tensor] = None):
         """`keep_bf16`: the caller will take a path that reads bf16-stored features in place (fused inference);
-        otherwise bf16 features are widened to fp32 here (exact) - e.g. for training."""
+        otherwise bf16 features are widened to fp32 here (exact) - e.g. for training.
+        `entity_text_cls` `[B, N, D]`: the token-0 rows of the text-text edge when `entity_text_feature` holds token
+        means pooled ahead of time (`EntityTable.pooled_text`)."""
         if len(batch) not in (14, 15):
             raise ValueError(f"batch must be the 14-sequence of drin/data.py:110-126 (got {len(batch)} items)")
         (mtf, _mask, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei) = batch[:14]
@@ -243,7 +285,14 @@ class _Call:
                 raise ValueError(f"entity_text_mask has shape {tuple(emask.shape)}, expected {tuple(etf.shape[:3])}")
         else:
             emask = None
-        self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei, entity_index]
+        if entity_text_cls is not None:
+            if token_level or table:
+                raise ValueError("entity_text_cls goes with pooled per-pair entity text [B, N, D]")
+            entity_text_cls = f32(entity_text_cls)
+            if tuple(entity_text_cls.shape) != (B, N, D):
+                raise ValueError(f"entity_text_cls has shape {tuple(entity_text_cls.shape)}, expected {(B, N, D)}")
+        self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei, entity_index,
+                     entity_text_cls]
         self.device = dev
         self.B, self.N, self.D = B, N, D
         c = _lib.DrinConfigC()
@@ -271,7 +320,7 @@ class _Call:
         for name, t in zip(("mention_text", "mention_start", "mention_end", "mention_image", "mention_object",
                             "mention_object_score", "entity_text", "entity_text_mask", "entity_image",
                             "entity_object", "entity_object_score", "miet_similarity", "mtei_similarity",
-                            "entity_index"), self.keep):
+                            "entity_index", "entity_text_cls"), self.keep):
             setattr(b, name, _ptr(t))
         self.batch = b
 
@@ -372,6 +421,7 @@ class Model(nn.Module):
 
     def forward(self, batch) -> torch.Tensor:
         params = _param_list(self)
+        cls = None
         if isinstance(batch, IndexedBatch):
             # table form: inference gathers inside the stream kernel; everything else (training,
             # exact-fp32 precision, geometries off the fused path) gathers with torch indexing first
@@ -391,7 +441,11 @@ class Model(nn.Module):
                         return self._forward_cached(call, t, params)
                     if planes:
                         return _DrinScore.apply(call, self._prepared, False, *params)
-            batch = batch.gathered()
+            if not inference and t.text.dim() == 3 and t.text.dtype == torch.float32:
+                # training on a token-level table: pool per entity once, gather pooled rows
+                batch, cls = batch.gathered_pooled(self.cfg)
+            else:
+                batch = batch.gathered()
         # grad mode is already off inside Function.forward (and needs_input_grad ignores no_grad), so the
         # caller's mode is read here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
@@ -401,6 +455,12 @@ class Model(nn.Module):
                     and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16))
         # "bf16" is a mode of the fused inference path; anything else it meets runs split-bf16
         prec = self.precision if (in_place or self.precision != _lib.PREC_BF16) else _lib.PREC_BF16X3
+        if cls is not None:
+            # pooled-ahead batch: the layer-by-layer entry points (the fused path folds the pooling into its one pass)
+            call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec, entity_text_cls=cls)
+            if call.B == 0:
+                return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
+            return _DrinScore.apply(call, None, training, *params)
         call = _Call(self.cfg, batch, prec, keep_bf16=in_place)
         if ((call.cfg.feature_dtype != _lib.FEAT_F32 or prec == _lib.PREC_BF16)
                 and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK):

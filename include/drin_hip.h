@@ -116,6 +116,12 @@ typedef struct {
    * entity_index[b, n] (clamped to [0, E-1]) instead of row b*N + n.  Taken by drin_forward_prepared;
    * drin_forward / drin_backward need the gathered per-pair tensors. */
   const int64_t* entity_index;        /* [B, N] or NULL                                          */
+  /* Optional, T == 0 only: the rows the text-text edge compares the mention span with (model.py:73-75: token 0 of
+   * the WikiMEL token block) when entity_text carries token means POOLED AHEAD OF TIME - the pooling of
+   * ghmfc.py:245-249 has no weights, so a training loop over an entity table can pool every entity once instead of
+   * every candidate every step.  NULL: the edge reads entity_text itself (the WikiDiverse layout).
+   * drin_forward / drin_backward / drin_edges_fwd; the fused inference entry points return DRIN_E_UNSUPPORTED. */
+  const float* entity_text_cls;       /* [B, N, D] or NULL                                       */
 } drin_batch;
 
 /* One GCNLayer's parameters (drin/model.py:109-119); nn.Linear layout weight[out][in]. */

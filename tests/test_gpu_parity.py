@@ -654,14 +654,44 @@ def test_indexed_batch_matches_gathered_batch(token_level):
     # training through the table form: same gradients as through the gathered tensors
     model = Model(cfg).to(DEV)
     model.load_state_dict(sd)
-    model(ib).sum().backward()
+    s1 = model(ib)
+    s1.sum().backward()
     g1 = [p.grad.clone() if p.grad is not None else None for p in model.parameters()]
     model.zero_grad()
-    model(gathered).sum().backward()
+    s2 = model(gathered)
+    s2.sum().backward()
+    assert torch.equal(s1, s2)
     for x, p in zip(g1, model.parameters()):
         assert (x is None) == (p.grad is None)
         if x is not None:
             assert torch.allclose(x, p.grad, rtol=1e-4, atol=1e-6)
+    if token_level:
+        # the training step took the pooled-ahead form: every entity's token mean computed once, by the library
+        pooled, cls = table.pooled_text(cfg)
+        assert table._pooled is not None and pooled.shape == (E, cfg.bert_embed_dim)
+        ref_pool = O.entity_token_mean(table.text.cpu().unsqueeze(0), table.mask.cpu().unsqueeze(0))[0]
+        np.testing.assert_allclose(pooled.cpu().numpy(), ref_pool.numpy(), atol=1e-6)
+        assert torch.equal(cls, table.text[:, 0, :])
+        # and the C ABI refuses the combinations it does not implement
+        from drin_amd.model import _Call
+        seq, cls_rows = ib.gathered_pooled(cfg)
+        call = _Call(cfg, seq, _lib.PREC_BF16X3, entity_text_cls=cls_rows)
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        edges = torch.empty(4, B, N, device=DEV)
+        span = torch.empty(B, cfg.bert_embed_dim, device=DEV)
+        _lib.check(lib.drin_edges_fwd(C.byref(call.cfg), C.byref(call.batch), edges.data_ptr(), span.data_ptr(), st))
+        full = _Call(cfg, gathered, _lib.PREC_BF16X3)
+        edges2 = torch.empty_like(edges)
+        _lib.check(lib.drin_edges_fwd(C.byref(full.cfg), C.byref(full.batch), edges2.data_ptr(), span.data_ptr(), st))
+        assert torch.equal(edges, edges2)
+        full.batch.entity_text_cls = cls_rows.data_ptr()               # token block + cls rows: not a form of the ABI
+        assert lib.drin_edges_fwd(C.byref(full.cfg), C.byref(full.batch), edges2.data_ptr(), span.data_ptr(), st) == _lib.E_UNSUPPORTED
+        assert lib.drin_fused_supported(C.byref(call.cfg)) == _lib.OK
+        ws = torch.empty(max(lib.drin_fused_workspace_bytes(C.byref(call.cfg)), 16), dtype=torch.uint8, device=DEV)
+        sc = torch.empty(B, N, device=DEV)
+        rc = lib.drin_forward_prepared(C.byref(call.cfg), C.byref(call.batch), None, None, ws.data_ptr(), ws.numel(), sc.data_ptr(), st)
+        assert rc in (_lib.E_UNSUPPORTED, _lib.E_NULL)
 
 
 def test_indexed_loader_and_runner(tmp_path):

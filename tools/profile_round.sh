@@ -13,6 +13,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.
 python3 tools/collect_pmc.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic.json > $O/hbm_traffic.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tab -- python3 bench.py --workload table --batch 256 --entity-cache --steps 10 --warmup 3 --no-cpu-baseline > $O/table_cache_bench_under_rocprof.json 2> $O/tab.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 3 > $O/train64_bench_under_rocprof.json 2> $O/train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train512 -- python3 bench.py --mode train --batch 512 --steps 20 --warmup 30 > $O/train512_bench_under_rocprof.json 2> $O/train512.err
+python3 bench.py --mode train --batch 512 --train-form table > $O/train512_table_bench.json 2> $O/train512_table.err
 python3 bench.py --workload wikidiverse --no-cpu-baseline > $O/wd_bench.json 2> $O/wd.err
 python3 bench.py --features bf16 --no-cpu-baseline > $O/wm_bf16_features_bench.json 2> $O/wmbf.err
 ls $O

@@ -108,3 +108,27 @@ def test_plain_c_abi_example_builds(tmp_path):
                         f"-L{REPO}/drin_amd", "-ldrin_hip", f"-Wl,-rpath,{REPO}/drin_amd", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.exists(exe)
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """Every struct of include/drin_hip.h as a plain C compiler lays it out == its ctypes mirror in drin_amd/_lib.py
+    (size and the offset of every field): the binding a maintainer writes from the header alone stays in step."""
+    pairs = [("drin_config", _lib.DrinConfigC), ("drin_batch", _lib.DrinBatchC), ("drin_layer_params", _lib.DrinLayerParamsC),
+             ("drin_params", _lib.DrinParamsC), ("drin_param_grads", _lib.DrinParamGradsC), ("drin_trace", _lib.DrinTraceC)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-o", str(exe), str(src)], check=True)   # the header is plain C
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert int(got[f"{cname}.{field}"]) == getattr(cls, field).offset, f"{cname}.{field}"
+    # and the header declares no field the mirror lacks (sizes equal + every mirrored field at its offset + no padding holes)
+    assert C.sizeof(_lib.DrinBatchC) == 8 * len(_lib.DrinBatchC._fields_)

@@ -422,7 +422,8 @@ def main():
             if dom == "gemm_planes":
                 step_flops = pairs_per_step * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
             elif dom == "gemm_x3" and fused:
-                step_flops = pairs_per_step * 2.0 * R * D                # x_i C_i^T (+ large mention-side problems)
+                # x_i C_i^T plus the mention-sized products, which run on the same kernel from 256 rows up
+                step_flops = pairs_per_step * 2.0 * R * D + (mention_flops(D, R, fused) * B if (x3 and B >= 256) else 0.0)
             else:
                 step_flops = flops_pair * pairs_per_step + mention_flops(D, R, fused) * B
             achieved = step_flops * args.steps / (ms * 1e-3) / 1e12

@@ -190,7 +190,7 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
     if args.torch_loss:
         from drin_amd.metrics import TripletLoss
         loss_fn = TripletLoss(cfg.triplet_margin)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=args.graph)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=args.graph, **({"fused": True} if args.fused_adam else {}))   # default: as train.py:55-56
     bucket = GradBucket(list(model.parameters()))
 
     def eager_step():
@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--train-entities", type=int, default=50_000, help="rows of the entity tables of --train-form table")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (score: the scoring call; train: forward, loss, backward, Adam) in one hipGraph and replay it")
+    ap.add_argument("--fused-adam", action="store_true", help="train mode: torch's fused single-kernel Adam instead of its default multi-tensor one (7 launches): -0.27 ms per step, different rounding")
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

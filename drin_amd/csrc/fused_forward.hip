@@ -27,7 +27,7 @@ namespace drin {
 
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
-      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, splitk, splitk_floats, total;
+      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, splitk, splitk_floats, pair_splitk, pair_splitk_floats, total;
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
@@ -70,6 +70,9 @@ struct FusedLayout {  // workspace offsets in floats
     // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
     splitk_floats = 2 * B <= 512 ? 8 * 2 * B * (D + R) : 0;
     splitk = take(splitk_floats);
+    // ... and of the pair-sized split-bf16 products when the whole batch is a handful of tiles (<= 2048 pairs)
+    pair_splitk_floats = (planes && M <= 2048) ? (M <= 512 ? 16 : 8) * ((M + 255) / 256 * 256) * D : 0;
+    pair_splitk = take(pair_splitk_floats);
     total = off;
   }
 };
@@ -364,20 +367,22 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
   DRIN_TRY(lin(vm1, D, L2.w_h, D, P.p_wh2, DD, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D));
   // (5) the two pair-sized layer-1 contractions on the folded weights
+  float* const psk = L.pair_splitk_floats ? ws + L.pair_splitk : nullptr;  // split-K scratch when the batch is a few tiles
+  const size_t pskf = L.pair_splitk_floats;
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
     DRIN_TRY(launch_gemm_x3_planes(xt_hi, (xt_exact || one_pass) ? nullptr : xt_hi + MD, D, ct,
-                                   one_pass ? nullptr : ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st));
+                                   one_pass ? nullptr : ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st, psk, pskf));
     if (xi_planes)
       DRIN_TRY(launch_gemm_x3_planes(xi_hi, (bf16_feat || one_pass) ? nullptr : xi_hi + MR, R, ci,
-                                     one_pass ? nullptr : ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st));
+                                     one_pass ? nullptr : ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st, psk, pskf));
     else if (bf16_feat)  // the bf16 image rows are read in place as the (only) plane of the A operand
       DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, one_pass ? nullptr : ci + (size_t)D * R, R, nullptr,
-                                     ws + L.h_image, D, M, D, R, st));
+                                     ws + L.h_image, D, M, D, R, st, psk, pskf));
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
-                                     ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192));
+                                     ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192, psk, pskf));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
@@ -417,7 +422,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   if (planes) {
     const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
     DRIN_TRY(launch_gemm_x3_planes(e1_hi, one_pass ? nullptr : e1_hi + MD, D, w2, one_pass ? nullptr : w2 + (size_t)D * D, D,
-                                   nullptr, h2, D, M, D, D, st));
+                                   nullptr, h2, D, M, D, D, st, psk, pskf));
   } else {
     DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
   }

@@ -345,6 +345,17 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
         break;
       }
   }
+  if (BM == 64 && tail != nullptr && tiles <= 128) {
+    // a handful of mentions (101 rows x 768 x 2048: 12 tiles walking 64 K-blocks each, 75 us): every tile splits K
+    const int nkb = K / BK;
+    for (int s = 16; s >= 2; s >>= 1)
+      if ((unsigned)s * tiles <= 2 * kCUs && nkb % s == 0 && nkb / s >= 4 &&
+          (size_t)tiles * (s - 1) * (BM * BN) <= tail_floats) {
+        ksplit = s;
+        full = 0;
+        break;
+      }
+  }
   const unsigned items = full + (tiles - full) * (unsigned)ksplit;
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(kern, dim3(items), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
@@ -391,8 +402,8 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   if (big)
     return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats)
                   : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
-  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate)
-                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
+  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats)
+                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
 }
 
 }  // namespace drin

@@ -262,6 +262,15 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   st4(dst, s);
 }
 
+int launch_splitk_reduce(const float* partial, int splits, int64_t part_stride, const float* bias, float* y, int64_t ldy,
+                         int64_t M, int N, bool accumulate, hipStream_t st) {
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, st, partial, splits, part_stride,
+                     bias, y, ldy, M, N / 4, accumulate ? 1 : 0);
+  DRIN_CHECK_LAUNCH("k_splitk_reduce");
+  return DRIN_OK;
+}
+
 // mention-sized fp32 products with a long reduction: split K over workgroups into `scratch`, then reduce in order
 template <bool B_KMAJOR>
 static int launch_small_splitk(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
@@ -274,11 +283,7 @@ static int launch_small_splitk(const float* x, int64_t ldx, const float* w, int6
   int used = 1;
   DRIN_TRY((launch<64, 64, false, B_KMAJOR>(x, ldx, w, ldw, nullptr, scratch, N, M, N, K, splits, GEMM_PARTIAL, st, what,
                                             part_stride, &used)));
-  KernelTimer timer(DRIN_KC_GEMM, st);
-  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, st, scratch, used, part_stride,
-                     bias, y, ldy, M, N / 4, accumulate ? 1 : 0);
-  DRIN_CHECK_LAUNCH("k_splitk_reduce");
-  return DRIN_OK;
+  return launch_splitk_reduce(scratch, used, part_stride, bias, y, ldy, M, N, accumulate, st);
 }
 
 static bool small_splitk_fits(int64_t M, int N, int K, int64_t ldy, const float* y, float* scratch, size_t scratch_floats) {

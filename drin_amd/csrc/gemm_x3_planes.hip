@@ -117,8 +117,20 @@ template <bool A_LO, bool B_LO>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                        const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
-                       const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K) {
+                       const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+                       int64_t part_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (gridDim.z > 1) {  // split K (small problems): slice blockIdx.z of the reduction, raw partial tile to scratch
+    K /= (int)gridDim.z;
+    const int64_t k0 = (int64_t)blockIdx.z * K;
+    a_hi += k0;
+    if (A_LO) a_lo += k0;
+    b_hi += k0;
+    if (B_LO) b_lo += k0;
+    C += (int64_t)blockIdx.z * part_stride;
+    ldc = N;
+    bias = nullptr;
+  }
 #ifdef DRIN_STAMPS
   const unsigned long long t_start = __builtin_readcyclecounter();
 #endif
@@ -280,7 +292,7 @@ int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream
 
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
-                          hipStream_t st) {
+                          hipStream_t st, float* splitk, size_t splitk_floats) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   const bool a_lo_plane = a_lo != nullptr;  // NULL: A is exact in bf16 (one plane, two MFMAs per tile pair)
   const bool b_lo_plane = b_lo != nullptr;  // NULL too: plain bf16 contraction (DRIN_PREC_BF16), one MFMA
@@ -309,19 +321,36 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_x3_planes)");
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(N, x3p::BN), (unsigned)mt);
-  KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
-  const __bf16 *ah = (const __bf16*)a_hi, *al = (const __bf16*)a_lo, *bh = (const __bf16*)b_hi, *bl = (const __bf16*)b_lo;
-  if (a_lo_plane)
-    hipLaunchKernelGGL((x3p::k_gemm_x3_planes<true, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh, bl,
-                       ldb, bias, y, ldy, M, N, K);
-  else if (b_lo_plane)
-    hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh, bl,
-                       ldb, bias, y, ldy, M, N, K);
-  else
-    hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, false>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
-                       bl, ldb, bias, y, ldy, M, N, K);
-  DRIN_CHECK_LAUNCH("k_gemm_x3_planes");
+  // A handful of mentions is a handful of tiles walking K serially (101 rows x 768 x 768: 3 workgroups, 50 us): split K
+  // over workgroups into scratch and add the slices in order (deterministic), as the mention-sized fp32 products do.
+  int splits = 1;
+  const int nkb = K / x3p::BK;
+  const int64_t tiles = mt * cdiv(N, x3p::BN);
+  if (splitk != nullptr && tiles <= 32 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && aligned16(splitk)) {
+    for (int s = 16; s >= 2; s >>= 1)
+      if (tiles * s <= 256 && nkb % s == 0 && nkb / s >= 3 && (size_t)s * M * N <= splitk_floats) {
+        splits = s;
+        break;
+      }
+  }
+  dim3 grid((unsigned)cdiv(N, x3p::BN), (unsigned)mt, (unsigned)splits);
+  const int64_t part_stride = M * (int64_t)N;
+  float* out = splits > 1 ? splitk : y;
+  {
+    KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
+    const __bf16 *ah = (const __bf16*)a_hi, *al = (const __bf16*)a_lo, *bh = (const __bf16*)b_hi, *bl = (const __bf16*)b_lo;
+    if (a_lo_plane)
+      hipLaunchKernelGGL((x3p::k_gemm_x3_planes<true, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
+                         bl, ldb, bias, out, ldy, M, N, K, part_stride);
+    else if (b_lo_plane)
+      hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
+                         bl, ldb, bias, out, ldy, M, N, K, part_stride);
+    else
+      hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, false>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
+                         bl, ldb, bias, out, ldy, M, N, K, part_stride);
+    DRIN_CHECK_LAUNCH("k_gemm_x3_planes");
+  }
+  if (splits > 1) DRIN_TRY(launch_splitk_reduce(splitk, splits, part_stride, bias, y, ldy, M, N, false, st));
   return DRIN_OK;
 }
 

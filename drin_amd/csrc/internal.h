@@ -82,7 +82,10 @@ int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t l
 // (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
-                          hipStream_t st);
+                          hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
+// y[m, n] (+)= bias[n] + sum_z partial[z][m][n] in order (the reduction step of every split-K product; gemm_f32.hip)
+int launch_splitk_reduce(const float* partial, int splits, int64_t part_stride, const float* bias, float* y, int64_t ldy,
+                         int64_t M, int N, bool accumulate, hipStream_t st);
 // fp32 -> bf16 hi / lo planes (n % 4 == 0)
 int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream_t st);
 // y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)

@@ -277,7 +277,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
                  const float* bias, float* y, int64_t ldy, int64_t rows, int n_out, int k) -> int {
     if (planes && (rows >= 256 || prec == DRIN_PREC_BF16X3_ALL) && (k % 32) == 0 && (ldw % 8) == 0) {
       const __bf16* hi = reinterpret_cast<const __bf16*>(pb + plane_off);
-      return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, st, hi, hi + plane_elems);
+      return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, st, hi, hi + plane_elems, false, false,
+                                   L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
     }
     return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, false, prec, st,
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);

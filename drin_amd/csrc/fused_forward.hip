@@ -68,7 +68,10 @@ struct FusedLayout {  // workspace offsets in floats
     p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
     // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
+    // (in split-bf16 precision at least 128 partial 256 x 256 tiles, so that a partly filled last round of tiles of the
+    //  larger products can split K over the idle CUs - gemm_bf16x3.hip)
     splitk_floats = 2 * B <= 512 ? 8 * 2 * B * (D + R) : 0;
+    if (planes && splitk_floats < (size_t)128 * 65536) splitk_floats = (size_t)128 * 65536;
     splitk = take(splitk_floats);
     // ... and of the pair-sized split-bf16 products when the whole batch is a handful of tiles (<= 2048 pairs)
     pair_splitk_floats = (planes && M <= 2048) ? (M <= 512 ? 16 : 8) * ((M + 255) / 256 * 256) * D : 0;
@@ -383,7 +386,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
                                      ws + L.h_image, D, M, D, R, st, psk, pskf));
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
-                                     ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192, psk, pskf));
+                                     ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192,
+                                     psk ? psk : ws + L.splitk, psk ? pskf : L.splitk_floats));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));

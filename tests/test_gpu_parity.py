@@ -1171,3 +1171,36 @@ def test_runner_with_device_loss_matches_torch_loss(tmp_path):
         hist[fused] = runner.fit(loaders, num_epoch=2, test_epoch_interval=2)
     for a, b in zip(hist[True].train + hist[True].valid + hist[True].test, hist[False].train + hist[False].valid + hist[False].test):
         assert abs(a.loss - b.loss) <= 2e-5 and a.topk == pytest.approx(b.topk, abs=1e-9)
+
+
+def test_table_rows_beyond_2_31_elements():
+    """A token-level entity table of 60 000 rows (11.8 GB: element offsets pass 2^31 from row 43 691 on) gathered inside
+    the stream kernel, and pooled once per entity for training, scores exactly like the gathered 14-sequence."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=100)
+    E, B, N = 60_000, 3, cfg.num_candidates_model
+    T, D, R = cfg.max_entity_attr_token_len, cfg.bert_embed_dim, cfg.resnet_embed_dim
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    text = torch.randn(E, T, D, device=DEV, generator=g)
+    ntok = torch.randint(4, T + 1, (E,), device=DEV, generator=g)
+    mask = (torch.arange(T, device=DEV)[None] < ntok[:, None]).to(torch.int64)
+    table = EntityTable(text, mask, torch.randn(E, 1, R, device=DEV, generator=g), torch.randn(E, 1, 1, R, device=DEV, generator=g),
+                        torch.rand(E, 1, device=DEV, generator=g))
+    men = synth.make_device_batch(cfg, B, 9, DEV)
+    cand = torch.randint(43_691, E, (B, N), device=DEV, generator=g)     # every candidate beyond the 32-bit offset range
+    cand[0, :4] = torch.tensor([0, E - 1, 43_690, 43_691], device=DEV)
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    sd = synth.make_state_dict(cfg, 3)
+    model = Model(cfg, precision="bf16x3").to(DEV)
+    model.load_state_dict(sd)
+    gathered = ib.gathered()
+    with torch.no_grad():
+        model.eval()
+        assert torch.equal(model(ib), model(gathered))
+    model.train()
+    a = model(ib)                                                         # pooled once per entity
+    b = model(gathered)
+    assert torch.equal(a, b)
+    del table, text
+    torch.cuda.empty_cache()

@@ -6,7 +6,10 @@
 // case.bin (written by tests/test_gpu_parity.py::test_c_abi_caller_without_torch): 12 int32 of geometry
 // (B N D R L P Km Ke T dynamic layers reserved), then the 13 batch tensors in drin_batch order (fp32 / int64), then
 // the parameters in the order of drin_params (vertex encoder, then per layer w_h b_h w_u b_u w_v b_v ln_w ln_b).
-// scores.bin: B*N fp32 from drin_forward (layer by layer) followed by B*N fp32 from drin_prepare + drin_forward_prepared.
+// When the 12th geometry word is 1, the answer tensor [B, N-1] uint8 follows the parameters.
+// scores.bin: B*N fp32 from drin_forward (layer by layer) followed by B*N fp32 from drin_prepare + drin_forward_prepared;
+// with an answer tensor then also one training step's device work (train.py:30-37): the TripletLoss value (1 fp32), the
+// top-1 hit count (1 fp32) and the gradient of every parameter tensor in drin_params order (fp32; dead ones all zero).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -115,6 +118,7 @@ int main(int argc, char** argv) {
     p.layer[l].ln_weight = (const float*)upload(f, D * 4);
     p.layer[l].ln_bias = (const float*)upload(f, D * 4);
   }
+  const uint8_t* answer = g[11] == 1 ? (const uint8_t*)upload(f, (size_t)(B * (N - 1))) : nullptr;
   fclose(f);
 
   hipStream_t st;
@@ -148,6 +152,80 @@ int main(int argc, char** argv) {
   std::vector<float> out(2 * M, 0.f);
   HIP_OK(hipMemcpy(out.data(), scores_a, M * 4, hipMemcpyDeviceToHost));
   if (have_b) HIP_OK(hipMemcpy(out.data() + M, scores_b, M * 4, hipMemcpyDeviceToHost));
+
+  // (3) the device work of one training step (train.py:30-37): forward keeping what backward reads, TripletLoss +
+  //     top-1 + d loss / d scores in one call, backward into caller-owned gradient buffers
+  if (answer != nullptr) {
+    const size_t tw = drin_workspace_bytes(&cfg, 1), lw = drin_loss_workspace_bytes((int32_t)B);
+    void *tws = nullptr, *lws = nullptr;
+    float *scores_t = nullptr, *loss = nullptr, *d_scores = nullptr;
+    int64_t* correct = nullptr;
+    HIP_OK(hipMalloc(&tws, tw));
+    HIP_OK(hipMalloc(&lws, lw));
+    HIP_OK(hipMalloc((void**)&scores_t, M * 4));
+    HIP_OK(hipMalloc((void**)&loss, 4));
+    HIP_OK(hipMalloc((void**)&d_scores, M * 4));
+    HIP_OK(hipMalloc((void**)&correct, 8));
+    HIP_OK(hipMemsetAsync(correct, 0, 8, st));
+    // gradient buffers: one zeroed arena, carved in drin_params order
+    std::vector<size_t> sizes = {(size_t)(D * D), (size_t)D, (size_t)(D * D), (size_t)D, (size_t)(D * R), (size_t)D, (size_t)(D * R), (size_t)D};
+    for (int l = 0; l < cfg.num_layers; ++l)
+      for (size_t n : {(size_t)(D * D), (size_t)D, (size_t)(D * D), (size_t)D, (size_t)(D * D), (size_t)D, (size_t)D, (size_t)D}) sizes.push_back(n);
+    size_t total = 0;
+    for (size_t n : sizes) total += (n + 63) & ~(size_t)63;
+    float* arena = nullptr;
+    HIP_OK(hipMalloc((void**)&arena, total * 4));
+    HIP_OK(hipMemsetAsync(arena, 0, total * 4, st));
+    std::vector<float*> gp;
+    {
+      size_t off = 0;
+      for (size_t n : sizes) {
+        gp.push_back(arena + off);
+        off += (n + 63) & ~(size_t)63;
+      }
+    }
+    drin_param_grads gr;
+    memset(&gr, 0, sizeof(gr));
+    gr.w_mention_text = gp[0];
+    gr.b_mention_text = gp[1];
+    gr.w_entity_text = gp[2];
+    gr.b_entity_text = gp[3];
+    gr.w_mention_image = gp[4];
+    gr.b_mention_image = gp[5];
+    gr.w_entity_image = gp[6];
+    gr.b_entity_image = gp[7];
+    for (int l = 0; l < cfg.num_layers; ++l) {
+      float** q = &gp[8 + 8 * l];
+      gr.layer[l].w_h = q[0];
+      gr.layer[l].b_h = q[1];
+      // the last layer's edge update never reaches the score (model.py:130-134): its w_u / w_v get no gradient
+      const bool live = cfg.dynamic_edges && l + 1 < cfg.num_layers;
+      gr.layer[l].w_u = live ? q[2] : nullptr;
+      gr.layer[l].b_u = live ? q[3] : nullptr;
+      gr.layer[l].w_v = live ? q[4] : nullptr;
+      gr.layer[l].b_v = live ? q[5] : nullptr;
+      gr.layer[l].ln_weight = q[6];
+      gr.layer[l].ln_bias = q[7];
+    }
+    const int32_t topk[1] = {1};
+    DRIN_OK_(drin_forward(&cfg, &b, &p, tws, tw, scores_t, 1, nullptr, st));
+    DRIN_OK_(drin_triplet_topk(scores_t, answer, (int32_t)B, (int32_t)N, 0.25f, topk, 1, loss, d_scores, correct, lws, lw, st));
+    DRIN_OK_(drin_backward(&cfg, &b, &p, tws, tw, d_scores, &gr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    float h_loss = 0.f;
+    int64_t h_correct = 0;
+    HIP_OK(hipMemcpy(&h_loss, loss, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&h_correct, correct, 8, hipMemcpyDeviceToHost));
+    out.push_back(h_loss);
+    out.push_back((float)h_correct);
+    for (size_t i = 0; i < sizes.size(); ++i) {
+      const size_t at = out.size();
+      out.resize(at + sizes[i]);
+      HIP_OK(hipMemcpy(out.data() + at, gp[i], sizes[i] * 4, hipMemcpyDeviceToHost));
+    }
+    printf("training step: loss %.7f, top-1 hits %lld of %lld\n", h_loss, (long long)h_correct, (long long)B);
+    for (void* d : {tws, lws, (void*)scores_t, (void*)loss, (void*)d_scores, (void*)correct, (void*)arena}) (void)hipFree(d);
+  }
   FILE* o = fopen(argv[2], "wb");
   if (!o || fwrite(out.data(), 4, out.size(), o) != out.size()) return 6;
   fclose(o);

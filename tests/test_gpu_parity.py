@@ -429,19 +429,23 @@ def test_c_abi_caller_without_torch(tmp_path, name):
     B, N, D, R = batch[0].shape[0], cfg.num_candidates_model, cfg.bert_embed_dim, cfg.resnet_embed_dim
     T = cfg.max_entity_attr_token_len if cfg.token_level_entities else 0
     blob = struct.pack("12i", B, N, D, R, cfg.max_mention_sentence_len, cfg.resnet_num_region, cfg.object_topk_mention,
-                       cfg.object_topk_entity, T, int(cfg.gcn_edge_type == "dynamic"), cfg.num_gcn_layers, 0)
+                       cfg.object_topk_entity, T, int(cfg.gcn_edge_type == "dynamic"), cfg.num_gcn_layers, 1)
     order = [0, 2, 3, 4, 5, 6, 7] + ([8] if T else []) + [9, 10, 11, 12, 13]      # drin_batch order (mask only when token-level)
     for i in order:
         blob += batch[i].contiguous().numpy().tobytes()
     for k in synth.STATE_DICT_SHAPES(D, R, cfg.num_gcn_layers):
         blob += sd[k[0]].contiguous().numpy().tobytes()
+    answer = batch[14].to(torch.uint8).contiguous()
+    blob += answer.numpy().tobytes()
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "scores.bin")
     open(case, "wb").write(blob)
     dbatch = _to_dev(batch[:14])
+    from drin_amd.metrics import DeviceLossMetric
     for prec_arg, prec in (("f32", "f32"), ("bf16x3", "bf16x3_all")):
         r = subprocess.run([exe, case, out, prec_arg], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
-        got = torch.from_numpy(np.fromfile(out, dtype=np.float32).reshape(2, B, N))
+        flat = torch.from_numpy(np.fromfile(out, dtype=np.float32))
+        got = flat[:2 * B * N].reshape(2, B, N)
         with torch.no_grad():
             layerwise = Model(cfg, precision=prec, fused=False).to(DEV).eval()
             layerwise.load_state_dict(sd)
@@ -449,6 +453,25 @@ def test_c_abi_caller_without_torch(tmp_path, name):
             folded.load_state_dict(sd)
             assert torch.equal(got[0], layerwise(dbatch).cpu()), prec
             assert torch.equal(got[1], folded(dbatch).cpu()), prec
+        # the training step's device work through the same three entry points the Module's autograd edge uses
+        layerwise.train()
+        metric = DeviceLossMetric(cfg.triplet_margin, (1,), DEV)
+        loss = metric(answer.to(DEV), layerwise(dbatch))
+        loss.backward()
+        rest = flat[2 * B * N:]
+        assert rest[0].item() == loss.item(), prec
+        assert int(rest[1].item()) == int(metric.correct[0].item())
+        at = 2
+        for name, shape in synth.STATE_DICT_SHAPES(D, R, cfg.num_gcn_layers):
+            n = int(np.prod(shape))
+            g_c = rest[at:at + n].reshape(shape)
+            at += n
+            g_t = dict(layerwise.named_parameters())[name].grad
+            if g_t is None:
+                assert not g_c.any(), name        # dead parameter: the C caller passed no buffer, its arena stayed zero
+            else:
+                assert torch.allclose(g_c, g_t.cpu(), rtol=1e-4, atol=1e-7), (prec, name)
+        assert at == rest.numel()
 
 
 def test_refuses_cpu_tensors():

@@ -73,8 +73,17 @@ struct FusedLayout {  // workspace offsets in floats
     splitk_floats = 2 * B <= 512 ? 8 * 2 * B * (D + R) : 0;
     if (planes && splitk_floats < (size_t)128 * 65536) splitk_floats = (size_t)128 * 65536;
     splitk = take(splitk_floats);
-    // ... and of the pair-sized split-bf16 products when the whole batch is a handful of tiles (<= 2048 pairs)
-    pair_splitk_floats = (planes && M <= 2048) ? (M <= 512 ? 16 : 8) * ((M + 255) / 256 * 256) * D : 0;
+    // ... and of the pair-sized split-bf16 products when the whole batch is less than half a round of 256 x 256 tiles
+    pair_splitk_floats = 0;
+    {
+      const size_t tiles = ((M + 255) / 256) * ((D + 255) / 256);
+      if (planes && tiles <= 128)
+        for (size_t s : {16, 8, 6, 4, 3, 2})
+          if (tiles * s <= 256) {
+            pair_splitk_floats = s * ((M + 255) / 256 * 256) * D;
+            break;
+          }
+    }
     pair_splitk = take(pair_splitk_floats);
     total = off;
   }

@@ -326,8 +326,8 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
   int splits = 1;
   const int nkb = K / x3p::BK;
   const int64_t tiles = mt * cdiv(N, x3p::BN);
-  if (splitk != nullptr && tiles <= 32 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && aligned16(splitk)) {
-    for (int s = 16; s >= 2; s >>= 1)
+  if (splitk != nullptr && tiles <= 128 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && aligned16(splitk)) {
+    for (int s : {16, 8, 6, 4, 3, 2})
       if (tiles * s <= 256 && nkb % s == 0 && nkb / s >= 3 && (size_t)s * M * N <= splitk_floats) {
         splits = s;
         break;

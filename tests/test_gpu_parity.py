@@ -724,17 +724,23 @@ def test_indexed_loader_and_runner(tmp_path):
     cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6, batch_size=4, num_epoch=1,
                      test_epoch_interval=1, shuffle_train_data=False, metrics_topk=(1, 3), acc_correction=(0.0, 0.0, 0.0), **TINY)
     write_synthetic_dataset(cfg, str(tmp_path), sizes=(12, 4, 4), seed=4, num_entities=30)
+    from drin_amd.data import create_device_splits
     hist = {}
-    for kind in ("gathered", "indexed"):
+    for kind in ("gathered", "indexed", "device"):
         seed_everything(cfg.seed)
         model = Model(cfg).to(DEV)
-        if kind == "indexed":
-            table = load_entity_table(cfg, str(tmp_path), DEV)
-            hist[kind] = MELRunner(cfg, model, DEV, entity_table=table).fit(create_indexed_datasets(cfg, str(tmp_path)))
-        else:
+        if kind == "gathered":
             hist[kind] = MELRunner(cfg, model, DEV).fit(create_datasets(cfg, str(tmp_path)))
+        else:
+            table = load_entity_table(cfg, str(tmp_path), DEV)
+            # "device": the whole split resident on the GPU, batches are slices - no host work in the step
+            loaders = create_indexed_datasets(cfg, str(tmp_path)) if kind == "indexed" else create_device_splits(cfg, str(tmp_path), DEV)
+            hist[kind] = MELRunner(cfg, model, DEV, entity_table=table).fit(loaders)
     for a, b in zip(hist["gathered"].train + hist["gathered"].test, hist["indexed"].train + hist["indexed"].test):
         assert abs(a.loss - b.loss) <= 1e-4 and a.topk == pytest.approx(b.topk, abs=1e-9)
+    for a, b in zip(hist["indexed"].train + hist["indexed"].test, hist["device"].train + hist["device"].test):
+        # the same batches through the same kernels (weight-gradient atomics of the small products may move last bits)
+        assert abs(a.loss - b.loss) <= 1e-6 and a.topk == pytest.approx(b.topk, abs=1e-9)
 
 
 # ---- ragged / unusual geometries against the oracle ---------------------------------------------------------

@@ -182,3 +182,29 @@ def test_device_loss_metric_refuses_host_tensors():
     m = DeviceLossMetric(0.25, (1, 3), "cpu")
     with pytest.raises(RuntimeError, match="AMD GPU only"):
         m(torch.zeros(2, 3, dtype=torch.uint8), torch.zeros(2, 4))
+
+
+def test_device_split_yields_the_indexed_loader_batches(tmp_path):
+    """`DeviceSplit` (a whole split resident on one device) iterates exactly the batches of a DataLoader over
+    `IndexedMELData`: order, sharding over ranks, per-epoch shuffling, dtypes and values."""
+    from drin_amd.data import create_device_splits, create_indexed_datasets, write_synthetic_dataset
+    for shuffle in (False, True):
+        cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6, batch_size=5,
+                         shuffle_train_data=shuffle, bert_embed_dim=64, gcn_embed_dim=64, resnet_embed_dim=128,
+                         max_mention_sentence_len=16, resnet_num_region=4)
+        root = tmp_path / f"s{int(shuffle)}"
+        root.mkdir()
+        write_synthetic_dataset(cfg, str(root), sizes=(13, 4, 4), seed=4, num_entities=30)
+        for world, rank in ((1, 0), (2, 1)):
+            ref = create_indexed_datasets(cfg, str(root), rank=rank, world_size=world)
+            got = create_device_splits(cfg, str(root), "cpu", rank=rank, world_size=world)
+            for epoch in (0, 1):
+                for la, lb in zip(ref, got):
+                    for ld in (la, lb):
+                        if hasattr(ld.sampler, "set_epoch"):
+                            ld.sampler.set_epoch(epoch)
+                    assert len(la) == len(lb)
+                    for ba, bb in zip(la, lb):
+                        assert len(ba) == len(bb) == 11
+                        for x, y in zip(ba, bb):
+                            assert x.dtype == y.dtype and torch.equal(x, y)

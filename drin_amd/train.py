@@ -224,7 +224,7 @@ def seed_everything(seed: int) -> None:
 
 
 def main(argv: Optional[Sequence[str]] = None) -> None:
-    """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I]"""
+    """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I] [--on-device]"""
     import argparse
     import os
 
@@ -240,6 +240,9 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--global-batch-loss", action="store_true")
+    ap.add_argument("--on-device", action="store_true",
+                    help="wikimel: entity tables and every split resident on the GPU (load_entity_table + create_device_splits): "
+                         "no host gather, no host-to-device copy in the step")
     a = ap.parse_args(argv)
     cfg = wikimel_config() if a.dataset == "wikimel" else DrinConfig()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,9 +252,15 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     seed_everything(cfg.seed)
-    loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())
+    table = None
+    if a.on_device:
+        from .data import create_device_splits, load_entity_table
+        table = load_entity_table(cfg, a.data, dev, entity_mmap="r")
+        loaders = create_device_splits(cfg, a.data, dev, a.batch_size, _rank(), _world(), mention_mmap="r")
+    else:
+        loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())
     model = Model(cfg).to(dev)
-    runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print)
+    runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print, entity_table=table)
     runner.fit(loaders, a.epochs, a.interval)
     if world > 1:
         dist.destroy_process_group()

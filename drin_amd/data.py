@@ -181,22 +181,29 @@ def create_indexed_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int
 
 
 class DeviceSplit:
-    """One WikiMEL split resident on the device (".npy -> HBM once"): the seven mention-side tensors,
+    """One split resident on the device (WikiMEL in table form; WikiDiverse as its per-mention tensors) (".npy -> HBM once"): the seven mention-side tensors,
     the candidate rows of the entity tables, the two similarity matrices and the answers of EVERY mention of the split
     are uploaded once (WikiMEL train: 18 k mentions x 0.82 MB = 15 GB of the 288 GB); iterating yields the same
     11-item batches as a `DataLoader` over `IndexedMELData` - same order, same sharding, same shuffling - but as slices /
     index-selects of device tensors: no worker processes, no host gather, no host-to-device copy in the step."""
 
-    def __init__(self, ds: IndexedMELData, device, batch_size: int, sampler: Optional["ShardSampler"]):
+    def __init__(self, ds: MELData, device, batch_size: int, sampler: Optional["ShardSampler"]):
         dev = torch.device(device)
         up = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-        rows = np.asarray([[ds.qid2idx[str(q)] for q in qs] for qs in ds.entity_qid], dtype=np.int64)   # data.py:88
-        self.tensors = [
-            up(ds.mention_text_feature), up(ds.mention_text_mask),
-            up(ds.mention_start_pos) + 1, up(ds.mention_end_pos) + 1,                               # data.py:113-114
-            up(ds.mention_image_feature), up(ds.mention_object_feature), up(ds.mention_object_score),
-            up(rows), up(ds.miet_similarity), up(ds.mtei_similarity),
-        ]
+        mention = [up(ds.mention_text_feature), up(ds.mention_text_mask),
+                   up(ds.mention_start_pos) + 1, up(ds.mention_end_pos) + 1,                         # data.py:113-114
+                   up(ds.mention_image_feature), up(ds.mention_object_feature), up(ds.mention_object_score)]
+        if isinstance(ds, IndexedMELData):
+            rows = np.asarray([[ds.qid2idx[str(q)] for q in qs] for qs in ds.entity_qid], dtype=np.int64)   # data.py:88
+            self.tensors = mention + [up(rows), up(ds.miet_similarity), up(ds.mtei_similarity)]
+        elif ds.cfg.dataset_name == "wikidiverse":
+            # WikiDiverse stores per-mention candidate tensors (data.py:31-34): the whole 15-tuple lives on the device
+            n = len(ds)
+            self.tensors = mention + [up(ds.entity_text_feature), torch.zeros(n, dtype=torch.int64, device=dev),   # data.py:86
+                                      up(ds.entity_image_feature), up(ds.entity_object_feature), up(ds.entity_object_score),
+                                      up(ds.miet_similarity), up(ds.mtei_similarity)]
+        else:
+            raise ValueError("a WikiMEL split goes on the device in table form: build it from IndexedMELData")
         self.onehot = up(ds.onehot)
         self.answer = up(np.asarray(ds.answer).astype(np.int64))
         self.n, self.batch_size, self.sampler, self.device = len(ds), batch_size, sampler, dev
@@ -219,8 +226,12 @@ class DeviceSplit:
 
 def create_device_splits(cfg: DrinConfig, root: str, device, batch_size: Optional[int] = None, rank: int = 0,
                          world_size: int = 1, mention_mmap: Optional[str] = None) -> List[DeviceSplit]:
-    """[train, valid, test] `DeviceSplit`s: drop-in for `create_indexed_datasets` in `MELRunner.fit` (WikiMEL only)."""
-    loaders = create_indexed_datasets(cfg, root, batch_size, 0, rank, world_size, mention_mmap)
+    """[train, valid, test] `DeviceSplit`s: drop-in for `create_indexed_datasets` (WikiMEL: table form, pass the
+    `EntityTable` to `MELRunner`) or `create_datasets` (WikiDiverse: the 15-tuples themselves) in `MELRunner.fit`."""
+    if cfg.dataset_name == "wikimel":
+        loaders = create_indexed_datasets(cfg, root, batch_size, 0, rank, world_size, mention_mmap)
+    else:
+        loaders = create_datasets(cfg, root, batch_size, 0, rank, world_size, mention_mmap, mention_mmap)
     return [DeviceSplit(ld.dataset, device, batch_size or cfg.batch_size, ld.sampler if isinstance(ld.sampler, ShardSampler) else None)
             for ld in loaders]
 

@@ -241,7 +241,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--global-batch-loss", action="store_true")
     ap.add_argument("--on-device", action="store_true",
-                    help="wikimel: entity tables and every split resident on the GPU (load_entity_table + create_device_splits): "
+                    help="every split (and, wikimel, the entity tables) resident on the GPU (create_device_splits, load_entity_table): "
                          "no host gather, no host-to-device copy in the step")
     a = ap.parse_args(argv)
     cfg = wikimel_config() if a.dataset == "wikimel" else DrinConfig()
@@ -255,7 +255,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     table = None
     if a.on_device:
         from .data import create_device_splits, load_entity_table
-        table = load_entity_table(cfg, a.data, dev, entity_mmap="r")
+        table = load_entity_table(cfg, a.data, dev, entity_mmap="r") if cfg.dataset_name == "wikimel" else None
         loaders = create_device_splits(cfg, a.data, dev, a.batch_size, _rank(), _world(), mention_mmap="r")
     else:
         loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())

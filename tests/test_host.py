@@ -208,3 +208,18 @@ def test_device_split_yields_the_indexed_loader_batches(tmp_path):
                         assert len(ba) == len(bb) == 11
                         for x, y in zip(ba, bb):
                             assert x.dtype == y.dtype and torch.equal(x, y)
+    # WikiDiverse layout: the per-mention candidate tensors themselves live on the device, batches are the 15-tuples
+    from drin_amd.data import create_datasets
+    cfg = DrinConfig(num_candidates_data=6, batch_size=5, shuffle_train_data=True, bert_embed_dim=64, gcn_embed_dim=64,
+                     resnet_embed_dim=128, max_mention_sentence_len=16, resnet_num_region=4)
+    root = tmp_path / "wd"
+    root.mkdir()
+    write_synthetic_dataset(cfg, str(root), sizes=(13, 4, 4), seed=4)
+    for world, rank in ((1, 0), (2, 0)):
+        for la, lb in zip(create_datasets(cfg, str(root), rank=rank, world_size=world),
+                          create_device_splits(cfg, str(root), "cpu", rank=rank, world_size=world)):
+            assert len(la) == len(lb)
+            for ba, bb in zip(la, lb):
+                assert len(ba) == len(bb) == 15
+                for x, y in zip(ba, bb):
+                    assert x.dtype == y.dtype and torch.equal(x, y)

@@ -144,7 +144,7 @@ class EntityTable:
             raise ValueError("pooled_text: the table already holds pooled text [E, D]")
         if self._pooled is None or self._pooled[0].data_ptr() != self.text.data_ptr():
             lib = _lib.load()
-            text = self.text.to(torch.float32).contiguous()
+            text = self.text.contiguous()
             E, T, D = text.shape
             mask = self.mask.to(torch.int64).contiguous()
             pooled = torch.empty(E, D, dtype=torch.float32, device=text.device)
@@ -152,13 +152,16 @@ class EntityTable:
             _lib.check(lib.drin_default_config(C.byref(c)))
             c.num_candidates, c.embed_dim, c.entity_tokens = 1, D, T
             stream = torch.cuda.current_stream(text.device).cuda_stream
-            step = 1 << 20
-            for e0 in range(0, E, step):                              # one launch per 2^20 entities
+            # fp32 tables: one launch per 2^20 entities, in place; bf16-stored tables: widened (exactly) 2^14 entities at a time
+            step = 1 << 20 if text.dtype == torch.float32 else 1 << 14
+            for e0 in range(0, E, step):
                 e1 = min(E, e0 + step)
                 c.batch = e1 - e0
+                chunk = text[e0:e1].to(torch.float32)
                 b = _lib.DrinBatchC()
-                b.entity_text, b.entity_text_mask = text[e0:e1].data_ptr(), mask[e0:e1].data_ptr()
+                b.entity_text, b.entity_text_mask = chunk.data_ptr(), mask[e0:e1].data_ptr()
                 _lib.check(lib.drin_pool_fwd(C.byref(c), C.byref(b), pooled[e0:e1].data_ptr(), None, None, stream))
+                del chunk                                              # stream-ordered: the allocator reuses it after the launch
             self._pooled = (self.text, pooled, text[:, 0, :])
         return self._pooled[1], self._pooled[2]
 
@@ -441,7 +444,7 @@ class Model(nn.Module):
                         return self._forward_cached(call, t, params)
                     if planes:
                         return _DrinScore.apply(call, self._prepared, False, *params)
-            if not inference and t.text.dim() == 3 and t.text.dtype == torch.float32:
+            if not inference and t.text.dim() == 3:
                 # training on a token-level table: pool per entity once, gather pooled rows
                 batch, cls = batch.gathered_pooled(self.cfg)
             else:

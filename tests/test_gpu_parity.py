@@ -1009,6 +1009,11 @@ def test_bf16_stored_entity_table():
         with torch.no_grad():
             model(ib)
     table.enable_cache(False)
+    # training from the bf16-stored table: tokens widened (exactly) and pooled once per entity - the same scores as a
+    # step on the gathered, widened 14-sequence, bit for bit
+    model.train()
+    assert torch.equal(model(ib), model(ib.gathered()))
+    assert table._pooled is not None and table._pooled[1].dtype == torch.float32
 
 
 # ---- per-entity precompute cache ----------------------------------------------------------

@@ -76,9 +76,13 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // (|error| <= 6e-7 in fp32 arithmetic, i.e. <= 5e-7 on gelu - the same order as fp32 rounding of the
 // reference's own erf) with the hardware exp2 / rcp; ~14 VALU instructions against ~60 with branches
 // for the library erff.  The row kernels are VALU-bound on this function.
+// (v_rcp_f32 itself, 1 ulp: `__frcp_rn` expands to the correctly rounded division sequence - ten more instructions per
+//  element, a fifth of k_pair_final - for an error forty times below the polynomial's own: row kernels 1.63 -> 1.41 ms per
+//  413 696 pairs.  Measured on top of it and dropped: the same arithmetic two columns at a time on the packed fp32 pipe
+//  (v_pk_fma_f32; 381 -> 244 VALU instructions per row of k_pair_final): no further change - no longer issue-bound.)
 __device__ __forceinline__ float gelu_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
   const float poly =
       t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float e = 1.0f - poly * __expf(-z * z);  // erf(|x| / sqrt 2)
@@ -89,7 +93,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // with branches; the LayerNorm backward kernel was half VALU time on it).
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
   const float poly =
       t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float g = __expf(-0.5f * x * x);  // = exp(-z^2)

@@ -20,10 +20,10 @@ __global__ void __launch_bounds__(256) k_cosine_bwd_entity(const float* __restri
                                                            float* __restrict__ coef, float* __restrict__ gc,
                                                            float* __restrict__ xnorm, int64_t pairs, int N, int D4,
                                                            float eps) {
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= pairs) return;
+  int64_t p, b;
+  if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
-  const float* xr = x + (p / N) * (int64_t)D4 * 4;
+  const float* xr = x + b * (int64_t)D4 * 4;
   const float* yr = y + p * (int64_t)D4 * 4;
   float4 xv[MAXV], yv[MAXV];
   float xy = 0.f, xx = 0.f, yy = 0.f;
@@ -106,7 +106,7 @@ int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx,
   float* xn = scratch3 + 2 * pairs;
   {
     KernelTimer timer(DRIN_KC_GCN, st);
-    hipLaunchKernelGGL(k_cosine_bwd_entity, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, x, y, g, dy, coef, gcv,
+    hipLaunchKernelGGL(k_cosine_bwd_entity, pair_grid(B, N), dim3(256), 0, st, x, y, g, dy, coef, gcv,
                        xn, pairs, N, D / 4, eps);
     DRIN_CHECK_LAUNCH("k_cosine_bwd_entity");
   }
@@ -501,28 +501,31 @@ int launch_mention_reduce2(const float* w, const float* v1, const float* v2, con
   return DRIN_OK;
 }
 
-// out[p, :] = scale * (w1[p] m1[b, :] + w2[p] m2[b, :])        (m2 may be NULL)
+// out[p, :] = scale * (w1[p] m1[b, :] + w2[p] m2[b, :])        (m2 may be NULL); one wave per pair
 __global__ void __launch_bounds__(256) k_entity_combine(const float* __restrict__ w1, const float* __restrict__ m1,
                                                         const float* __restrict__ w2, const float* __restrict__ m2,
-                                                        float* __restrict__ out, int64_t total4, int N, int D4,
+                                                        float* __restrict__ out, int64_t pairs, int N, int D4,
                                                         float scale) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total4) return;
-  const int64_t p = i / D4;
-  const int c4 = (int)(i - p * D4);
-  const int64_t b = p / N;
-  float4 s = ld4(m1 + b * (int64_t)D4 * 4 + c4 * 4) * w1[p];
-  if (m2 != nullptr) s = fma4(w2[p], ld4(m2 + b * (int64_t)D4 * 4 + c4 * 4), s);
-  st4(out + i * 4, s * scale);
+  int64_t p, b;
+  if (!wave_pair(pairs, N, p, b)) return;
+  const int lane = threadIdx.x & 63;
+  const float a1 = w1[p], a2 = m2 != nullptr ? w2[p] : 0.f;
+  const float* r1 = m1 + b * (int64_t)D4 * 4;
+  const float* r2 = m2 != nullptr ? m2 + b * (int64_t)D4 * 4 : nullptr;
+  float* o = out + p * (int64_t)D4 * 4;
+  for (int c4 = lane; c4 < D4; c4 += 64) {
+    float4 s = ld4(r1 + c4 * 4) * a1;
+    if (r2 != nullptr) s = fma4(a2, ld4(r2 + c4 * 4), s);
+    st4(o + c4 * 4, s * scale);
+  }
 }
 
 int launch_entity_combine(const float* w1, const float* m1, const float* w2, const float* m2, float* out, int B, int N,
                           int D, float scale, hipStream_t st) {
-  const int64_t total4 = (int64_t)B * N * (D / 4);
-  if (total4 <= 0) return DRIN_OK;
+  const int64_t pairs = (int64_t)B * N;
+  if (pairs <= 0 || D <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_entity_combine, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st, w1, m1, w2, m2, out, total4,
-                     N, D / 4, scale);
+  hipLaunchKernelGGL(k_entity_combine, pair_grid(B, N), dim3(256), 0, st, w1, m1, w2, m2, out, pairs, N, D / 4, scale);
   DRIN_CHECK_LAUNCH("k_entity_combine");
   return DRIN_OK;
 }
@@ -544,10 +547,9 @@ __global__ void __launch_bounds__(256)
                       const float* __restrict__ de_extra, float* __restrict__ d_et, float* __restrict__ d_ei,
                       float* __restrict__ de, int64_t pairs, int N, int D4, float m0, float m1, float m2, float m3,
                       bool accumulate) {
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= pairs) return;
+  int64_t p, b;
+  if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
-  const int64_t b = p / N;
   const float inv_n = 1.0f / (float)N;
   const float e_tt = e[p], e_ti = e[pairs + p], e_it = e[2 * pairs + p], e_ii = e[3 * pairs + p];
   float s_tt = 0.f, s_ti = 0.f, s_it = 0.f, s_ii = 0.f;
@@ -595,7 +597,7 @@ int launch_entity_side_bwd(const float* dA_mt, const float* dA_mi, const float* 
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_entity_side_bwd, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, dA_mt, dA_mi, dA_et, dA_ei,
+  hipLaunchKernelGGL(k_entity_side_bwd, pair_grid(B, N), dim3(256), 0, st, dA_mt, dA_mi, dA_et, dA_ei,
                      mt, mi, et, ei, e, de_extra, d_et, d_ei, de, pairs, N, D / 4, mask[0], mask[1], mask[2], mask[3], accumulate);
   DRIN_CHECK_LAUNCH("k_entity_side_bwd");
   return DRIN_OK;

@@ -108,4 +108,20 @@ __device__ __forceinline__ float cosine_from_sums(float xy, float xx, float yy, 
   return xy / (fmaxf(sqrtf(xx), eps) * fmaxf(sqrtf(yy), eps));
 }
 
+// One wave per (mention, candidate) pair, four pairs per 256-thread block.  Launched as grid (ceil(N / 4), B) - see
+// pair_grid() - the pair comes from the block indices; the flat grid (ceil(pairs / 4), 1) of B == 1 or B > 65 535 pays a
+// 64-bit division per wave: ~100 VALU instructions, more than the arithmetic of a 3 KB row.
+__device__ __forceinline__ bool wave_pair(int64_t pairs, int N, int64_t& p, int64_t& b) {
+  const int wave = threadIdx.x >> 6;
+  if (gridDim.y > 1) {
+    const int n = (int)blockIdx.x * 4 + wave;
+    b = blockIdx.y;
+    p = b * N + n;
+    return n < N;
+  }
+  p = (int64_t)blockIdx.x * 4 + wave;
+  b = p / N;
+  return p < pairs;
+}
+
 }  // namespace drin

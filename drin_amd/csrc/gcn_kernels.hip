@@ -289,11 +289,11 @@ int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta,
 __global__ void __launch_bounds__(256) k_edge_update4(const float* __restrict__ fu, const float* __restrict__ fv,
                                                       const float* __restrict__ e, float* __restrict__ out,
                                                       int64_t pairs, int B, int N, int D4) {
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= pairs) return;
+  int64_t p, b;
+  if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
   const int64_t D = (int64_t)D4 * 4;
-  const float* ut = fu + (p / N) * D;
+  const float* ut = fu + b * D;
   const float* ui = ut + (int64_t)B * D;
   const float* vt = fv + p * D;
   const float* vi = vt + pairs * D;
@@ -327,7 +327,7 @@ int launch_edge_update4(const float* fu, const float* fv, const float* e, float*
     return DRIN_E_SHAPE;
   }
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_edge_update4, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4);
+  hipLaunchKernelGGL(k_edge_update4, pair_grid(B, N), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4);
   DRIN_CHECK_LAUNCH("k_edge_update4");
   return DRIN_OK;
 }

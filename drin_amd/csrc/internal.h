@@ -34,6 +34,10 @@ struct KernelTimer {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// grid of the one-wave-per-pair kernels (device_utils.h: wave_pair)
+inline dim3 pair_grid(int B, int N) {
+  return (B > 1 && B <= 65535) ? dim3((unsigned)cdiv(N, 4), (unsigned)B) : dim3((unsigned)cdiv((int64_t)B * N, 4));
+}
 
 // ---- streaming / pooling kernels (stream_kernels.hip) -------------------------------------------
 // out[g, c] = mean_s in[g, s, c]

@@ -166,10 +166,10 @@ int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out,
 __global__ void __launch_bounds__(256) k_cosine_rows(const float* __restrict__ x, const float* __restrict__ y,
                                                      int64_t y_stride, float* __restrict__ out, int64_t pairs, int N,
                                                      int D4, float eps, float scale) {
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= pairs) return;
+  int64_t p, b;
+  if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
-  const float* xr = x + (p / N) * (int64_t)D4 * 4;
+  const float* xr = x + b * (int64_t)D4 * 4;
   const float* yr = y + p * y_stride;
   float xy = 0.f, xx = 0.f, yy = 0.f;
   for (int c4 = lane; c4 < D4; c4 += 64) {
@@ -193,7 +193,7 @@ int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* 
     return DRIN_E_SHAPE;
   }
   KernelTimer timer(DRIN_KC_EDGE, st);
-  hipLaunchKernelGGL(k_cosine_rows, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, x, y, y_stride, out, pairs, N,
+  hipLaunchKernelGGL(k_cosine_rows, pair_grid(B, N), dim3(256), 0, st, x, y, y_stride, out, pairs, N,
                      D / 4, eps, scale);
   DRIN_CHECK_LAUNCH("k_cosine_rows");
   return DRIN_OK;

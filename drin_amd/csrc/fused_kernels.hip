@@ -300,25 +300,37 @@ int launch_entity_stream(const StreamArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // Sum the per-chunk partials in chunk order and lay them out for the mention-side GEMMs:
 //   s_text [2][B][D] = (S_tt, S_it), s_img [2][B][R] = (S_ti, S_ii), sig [4][B] = (tt, ti, it, ii)
+// (four columns per thread, the chunk loads of a trip independent of each other: 0.21 -> ~0.13 ms per 4096 mentions;
+//  D and R are multiples of 4, so a float4 never straddles two of the output regions)
 __global__ void __launch_bounds__(256) k_reduce_stream_partials(const float* __restrict__ part, float* __restrict__ s_text,
                                                                 float* __restrict__ s_img, float* __restrict__ sig,
                                                                 int B, int D, int R, int chunks) {
   const int64_t b = blockIdx.y;
   const int width = 2 * D + 2 * R + 4;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= width) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[(b * chunks + c) * (int64_t)width + i];
+  const float* src = part + (b * chunks) * (int64_t)width + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    const float4 v0 = ld4(src + (int64_t)c * width), v1 = ld4(src + (int64_t)(c + 1) * width);
+    const float4 v2 = ld4(src + (int64_t)(c + 2) * width), v3 = ld4(src + (int64_t)(c + 3) * width);
+    s = (((s + v0) + v1) + v2) + v3;  // chunk order, as a serial loop would add them
+  }
+  for (; c < chunks; ++c) s = s + ld4(src + (int64_t)c * width);
   if (i < D) {
-    s_text[b * D + i] = s;
+    st4(s_text + b * D + i, s);
   } else if (i < 2 * D) {
-    s_text[((int64_t)B + b) * D + (i - D)] = s;
+    st4(s_text + ((int64_t)B + b) * D + (i - D), s);
   } else if (i < 2 * D + R) {
-    s_img[b * R + (i - 2 * D)] = s;
+    st4(s_img + b * R + (i - 2 * D), s);
   } else if (i < 2 * D + 2 * R) {
-    s_img[((int64_t)B + b) * R + (i - 2 * D - R)] = s;
+    st4(s_img + ((int64_t)B + b) * R + (i - 2 * D - R), s);
   } else {
-    sig[(int64_t)(i - 2 * D - 2 * R) * B + b] = s;
+    sig[b] = s.x;
+    sig[(int64_t)B + b] = s.y;
+    sig[2 * (int64_t)B + b] = s.z;
+    sig[3 * (int64_t)B + b] = s.w;
   }
 }
 
@@ -326,7 +338,7 @@ int launch_reduce_stream_partials(const float* part, float* s_text, float* s_img
                                   int chunks, hipStream_t st) {
   if (B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_reduce_stream_partials, dim3((unsigned)cdiv(2 * D + 2 * R + 4, 256), (unsigned)B), dim3(256), 0,
+  hipLaunchKernelGGL(k_reduce_stream_partials, dim3((unsigned)cdiv((2 * D + 2 * R + 4) / 4, 256), (unsigned)B), dim3(256), 0,
                      st, part, s_text, s_img, sig, B, D, R, chunks);
   DRIN_CHECK_LAUNCH("k_reduce_stream_partials");
   return DRIN_OK;

@@ -68,10 +68,10 @@ struct FusedLayout {  // workspace offsets in floats
     p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
     // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
-    // (in split-bf16 precision at least 128 partial 256 x 256 tiles, so that a partly filled last round of tiles of the
+    // (in split-bf16 precision at least 192 partial 256 x 256 tiles, so that a partly filled last round of tiles of the
     //  larger products can split K over the idle CUs - gemm_bf16x3.hip)
     splitk_floats = 2 * B <= 512 ? 8 * 2 * B * (D + R) : 0;
-    if (planes && splitk_floats < (size_t)128 * 65536) splitk_floats = (size_t)128 * 65536;
+    if (planes && splitk_floats < (size_t)192 * 65536) splitk_floats = (size_t)192 * 65536;   // 64 tail tiles x 3 partials
     splitk = take(splitk_floats);
     // ... and of the pair-sized split-bf16 products when the whole batch is less than half a round of 256 x 256 tiles
     pair_splitk_floats = 0;
@@ -380,8 +380,9 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
   DRIN_TRY(lin(vm1, D, L2.w_h, D, P.p_wh2, DD, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D));
   // (5) the two pair-sized layer-1 contractions on the folded weights
-  float* const psk = L.pair_splitk_floats ? ws + L.pair_splitk : nullptr;  // split-K scratch when the batch is a few tiles
-  const size_t pskf = L.pair_splitk_floats;
+  // split-K scratch: the whole-product split when the batch is a few tiles, else the tail-split scratch
+  float* const psk = L.pair_splitk_floats ? ws + L.pair_splitk : (L.splitk_floats ? ws + L.splitk : nullptr);
+  const size_t pskf = L.pair_splitk_floats ? L.pair_splitk_floats : L.splitk_floats;
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
@@ -396,7 +397,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
                                      ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192,
-                                     psk ? psk : ws + L.splitk, psk ? pskf : L.splitk_floats));
+                                     psk, pskf));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));

@@ -371,6 +371,15 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
 
 }  // namespace x3
 
+int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int N, unsigned col_tiles, unsigned full,
+                        unsigned tail_tiles, int ksplit, hipStream_t st) {
+  KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
+  hipLaunchKernelGGL((x3::k_tail_add<256, 256>), dim3(256, tail_tiles), dim3(256), 0, st, tail, y, ldy, M, N, col_tiles, full,
+                     ksplit);
+  DRIN_CHECK_LAUNCH("k_tail_add");
+  return DRIN_OK;
+}
+
 // w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo,

@@ -29,12 +29,24 @@ constexpr int LDS_BYTES = 2 * BUF_BYTES;
 // The column tiles of one row tile all stream the same A rows, so they should run on ONE XCD at the same
 // time: XCD x takes a contiguous range of the tile sequence (column index fastest).  Without this the
 // A operand is fetched from HBM once per column tile (3x for N = 768).  Placement only affects speed.
-__device__ __forceinline__ void tile_of_block(int& tile_x, int64_t& tile_y, int nx) {
-  const unsigned nwg = gridDim.x * gridDim.y;
-  const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
-  const unsigned xcd = id & 7, k = id >> 3;
-  const unsigned q = nwg >> 3, rem = nwg & 7;
-  const unsigned t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+// Tail split (as in gemm_bf16x3.hip): the grid is 1-D; ids below `full` are whole tiles in the XCD order above, the
+// `tail_tiles` of a partly filled last round follow as `ksplit` work items each, one per slice of K.
+__device__ __forceinline__ void tile_of_block(int& tile_x, int64_t& tile_y, int nx, unsigned full, int ksplit, int& kpart,
+                                              unsigned& tail_slot) {
+  const unsigned id = blockIdx.x;
+  unsigned t;
+  kpart = 0;
+  tail_slot = 0;
+  if (id < full) {
+    const unsigned xcd = id & 7, k = id >> 3;
+    const unsigned q = full >> 3, rem = full & 7;
+    t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  } else {
+    const unsigned u = id - full;
+    t = full + u / (unsigned)ksplit;
+    kpart = (int)(u % (unsigned)ksplit);
+    tail_slot = (u / (unsigned)ksplit) * (unsigned)(ksplit - 1) + (unsigned)(kpart - 1);
+  }
   tile_x = (int)(t % (unsigned)nx);
   tile_y = (int64_t)(t / (unsigned)nx);
 }
@@ -118,7 +130,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                        const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
                        const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                       int64_t part_stride) {
+                       int64_t part_stride, int nx, unsigned full, int ksplit, float* __restrict__ tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (gridDim.z > 1) {  // split K (small problems): slice blockIdx.z of the reduction, raw partial tile to scratch
     K /= (int)gridDim.z;
@@ -134,11 +146,20 @@ __global__ void __launch_bounds__(THREADS, 2)
 #ifdef DRIN_STAMPS
   const unsigned long long t_start = __builtin_readcyclecounter();
 #endif
-  int tx;
+  int tx, kpart;
   int64_t ty;
-  tile_of_block(tx, ty, (int)gridDim.x);
+  unsigned tail_slot;
+  tile_of_block(tx, ty, nx, full, ksplit, kpart, tail_slot);
   const int64_t m0 = ty * BM;
   const int n0 = tx * BN;
+  if (blockIdx.x >= full) {  // a K-slice of a tail tile
+    K /= ksplit;
+    const int64_t k0 = (int64_t)kpart * K;
+    a_hi += k0;
+    if (A_LO) a_lo += k0;
+    b_hi += k0;
+    if (B_LO) b_lo += k0;
+  }
   const int nkb = K / BK;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3;
@@ -161,7 +182,7 @@ __global__ void __launch_bounds__(THREADS, 2)
 
   for (int kb = 0; kb < nkb; ++kb) {
 #ifdef DRIN_STAMPS
-    const bool stamp = blockIdx.x == 1 && blockIdx.y == 40 && lane == 0 && kb < 64;
+    const bool stamp = blockIdx.x == 121 && lane == 0 && kb < 64;
     if (stamp) g_stamps[(wave * 64 + kb) * 4 + 0] = __builtin_readcyclecounter();
 #endif
     const int cur = kb & 1;
@@ -216,6 +237,16 @@ __global__ void __launch_bounds__(THREADS, 2)
   // tile are four consecutive output COLUMNS of one row (row lane & 15, columns 4 (lane >> 4) + v): one 16-byte store
   // per tile instead of four scattered 4-byte ones (32 instead of 128 store instructions per wave; the epilogue was
   // 24 % of a tile's time at K = 768).
+  if (kpart > 0) {  // raw accumulators of a tail slice: [slot][256][256], folded into C by the tail-add launch
+    float* part = tail + (size_t)tail_slot * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        st4(part + (wm * 128 + i * 16 + r) * BN + wn * 64 + j * 16 + c * 4,
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+    return;
+  }
   const bool vec_ok = (ldc % 4) == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -237,7 +268,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     }
   }
 #ifdef DRIN_STAMPS
-  if (blockIdx.x == 1 && blockIdx.y == 40 && (threadIdx.x & 63) == 0) {
+  if (blockIdx.x == 121 && (threadIdx.x & 63) == 0) {
     __builtin_amdgcn_s_waitcnt(0);  // stores issued and acknowledged
     const int wv = threadIdx.x >> 6;
     unsigned long long* o = g_stamps + 8 * 64 * 4 + wv * 4;
@@ -333,7 +364,22 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
         break;
       }
   }
-  dim3 grid((unsigned)cdiv(N, x3p::BN), (unsigned)mt, (unsigned)splits);
+  // otherwise, a partly filled last round of tiles (fewer than half the CUs) splits K over the idle CUs
+  const int nx = (int)cdiv(N, x3p::BN);
+  unsigned full = (unsigned)tiles;
+  int ksplit = 1;
+  if (splits == 1 && splitk != nullptr && aligned16(splitk) && tiles <= 16 * 256) {
+    const unsigned frac = (unsigned)(tiles % 256);
+    for (int s = 4; s >= 2 && frac > 0; --s)
+      if ((unsigned)s * frac <= 256 && nkb % s == 0 && nkb / s >= 4 &&
+          (size_t)frac * (s - 1) * (x3p::BM * x3p::BN) <= splitk_floats) {
+        ksplit = s;
+        full = (unsigned)tiles - frac;
+        break;
+      }
+  }
+  const unsigned items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
+  dim3 grid(items, 1, (unsigned)splits);
   const int64_t part_stride = M * (int64_t)N;
   float* out = splits > 1 ? splitk : y;
   {
@@ -341,16 +387,17 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
     const __bf16 *ah = (const __bf16*)a_hi, *al = (const __bf16*)a_lo, *bh = (const __bf16*)b_hi, *bl = (const __bf16*)b_lo;
     if (a_lo_plane)
       hipLaunchKernelGGL((x3p::k_gemm_x3_planes<true, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
-                         bl, ldb, bias, out, ldy, M, N, K, part_stride);
+                         bl, ldb, bias, out, ldy, M, N, K, part_stride, nx, full, ksplit, splitk);
     else if (b_lo_plane)
       hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
-                         bl, ldb, bias, out, ldy, M, N, K, part_stride);
+                         bl, ldb, bias, out, ldy, M, N, K, part_stride, nx, full, ksplit, splitk);
     else
       hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, false>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
-                         bl, ldb, bias, out, ldy, M, N, K, part_stride);
+                         bl, ldb, bias, out, ldy, M, N, K, part_stride, nx, full, ksplit, splitk);
     DRIN_CHECK_LAUNCH("k_gemm_x3_planes");
   }
   if (splits > 1) DRIN_TRY(launch_splitk_reduce(splitk, splits, part_stride, bias, y, ldy, M, N, false, st));
+  if (ksplit > 1) DRIN_TRY(launch_tail_add_256(splitk, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
   return DRIN_OK;
 }
 

@@ -87,6 +87,9 @@ int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t l
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
                           hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
+// y[tail tile] += its ksplit - 1 partial 256 x 256 tiles, in order (tail split of the two split-bf16 NT kernels)
+int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int N, unsigned col_tiles, unsigned full,
+                        unsigned tail_tiles, int ksplit, hipStream_t st);
 // y[m, n] (+)= bias[n] + sum_z partial[z][m][n] in order (the reduction step of every split-K product; gemm_f32.hip)
 int launch_splitk_reduce(const float* partial, int splits, int64_t part_stride, const float* bias, float* y, int64_t ldy,
                          int64_t M, int N, bool accumulate, hipStream_t st);

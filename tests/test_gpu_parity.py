@@ -1238,3 +1238,27 @@ def test_table_rows_beyond_2_31_elements():
     assert torch.equal(a, b)
     del table, text
     torch.cuda.empty_cache()
+
+
+def test_mid_size_batch_tail_split_paths_agree():
+    """256 WikiMEL-shaped mentions = 25 856 pairs = 303 output tiles of 256 x 256: the 47 tiles of the partly filled last
+    round split K over the idle CUs in both split-bf16 NT kernels.  The folded path (planes kernel, tail split) against
+    the layer-by-layer path (its own kernels and tail split) on the same device batch, and a 64-mention slice of the
+    batch scored on its own (whole-product split-K instead): all within fp32 re-association."""
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=100)
+    B = 256
+    sd = synth.make_state_dict(cfg, 5)
+    batch = synth.make_device_batch(cfg, B, 77, DEV)[:14]
+    with torch.no_grad():
+        folded = Model(cfg, precision="bf16x3").to(DEV).eval()
+        folded.load_state_dict(sd)
+        generic = Model(cfg, precision="bf16x3", fused=False).to(DEV).eval()
+        generic.load_state_dict(sd)
+        a = folded(batch)
+        b = generic(batch)
+        c = folded([t[:64] for t in batch])
+    assert torch.isfinite(a).all()
+    assert (a - b).abs().max().item() <= 1e-5
+    assert (a[:64] - c).abs().max().item() <= 2e-6
+    ref = O.forward(sd, [t[:4].cpu() for t in batch])
+    assert (a[:4].cpu() - ref).abs().max().item() <= 1e-5

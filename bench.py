@@ -169,7 +169,7 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
     from drin_amd.train import GradBucket
 
     model.train()
-    full = synth.make_device_batch(cfg, B, 200 + rank, dev)
+    full = synth.make_device_batch(cfg, B, 200 + rank, dev, dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)
     batch, y = full[:14], full[14]
     if args.train_form != "gathered":
         # table form: the entity tables live on the device, a step carries candidate indices.
@@ -177,7 +177,8 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
         # blocks are gathered with torch indexing every step (what the reference's loader does on the host)
         from drin_amd.model import EntityTable, IndexedBatch
         E = args.train_entities
-        tab = synth.make_device_batch(cfg.with_(num_candidates_data=E - 1), 1, 300 + rank, dev)
+        tab = synth.make_device_batch(cfg.with_(num_candidates_data=E - 1), 1, 300 + rank, dev,
+                                      dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)
         table = EntityTable(tab[7][0], tab[8][0] if cfg.token_level_entities else None, tab[9][0], tab[10][0], tab[11][0])
         del tab
         g = torch.Generator(device=dev)
@@ -245,6 +246,7 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)"
+                                   + (", features stored as bf16 (token blocks pooled in place, the rest widened)" if args.features == "bf16" else "")
                                    + ({"gathered": "", "table": f", candidates indexed into a device-resident table of {args.train_entities} entities (tokens pooled once per entity)",
                                        "table-tokens": f", candidates gathered from a device-resident table of {args.train_entities} entities with torch indexing every step"}[args.train_form]),
                        "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},

@@ -354,8 +354,10 @@ int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled
     set_error("batch is NULL");
     return DRIN_E_NULL;
   }
-  if (cfg->feature_dtype != DRIN_FEAT_F32) {
-    set_error("drin_pool_fwd: bf16 feature storage is read by drin_forward_prepared only; widen the features to fp32");
+  const bool bf16 = cfg->feature_dtype == DRIN_FEAT_BF16;
+  if (bf16 && (pooled_mention_image || pooled_entity_image)) {
+    set_error("drin_pool_fwd: with bf16 feature storage only the entity token pooling is built here (the image means of the "
+              "fused path are taken inside drin_forward_prepared)");
     return DRIN_E_UNSUPPORTED;
   }
   // only the inputs of the requested outputs are needed (pooling an entity TABLE once passes the text alone)
@@ -376,8 +378,12 @@ int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled
       set_error("drin_pool_fwd: entity text is already pooled when entity_tokens == 0");
       return DRIN_E_SHAPE;
     }
-    DRIN_TRY(launch_entity_token_mean(batch->entity_text, batch->entity_text_mask, pooled_entity_text, M,
-                                      cfg->entity_tokens, cfg->embed_dim, st));
+    if (bf16)  // tokens stored as bf16: pooled in place (half the bytes of the HBM-bound pass), fp32 sums
+      DRIN_TRY(launch_entity_token_mean_bf16(batch->entity_text, batch->entity_text_mask, pooled_entity_text, M,
+                                             cfg->entity_tokens, cfg->embed_dim, st));
+    else
+      DRIN_TRY(launch_entity_token_mean(batch->entity_text, batch->entity_text_mask, pooled_entity_text, M,
+                                        cfg->entity_tokens, cfg->embed_dim, st));
   }
   if (pooled_mention_image)
     DRIN_TRY(launch_axis_mean(batch->mention_image, pooled_mention_image, cfg->batch, cfg->image_regions,

@@ -52,6 +52,8 @@ int launch_span_mean_bf16(const void* seq, const int64_t* start, const int64_t* 
 // ghmfc.py:245-249: out[p, :] = mean(feat[p, 1:ntok-1, :]), ntok = sum(mask[p, :])
 int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
                              hipStream_t st);
+int launch_entity_token_mean_bf16(const void* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
+                                  hipStream_t st);
 // out[b*N + n] = scale * cos(x[b, :], y[(b*N + n) * y_stride : +D])
 int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
                        float scale, hipStream_t st);

@@ -114,7 +114,9 @@ int launch_span_mean_bf16(const void* seq, const int64_t* start, const int64_t* 
 // WikiMEL entity pooling (baselines/ghmfc.py:245-249): x[p] = mean(feat[p, 1:ntok-1]), ntok = sum(mask[p]).
 // Only the rows inside the slice are read (the compulsory bytes).  One block per pair;
 // each thread owns float4 columns and keeps 8 token rows in flight.
-__global__ void __launch_bounds__(256) k_entity_token_mean(const float* __restrict__ feat,
+// T_ = float or __bf16 (features stored as bf16: values widen exactly, the sums are the fp32 sums of the widened rows).
+template <typename T_>
+__global__ void __launch_bounds__(256) k_entity_token_mean(const T_* __restrict__ feat,
                                                            const int64_t* __restrict__ mask, float* __restrict__ out,
                                                            int T, int D4) {
   const int64_t p = blockIdx.x;
@@ -127,9 +129,9 @@ __global__ void __launch_bounds__(256) k_entity_token_mean(const float* __restri
   if (stop < 0) stop = 0;
   if (stop > T) stop = T;
   const int n = stop - 1;  // rows 1 .. stop-1
-  const float* base = feat + p * (int64_t)T * D4 * 4;
+  const T_* base = feat + p * (int64_t)T * D4 * 4;
   for (int c4 = threadIdx.x; c4 < D4; c4 += blockDim.x) {
-    const float* col = base + (int64_t)c4 * 4;
+    const T_* col = base + (int64_t)c4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int t = 1;
     for (; t + 8 <= stop; t += 8) {
@@ -145,8 +147,9 @@ __global__ void __launch_bounds__(256) k_entity_token_mean(const float* __restri
   }
 }
 
-int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
-                             hipStream_t st) {
+template <typename T_>
+static int launch_entity_token_mean_t(const T_* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
+                                      hipStream_t st) {
   if (pairs <= 0) return DRIN_OK;
   if (D % 4 != 0 || T <= 0) {
     set_error("entity_token_mean: D=%d must be a multiple of 4, T=%d positive", D, T);
@@ -155,9 +158,18 @@ int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out,
   const int D4 = D / 4;
   int threads = D4 >= 192 ? 192 : (D4 > 64 ? 128 : 64);  // D = 768 -> one float4 column per thread, 3 waves
   KernelTimer timer(DRIN_KC_POOL, st);
-  hipLaunchKernelGGL(k_entity_token_mean, dim3((unsigned)pairs), dim3(threads), 0, st, feat, mask, out, T, D4);
+  hipLaunchKernelGGL(k_entity_token_mean<T_>, dim3((unsigned)pairs), dim3(threads), 0, st, feat, mask, out, T, D4);
   DRIN_CHECK_LAUNCH("k_entity_token_mean");
   return DRIN_OK;
+}
+
+int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
+                             hipStream_t st) {
+  return launch_entity_token_mean_t<float>(feat, mask, out, pairs, T, D, st);
+}
+int launch_entity_token_mean_bf16(const void* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
+                                  hipStream_t st) {
+  return launch_entity_token_mean_t<__bf16>(static_cast<const __bf16*>(feat), mask, out, pairs, T, D, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -93,6 +93,33 @@ def _fill_params(struct, tensors: Sequence[Optional[torch.Tensor]], per_layer: i
             setattr(struct.layer[l], n, _ptr(tensors[8 + per_layer * l + j]))
 
 
+@torch.no_grad()
+def _pool_tokens(text: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """Masked token mean of `ghmfc.py:245-249` for `text [..., T, D]` (fp32 or bf16, read in place) and
+    `mask [..., T]` -> `[..., D]` fp32, by the library's pooling kernel (`drin_pool_fwd`)."""
+    lib = _lib.load()
+    lead, (T, D) = text.shape[:-2], text.shape[-2:]
+    text = text.contiguous().view(-1, T, D)
+    if text.dtype not in (torch.float32, torch.bfloat16):
+        text = text.to(torch.float32)
+    mask = mask.to(torch.int64).contiguous().view(-1, T)
+    E = text.shape[0]
+    pooled = torch.empty(E, D, dtype=torch.float32, device=text.device)
+    c = _lib.DrinConfigC()
+    _lib.check(lib.drin_default_config(C.byref(c)))
+    c.num_candidates, c.embed_dim, c.entity_tokens = 1, D, T
+    c.feature_dtype = _lib.FEAT_BF16 if text.dtype == torch.bfloat16 else _lib.FEAT_F32
+    stream = torch.cuda.current_stream(text.device).cuda_stream
+    step = 1 << 20
+    for e0 in range(0, E, step):                                      # one launch per 2^20 rows
+        e1 = min(E, e0 + step)
+        c.batch = e1 - e0
+        b = _lib.DrinBatchC()
+        b.entity_text, b.entity_text_mask = text[e0:e1].data_ptr(), mask[e0:e1].data_ptr()
+        _lib.check(lib.drin_pool_fwd(C.byref(c), C.byref(b), pooled[e0:e1].data_ptr(), None, None, stream))
+    return pooled.view(*lead, D)
+
+
 class EntityTable:
     """The WikiMEL entity tables of `drin/data.py:163-175`, resident on the device: text features
     `[E, T, D]` (+ mask `[E, T]`) or pooled `[E, D]`, image `[E, (1,) R]`, object `[E, Ke, (1,) R]`, object
@@ -143,26 +170,8 @@ class EntityTable:
         if self.text.dim() != 3:
             raise ValueError("pooled_text: the table already holds pooled text [E, D]")
         if self._pooled is None or self._pooled[0].data_ptr() != self.text.data_ptr():
-            lib = _lib.load()
             text = self.text.contiguous()
-            E, T, D = text.shape
-            mask = self.mask.to(torch.int64).contiguous()
-            pooled = torch.empty(E, D, dtype=torch.float32, device=text.device)
-            c = _lib.DrinConfigC()
-            _lib.check(lib.drin_default_config(C.byref(c)))
-            c.num_candidates, c.embed_dim, c.entity_tokens = 1, D, T
-            stream = torch.cuda.current_stream(text.device).cuda_stream
-            # fp32 tables: one launch per 2^20 entities, in place; bf16-stored tables: widened (exactly) 2^14 entities at a time
-            step = 1 << 20 if text.dtype == torch.float32 else 1 << 14
-            for e0 in range(0, E, step):
-                e1 = min(E, e0 + step)
-                c.batch = e1 - e0
-                chunk = text[e0:e1].to(torch.float32)
-                b = _lib.DrinBatchC()
-                b.entity_text, b.entity_text_mask = chunk.data_ptr(), mask[e0:e1].data_ptr()
-                _lib.check(lib.drin_pool_fwd(C.byref(c), C.byref(b), pooled[e0:e1].data_ptr(), None, None, stream))
-                del chunk                                              # stream-ordered: the allocator reuses it after the launch
-            self._pooled = (self.text, pooled, text[:, 0, :])
+            self._pooled = (self.text, _pool_tokens(text, self.mask), text[:, 0, :])
         return self._pooled[1], self._pooled[2]
 
     def to(self, device) -> "EntityTable":
@@ -458,6 +467,14 @@ class Model(nn.Module):
                     and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16))
         # "bf16" is a mode of the fused inference path; anything else it meets runs split-bf16
         prec = self.precision if (in_place or self.precision != _lib.PREC_BF16) else _lib.PREC_BF16X3
+        if (cls is None and training and len(batch) >= 14 and batch[7].dtype == torch.bfloat16 and batch[7].dim() == 4
+                and batch[7].is_cuda and batch[7].shape[0] > 0):
+            # a training step on bf16-stored token blocks: pooled in place by the library - half
+            # the bytes, no widened copy of the 197 KB per candidate - then the pooled-ahead form below
+            etf = batch[7]
+            batch = list(batch[:7]) + [_pool_tokens(etf, batch[8]), torch.zeros(etf.shape[0], dtype=torch.int64, device=etf.device)] \
+                + list(batch[9:])
+            cls = etf[:, :, 0, :]
         if cls is not None:
             # pooled-ahead batch: the layer-by-layer entry points (the fused path folds the pooling into its one pass)
             call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec, entity_text_cls=cls)

@@ -182,7 +182,10 @@ DRIN_API int drin_edges_fwd(const drin_config* cfg, const drin_batch* batch, flo
 
 /* Input pooling of VertexEncoder.forward: entity token mean (ghmfc.py:245-249, only T>0),
  * mention region mean (model.py:41), entity image inner mean (model.py:43-44).  Any output may be
- * NULL to skip it.  pooled_entity_text [B,N,D], pooled_mention_image [B,R], pooled_entity_image [B,N,R]. */
+ * NULL to skip it.  pooled_entity_text [B,N,D], pooled_mention_image [B,R], pooled_entity_image [B,N,R].
+ * Only the inputs of the requested outputs are read (pooling an entity TABLE once passes the text and its mask alone).
+ * With cfg.feature_dtype == DRIN_FEAT_BF16 the entity token pooling reads bf16 tokens in place (fp32 sums of the
+ * exactly widened values); the two image means are then not available here (DRIN_E_UNSUPPORTED). */
 DRIN_API int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled_entity_text,
                   float* pooled_mention_image, float* pooled_entity_image, void* stream);
 

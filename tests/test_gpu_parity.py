@@ -1262,3 +1262,42 @@ def test_mid_size_batch_tail_split_paths_agree():
     assert (a[:64] - c).abs().max().item() <= 2e-6
     ref = O.forward(sd, [t[:4].cpu() for t in batch])
     assert (a[:4].cpu() - ref).abs().max().item() <= 1e-5
+
+
+def test_training_from_bf16_stored_features_pools_in_place():
+    """A training step on a batch whose features are stored as bf16: the token blocks are pooled in place by the library
+    (`drin_pool_fwd`, bf16 tokens, fp32 sums) instead of being widened first - scores and gradients equal those of the same
+    step on the widened batch, bit for bit on the scores."""
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    batch = _to_dev(_bf16_features(synth.make_batch(cfg, 5, 72)))
+    wide = [t.float() if t.dtype == torch.bfloat16 else t for t in batch]
+    model = Model(cfg, precision="bf16x3").to(DEV)
+    model.load_state_dict(sd)
+    lib = _lib.load()
+    _lib.profile_begin()
+    a = model(batch[:14])
+    prof = _lib.profile_end()
+    assert prof["pool"][1] >= 1
+    a.sum().backward()
+    g1 = [p.grad.clone() if p.grad is not None else None for p in model.parameters()]
+    model.zero_grad()
+    b = model(wide[:14])
+    b.sum().backward()
+    assert torch.equal(a, b)
+    for x, p in zip(g1, model.parameters()):
+        assert (x is None) == (p.grad is None)
+        if x is not None:
+            assert torch.allclose(x, p.grad, rtol=1e-4, atol=1e-6)
+    # the C entry point: bf16 tokens pooled in place == fp32 pooling of the widened tokens; the image means are refused
+    from drin_amd.model import _pool_tokens
+    assert torch.equal(_pool_tokens(batch[7], batch[8]), _pool_tokens(wide[7], wide[8]))
+    ref = O.entity_token_mean(wide[7].cpu(), wide[8].cpu())
+    np.testing.assert_allclose(_pool_tokens(batch[7], batch[8]).cpu().numpy(), ref.numpy(), atol=1e-6)
+    c = _lib.DrinConfigC()
+    lib.drin_default_config(C.byref(c))
+    c.batch, c.num_candidates, c.embed_dim, c.entity_tokens, c.feature_dtype = 5, 21, cfg.bert_embed_dim, 10, _lib.FEAT_BF16
+    bt = _lib.DrinBatchC()
+    bt.entity_text, bt.entity_text_mask, bt.mention_image = batch[7].data_ptr(), batch[8].data_ptr(), batch[4].data_ptr()
+    out = torch.empty(5, cfg.resnet_embed_dim, device=DEV)
+    assert lib.drin_pool_fwd(C.byref(c), C.byref(bt), None, out.data_ptr(), None, torch.cuda.current_stream().cuda_stream) == _lib.E_UNSUPPORTED

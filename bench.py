@@ -162,6 +162,35 @@ def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None):
     return out, parity
 
 
+def train_roofline(cfg, B, N, prof, args):
+    """The dominant kernel class of a training step is the split-bf16 GEMM family (k_gemm_bf16x3 + k_gemm_tn_bf16x3):
+    algorithmic FLOPs of the pair-sized contractions (forward with the dead work of the last layer removed, dX and dW of
+    backward: 17 D^2 + 2 . 2 R D multiply-adds per pair for two dynamic layers) over its summed launch time."""
+    D, R, nl = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_gcn_layers
+    dyn = cfg.gcn_edge_type == "dynamic"
+    # forward: W_et, W_ei, per layer W_h on et (+ ei unless last), W_v on (et, ei) unless last / static
+    fwd = 2.0 * D * D + 2.0 * R * D
+    bwd = 2.0 * D * D + 2.0 * R * D          # dW of the two vertex encoders (inputs carry no gradient)
+    for l in range(nl):
+        last = l == nl - 1
+        wh = (1 if last else 2) * 2.0 * D * D
+        wv = 0.0 if (last or not dyn) else 2 * 2.0 * D * D
+        fwd += wh + wv
+        bwd += 2 * (wh + wv)                 # dX and dW
+    ms, launches = prof.get("gemm_x3", (0.0, 0))
+    if ms <= 0:
+        return None
+    tf = (fwd + bwd) * B * N * args.steps / (ms * 1e-3) / 1e12
+    x3 = args.precision in ("bf16x3", "bf16")
+    peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS
+    out = {"bound": "mfma", "kernel": "k_gemm_bf16x3 + k_gemm_tn_bf16x3", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+           "frac": tf / peak, "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
+           "flops_per_pair": fwd + bwd}
+    if x3:
+        out["executed_bf16_tflops"], out["executed_frac"] = 3 * tf, 3 * tf / peak
+    return out
+
+
 def bench_train(args, cfg, model, dev, world, rank, B, barrier):
     """One optimisation step of train.py:30-56 per "step": forward (intermediates kept), TripletLoss, backward
     through the HIP kernels, one RCCL all-reduce of the flat gradient bucket (world > 1), Adam."""
@@ -251,6 +280,7 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
                                        "table-tokens": f", candidates gathered from a device-resident table of {args.train_entities} entities with torch indexing every step"}[args.train_form]),
                        "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "roofline": train_roofline(cfg, B, N, prof, args),
             "final_loss": float(loss)}))
     if world > 1:
         import torch.distributed as dist

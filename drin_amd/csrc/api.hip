@@ -494,10 +494,14 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   // buffer is idle during the forward pass and between the weight-gradient products of the backward pass)
   float* const tl = L.tn_part_floats ? ws + L.tn_part : nullptr;
   const size_t tlf = L.tn_part_floats;
+  // mention-sized products beyond the exact-fp32 split-K range (2 B > 512 rows) run split-bf16 on small tiles and split K
+  // into the same scratch
+  float* const msk = sk ? sk : tl;
+  const size_t mskf = sk ? skf : tlf;
   DRIN_TRY(launch_gemm_nt(P.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false,
-                          prec, st, sk, skf));
+                          prec, st, msk, mskf));
   DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
-                          D, B, D, R, false, prec, st, sk, skf));
+                          D, B, D, R, false, prec, st, msk, mskf));
   DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
                           prec, st, tl, tlf));
   DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
@@ -550,7 +554,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     // shared W_h + LayerNorm + GELU for all vertex types of the layer (model.py:128)
     float* h_m = ws + L.h_m[l];
     float* h_e = ws + L.h_e[l];
-    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, sk, skf));
+    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, msk, mskf));
     DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st, tl, tlf));
     float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
     float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
@@ -566,7 +570,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
       float* fv = ws + L.fv[l];
       float* pre = ws + L.pre[l];
       const int H = D / 2;
-      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, H, 2 * (int64_t)B, H, D, false, prec, st, sk, skf));
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, H, 2 * (int64_t)B, H, D, false, prec, st, msk, mskf));
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, H, 2 * M, H, D, false, prec, st));
       DRIN_TRY(launch_edge_pre_vec(fu, fv, e, pre, B, N, D, st));
       DRIN_TRY(launch_gemm_nt(pre, D, W.w_m, D, W.b_m, e_next, D, 4 * M, D, D, false, prec, st));
@@ -574,7 +578,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
-      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, sk, skf));
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, msk, mskf));
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf));
       DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st));
     } else if (!cfg->dynamic_edges) {

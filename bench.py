@@ -109,7 +109,7 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("DRIN_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None):
+def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None, features="f32"):
     """The CPU oracle timed on the host cores this process may use; with `model`, the same sample batches are also
     scored by the HIP path and compared (max |score error|, top-1 agreement) - the checker, never the thing measured."""
     from oracle import drin_oracle as O
@@ -120,17 +120,28 @@ def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None):
     batch = synth.make_batch(cfg, B, 3)
     parity = None
     if model is not None:
-        err, agree, total = 0.0, 0, 0
+        err, agree, total, err32, agree32 = 0.0, 0, 0, 0.0, 0
+        feat_slots = (0, 4, 5, 7, 9, 10)    # the six feature tensors of the 14-sequence
         with torch.no_grad():
             for seed in range(3, 3 + (8 if cfg.token_level_entities else 2)):   # 64 / 128 mentions
                 b = synth.make_batch(cfg, B, seed)
-                ref = O.forward(sd, b)
-                got = model([t.to(dev) for t in b[:14]]).cpu()
+                ref32 = O.forward(sd, b)
+                if features == "bf16":   # stored as bf16 on the device; the oracle scores the same values widened
+                    stored = [t.to(torch.bfloat16) if i in feat_slots else t for i, t in enumerate(b[:14])]
+                    ref = O.forward(sd, [t.float() if t.dtype == torch.bfloat16 else t for t in stored])
+                else:
+                    stored, ref = b[:14], ref32
+                got = model([t.to(dev) for t in stored]).cpu()
                 err = max(err, (got - ref).abs().max().item())
                 agree += int((got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).sum())
+                err32 = max(err32, (got - ref32).abs().max().item())
+                agree32 += int((got[:, :-1].argmax(1) == ref32[:, :-1].argmax(1)).sum())
                 total += B
         parity = {"max_abs_score_err": err, "top1_agreement": agree / total, "mentions": total,
-                  "against": "CPU oracle (pinned to the reference by tests/golden), same synthetic inputs"}
+                  "against": "CPU oracle (pinned to the reference by tests/golden), same synthetic inputs"
+                             + (" as stored (bf16 values widened)" if features == "bf16" else "")}
+        if features == "bf16":           # what storing the features as bf16 costs against the fp32 inputs
+            parity["vs_fp32_features"] = {"max_abs_score_err": err32, "top1_agreement": agree32 / total}
     with torch.no_grad():
         O.forward(sd, batch)  # warm-up
         t0 = time.perf_counter()
@@ -495,7 +506,8 @@ def main():
                             "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], line["parity"] = cpu_baseline(cfg, sd, model=model if args.workload != "table" else None, dev=dev)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(cfg, sd, model=model if args.workload != "table" else None, dev=dev,
+                                                                   features=args.features)
             if line["parity"] is None:
                 del line["parity"]
         print(json.dumps(line))

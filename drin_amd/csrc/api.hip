@@ -245,12 +245,13 @@ int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P,
   // (entity_text_cls: the raw rows of a batch whose token means were pooled ahead of time)
   const float* raw = b->entity_text_cls ? b->entity_text_cls : b->entity_text;
   const int64_t raw_stride = b->entity_text_cls ? (int64_t)c->embed_dim : P.entity_text_raw_stride;
-  DRIN_TRY(launch_cosine_rows(P.span_mean, raw, raw_stride, edges + 0 * M, B, N, c->embed_dim, c->cosine_eps, 1.0f, st));
+  DRIN_TRY(launch_cosine_rows(P.span_mean, raw, raw_stride, edges + 0 * M, B, N, c->embed_dim, c->cosine_eps, 1.0f, st,
+                              b->entity_index));
   DRIN_TRY(launch_scale_div(b->mtei_similarity, edges + 1 * M, M, 1.0f, c->clip_scale, st));
   DRIN_TRY(launch_scale_div(b->miet_similarity, edges + 2 * M, M, 1.0f, c->clip_scale, st));
   DRIN_TRY(launch_miei(P.mention_object, b->mention_object_score, P.entity_object, b->entity_object_score,
                        edges + 3 * M, B, N, c->mention_objects, c->entity_objects, c->image_dim, c->cosine_eps,
-                       c->miei_eps, 1.0f, st));
+                       c->miei_eps, 1.0f, st, b->entity_index));
   return DRIN_OK;
 }
 
@@ -269,6 +270,25 @@ static int tap(const drin_trace* t, int l, const Layout& L, const float* ws, int
   DRIN_TRY(copy_out(t->entity_text_vertex[l], ws + L.ve[l], (size_t)M * D, st));
   DRIN_TRY(copy_out(t->entity_image_vertex[l], ws + L.ve[l] + (size_t)M * D, (size_t)M * D, st));
   DRIN_TRY(copy_out(t->edges[l], ws + L.edges[l], (size_t)4 * M * edge_width, st));
+  return DRIN_OK;
+}
+
+// Table form of the layer-by-layer entry points (training over device-resident entity tables): the entity tensors of the
+// batch are TABLES of cfg.num_entities rows and pair p reads row entity_index[p] - inside the static-edge kernels and in
+// the row addressing of the vertex-encoder GEMMs (forward x W^T, backward dY^T x), never as gathered copies.
+static int indexed_supported(const drin_config* c, const drin_batch* b, const char* who) {
+  const int64_t M = (int64_t)c->batch * c->num_candidates;
+  const int D = c->embed_dim, R = c->image_dim;
+  const bool x3 = c->precision == DRIN_PREC_BF16X3 || c->precision == DRIN_PREC_BF16X3_ALL;
+  if (c->num_entities <= 0 || c->entity_tokens != 0 || c->entity_image_inner > 1 || c->entity_object_inner > 1 ||
+      c->entity_objects != 1 || c->vector_edges || !x3 || M < 1024 || (D % 32) || (R % 32) || D < 128 || R < 128 ||
+      R > 2048 || c->batch > 65535) {
+    set_error("%s: entity_index needs pooled entity text tables (entity_tokens = 0, num_entities > 0), one object per entity, "
+              "inner dims <= 1, scalar edges, split-bf16 precision, D and R multiples of 32 (>= 128, R <= 2048) and at least "
+              "1024 pairs; gather on the caller side otherwise", who);
+    return DRIN_E_UNSUPPORTED;
+  }
+  (void)b;
   return DRIN_OK;
 }
 
@@ -444,10 +464,8 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
   DRIN_TRY(validate_params(cfg, params));
-  if (batch->entity_index) {
-    set_error("drin_forward: entity_index (table form) is taken by drin_forward_prepared only; pass gathered tensors");
-    return DRIN_E_UNSUPPORTED;
-  }
+  const int64_t* eidx = batch->entity_index;
+  if (eidx) DRIN_TRY(indexed_supported(cfg, batch, "drin_forward"));
   if (!scores) {
     set_error("scores is NULL");
     return DRIN_E_NULL;
@@ -502,10 +520,17 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
                           prec, st, msk, mskf));
   DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
                           D, B, D, R, false, prec, st, msk, mskf));
-  DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
-                          prec, st, tl, tlf));
-  DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
-                          M, D, R, false, prec, st, tl, tlf));
+  if (eidx) {  // rows of the entity tables, addressed through the candidate index by the GEMM's stager
+    DRIN_TRY(launch_gemm_nt_bf16x3(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, st,
+                                   nullptr, nullptr, false, false, tl, tlf, eidx));
+    DRIN_TRY(launch_gemm_nt_bf16x3(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D,
+                                   D, M, D, R, st, nullptr, nullptr, false, false, tl, tlf, eidx));
+  } else {
+    DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
+                            prec, st, tl, tlf));
+    DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
+                            M, D, R, false, prec, st, tl, tlf));
+  }
   DRIN_TRY(tap(trace, 0, L, ws, B, M, D, st, EW));
 
   bool all_enabled = true;
@@ -668,6 +693,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     set_error("drin_backward: grad_scores / grads is NULL");
     return DRIN_E_NULL;
   }
+  const int64_t* eidx = batch->entity_index;
+  if (eidx) DRIN_TRY(indexed_supported(cfg, batch, "drin_backward"));
   Layout L;
   L.build(*cfg, true);
   if (!workspace || !aligned16(workspace)) {
@@ -850,12 +877,22 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   const float* g_ei = g_ve[cur] + MD;
   if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st, tnp, tnf));
   DRIN_TRY(launch_colsum(g_mt, grads->b_mention_text, B, D, st));
-  if (grads->w_entity_text) DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st, tnp, tnf));
+  if (grads->w_entity_text) {
+    if (eidx)
+      DRIN_TRY(launch_gemm_tn_bf16x3(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, st, tnp, tnf, eidx));
+    else
+      DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st, tnp, tnf));
+  }
   DRIN_TRY(launch_colsum(g_et, grads->b_entity_text, (int64_t)M, D, st));
   if (have_image) {
     if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st, tnp, tnf));
     DRIN_TRY(launch_colsum(g_mi, grads->b_mention_image, B, D, st));
-    if (grads->w_entity_image) DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st, tnp, tnf));
+    if (grads->w_entity_image) {
+      if (eidx)
+        DRIN_TRY(launch_gemm_tn_bf16x3(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, st, tnp, tnf, eidx));
+      else
+        DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st, tnp, tnf));
+    }
     DRIN_TRY(launch_colsum(g_ei, grads->b_entity_image, (int64_t)M, D, st));
   }
   return DRIN_OK;

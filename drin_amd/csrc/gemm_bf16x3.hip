@@ -59,12 +59,15 @@ struct Stager {
   const float* p[PASSES];
   float4 v[PASSES];
 
-  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows) {
+  // (index: row m of the operand is row index[m] of a table - table-form training gathers the vertex-encoder inputs here)
+  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
+                                       const int64_t* __restrict__ index = nullptr) {
     const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
       int64_t row = row0 + r + RPP * i;
       row = row < rows ? row : rows - 1;
+      if (index != nullptr) row = index[row];
       p[i] = src + row * ld + c4 * 4;
     }
   }
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
                   const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
                   int64_t ldc, int64_t M, int N, int K, int accumulate, unsigned col_tiles, unsigned full, int ksplit,
-                  float* __restrict__ tail) {
+                  float* __restrict__ tail, const int64_t* __restrict__ a_index) {
   using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   Stager<BM, G::THREADS> sa;
   Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;  // one dummy pass when the weights come by DMA
   PlaneDma<BN, WM * WN> dma;
-  sa.init(A, lda, m0, M);
+  sa.init(A, lda, m0, M, a_index);
   if (W_PLANES)
     dma.init(w_hi, w_lo, ldw, n0, N);
   else
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(BN) k_tail_add(const float* __restrict__ tail,
 template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
 static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
                   const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate,
-                  float* tail = nullptr, size_t tail_floats = 0) {
+                  float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr) {
   using G = Cfg<BM, BN, WM, WN>;
   const int64_t mt = cdiv(M, BM), nt = cdiv(N, BN);
   if (mt * nt > (int64_t)1 << 30) {
@@ -359,7 +362,7 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
   const unsigned items = full + (tiles - full) * (unsigned)ksplit;
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(kern, dim3(items), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
-                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail);
+                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail, a_index);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
   if (ksplit > 1) {
     hipLaunchKernelGGL((k_tail_add<BM, BN>), dim3(BM, tiles - full), dim3(BN), 0, st, tail, y, ldy, M, N, (unsigned)nt,
@@ -383,8 +386,12 @@ int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int
 // w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo,
-                          bool accumulate, bool one_pass, float* tail, size_t tail_floats) {
+                          bool accumulate, bool one_pass, float* tail, size_t tail_floats, const int64_t* a_index) {
   if (M <= 0 || N <= 0) return DRIN_OK;
+  if (a_index != nullptr && ((K % x3::BK) || K <= 0 || one_pass)) {
+    set_error("gemm_bf16x3: indexed rows need K %% 32 == 0 (got %d) on the split-bf16 kernel", K);
+    return DRIN_E_UNSUPPORTED;
+  }
   if ((K % x3::BK) || K <= 0) {  // odd reduction lengths take the exact fp32 kernel (guarded loads)
     if (!w) {
       set_error("gemm_bf16x3: K=%d is not a multiple of 32 and no fp32 weights were given", K);
@@ -409,10 +416,10 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   }
   if (tail != nullptr && !aligned16(tail)) tail = nullptr;
   if (big)
-    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats)
-                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
-  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats)
-                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
+    return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
+                  : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);
+  return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
+                : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);
 }
 
 }  // namespace drin

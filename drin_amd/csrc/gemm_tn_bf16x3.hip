@@ -43,13 +43,20 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 
 // 32 (m) x 256 (columns) fp32 staged by 512 threads: lane = (m-group mg = lane >> 3, column group cgl = lane & 7),
 // wave w covers column groups 8 w .. 8 w + 7; a column group is 4 adjacent columns.
+// INDEXED: reduction row m of the operand is row index[m] of a TABLE (the entity tables of table-form training: the
+// vertex-encoder inputs are gathered here instead of being materialised per step).  The indices of the NEXT stage are
+// fetched one call ahead, so the dependent address -> data chain never sits inside a stage.
+template <bool INDEXED>
 struct TransposeStager {
-  const float* p;   // first row of the reduction range, this thread's column
+  const float* p;   // first row of the reduction range (or of the table), this thread's column
   int64_t ld;
   int mg, cg;
   float4 v[4];
+  const int64_t* index;
+  int64_t next_row[4];
 
-  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld_, int col0, int ncols) {
+  __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld_, int col0, int ncols,
+                                       const int64_t* __restrict__ index_ = nullptr, int64_t m_first = 0, int64_t m_end = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     mg = lane >> 3;
     cg = wave * 8 + (lane & 7);
@@ -57,15 +64,29 @@ struct TransposeStager {
     col = col + 4 <= ncols ? col : ncols - 4;  // clamped columns feed output rows / columns that are never stored
     p = src + col;
     ld = ld_;
+    index = index_;
+    if (INDEXED) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t m = m_first + 4 * mg + i;
+        next_row[i] = index[m < m_end ? m : m_end - 1];
+      }
+    }
   }
-  // rows m0 + 4 mg + i; rows at or past m_end contribute zero (the loads stay unconditional: clamped row, then masked)
+  // rows m0 + 4 mg + i; rows at or past m_end contribute zero (the loads stay unconditional: clamped row, then masked).
+  // Calls walk m0 in steps of BK (the pipeline's stage order), which is what the index prefetch relies on.
   __device__ __forceinline__ void load(int64_t m0, int64_t m_end) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + 4 * mg + i;
       const bool live = m < m_end;
-      const float4 x = ld4(p + (live ? m : m_end - 1) * ld);
+      const int64_t row = INDEXED ? next_row[i] : (live ? m : m_end - 1);
+      const float4 x = ld4(p + row * ld);
       v[i] = live ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (INDEXED) {
+        const int64_t mn = m + BK;
+        next_row[i] = index[mn < m_end ? mn : m_end - 1];
+      }
     }
   }
   __device__ __forceinline__ void store(char* __restrict__ hi_plane, char* __restrict__ lo_plane) const {
@@ -89,10 +110,11 @@ struct TransposeStager {
 };
 
 // grid: x = output tile (n-tile major), y = slice of the reduction
+template <bool B_INDEXED>
 __global__ void __launch_bounds__(THREADS, 1)
     k_gemm_tn_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
                      float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, int64_t rows_per_slice, int k_tiles,
-                     float* __restrict__ partial) {
+                     float* __restrict__ partial, const int64_t* __restrict__ b_index) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n0 = (blockIdx.x / k_tiles) * TILE, k0 = (blockIdx.x % k_tiles) * TILE;
   const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
@@ -111,9 +133,10 @@ __global__ void __launch_bounds__(THREADS, 1)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
-  TransposeStager sa, sb;
+  TransposeStager<false> sa;
+  TransposeStager<B_INDEXED> sb;
   sa.init(A, lda, n0, N);
-  sb.init(Bm, ldb, k0, K);
+  sb.init(Bm, ldb, k0, K, b_index, m_begin, m_end);
   sa.load(m_begin, m_end);
   sb.load(m_begin, m_end);
   sa.store(smem, smem + PLANE);
@@ -217,7 +240,7 @@ bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, cons
 }
 
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
-                          int N, int K, hipStream_t st, float* scratch, size_t scratch_floats) {
+                          int N, int K, hipStream_t st, float* scratch, size_t scratch_floats, const int64_t* b_index) {
   if (M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
   if (!gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b)) {
     set_error("gemm_tn_bf16x3: shape M=%lld N=%d K=%d / alignment outside the kernel's contract", (long long)M, N, K);
@@ -238,16 +261,25 @@ int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t l
   }
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, x3tn::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, x3tn::LDS_BYTES);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_tn_bf16x3)");
     attr_done = true;
   }
   const bool two_stage = scratch != nullptr && slices > 1 && (size_t)slices * N * K <= scratch_floats && (ldy % 4) == 0 &&
                          aligned16(y) && aligned16(scratch);
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
-  hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS), x3tn::LDS_BYTES,
-                     st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles, two_stage ? scratch : (float*)nullptr);
+  if (b_index != nullptr)
+    hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3<true>, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS),
+                       x3tn::LDS_BYTES, st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles,
+                       two_stage ? scratch : (float*)nullptr, b_index);
+  else
+    hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3<false>, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS),
+                       x3tn::LDS_BYTES, st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles,
+                       two_stage ? scratch : (float*)nullptr, b_index);
   DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
   if (two_stage) {
     hipLaunchKernelGGL(x3tn::k_tn_reduce, dim3((unsigned)cdiv((int64_t)N * (K / 4), 256)), dim3(256), 0, st, scratch, (int)slices,

@@ -56,10 +56,11 @@ int launch_entity_token_mean_bf16(const void* feat, const int64_t* mask, float* 
                                   hipStream_t st);
 // out[b*N + n] = scale * cos(x[b, :], y[(b*N + n) * y_stride : +D])
 int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
-                       float scale, hipStream_t st);
+                       float scale, hipStream_t st, const int64_t* y_index = nullptr);
 // model.py:84-92: weighted object-pair similarity
 int launch_miei(const float* mobj, const float* mscore, const float* eobj, const float* escore, float* out, int B,
-                int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st);
+                int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st,
+                const int64_t* e_index = nullptr);
 // out[i] = in[i] * mul / div
 int launch_scale_div(const float* in, float* out, int64_t n, float mul, float div, hipStream_t st);
 
@@ -75,7 +76,8 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi = nullptr,
                           const void* w_lo = nullptr, bool accumulate = false, bool one_pass = false,
-                          float* tail = nullptr, size_t tail_floats = 0);
+                          float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr);
+// (a_index: row m of x is row a_index[m] of a table)
 // (tail: optional scratch; a partly filled last round of 256 x 256 tiles is then split along K over the idle CUs)
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
@@ -83,7 +85,9 @@ bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, cons
 // (scratch: optional [slices][N][K] floats - the slices then store plainly and are reduced in order instead of
 //  adding to y with atomics)
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
-                          int N, int K, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
+                          int N, int K, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0,
+                          const int64_t* b_index = nullptr);
+// (b_index: reduction row m of b is row b_index[m] of a table - the gathered form never materialised)
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 // (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,

@@ -177,12 +177,12 @@ int launch_entity_token_mean_bf16(const void* feat, const int64_t* mask, float* 
 // y = entity pooler vector or token 0 of the token block) and for the final score (model.py:207-209).
 __global__ void __launch_bounds__(256) k_cosine_rows(const float* __restrict__ x, const float* __restrict__ y,
                                                      int64_t y_stride, float* __restrict__ out, int64_t pairs, int N,
-                                                     int D4, float eps, float scale) {
+                                                     int D4, float eps, float scale, const int64_t* __restrict__ y_index) {
   int64_t p, b;
   if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
   const float* xr = x + b * (int64_t)D4 * 4;
-  const float* yr = y + p * y_stride;
+  const float* yr = y + (y_index != nullptr ? y_index[p] : p) * y_stride;  // y_index: y is a table, pair p reads row y_index[p]
   float xy = 0.f, xx = 0.f, yy = 0.f;
   for (int c4 = lane; c4 < D4; c4 += 64) {
     const float4 a = ld4(xr + c4 * 4), b = ld4(yr + c4 * 4);
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_cosine_rows(const float* __restrict__ x
 }
 
 int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
-                       float scale, hipStream_t st) {
+                       float scale, hipStream_t st, const int64_t* y_index) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   if (D % 4 != 0 || y_stride % 4 != 0) {
@@ -206,7 +206,7 @@ int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* 
   }
   KernelTimer timer(DRIN_KC_EDGE, st);
   hipLaunchKernelGGL(k_cosine_rows, pair_grid(B, N), dim3(256), 0, st, x, y, y_stride, out, pairs, N,
-                     D / 4, eps, scale);
+                     D / 4, eps, scale, y_index);
   DRIN_CHECK_LAUNCH("k_cosine_rows");
   return DRIN_OK;
 }
@@ -223,7 +223,7 @@ constexpr int kMieiChunk = 32;
 __global__ void __launch_bounds__(256) k_miei_lds(const float* __restrict__ mobj, const float* __restrict__ mscore,
                                                   const float* __restrict__ eobj, const float* __restrict__ escore,
                                                   float* __restrict__ out, int N, int Km, int R4, float cos_eps,
-                                                  float miei_eps, float scale) {
+                                                  float miei_eps, float scale, const int64_t* __restrict__ e_index) {
   extern __shared__ float4 lds4[];  // [Km][R4] rows, then Km squared norms
   float* lds_xx = reinterpret_cast<float*>(lds4 + (size_t)Km * R4);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(256) k_miei_lds(const float* __restrict__ mobj
   const int n_end = min(N, ((int)blockIdx.x + 1) * kMieiChunk);
   for (int n = blockIdx.x * kMieiChunk + wave; n < n_end; n += 4) {
     const int64_t p = b * N + n;
-    const float* yr = eobj + p * (int64_t)R4 * 4;
+    const int64_t er = e_index != nullptr ? e_index[p] : p;  // e_index: eobj / escore are tables
+    const float* yr = eobj + er * (int64_t)R4 * 4;
     float4 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) k_miei_lds(const float* __restrict__ mobj
 #pragma unroll
     for (int k = 0; k < 8; ++k) yy += dot4(v[k], v[k]);
     yy = wave_sum(yy);
-    const float es = escore[p];
+    const float es = escore[er];
     float sim = 0.f, wsum = 0.f;
     for (int i = 0; i < Km; ++i) {
       float xy = 0.f;
@@ -306,7 +307,8 @@ __global__ void __launch_bounds__(256) k_miei(const float* __restrict__ mobj, co
 }
 
 int launch_miei(const float* mobj, const float* mscore, const float* eobj, const float* escore, float* out, int B,
-                int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st) {
+                int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st,
+                const int64_t* e_index) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   if (R % 4 != 0) {
@@ -317,7 +319,10 @@ int launch_miei(const float* mobj, const float* mscore, const float* eobj, const
   const size_t lds = ((size_t)Km * R + Km) * sizeof(float);
   if (Ke == 1 && R <= 2048 && lds <= 64 * 1024 && B <= 65535) {
     hipLaunchKernelGGL(k_miei_lds, dim3((unsigned)cdiv(N, kMieiChunk), (unsigned)B), dim3(256), lds, st, mobj, mscore,
-                       eobj, escore, out, N, Km, R / 4, cos_eps, miei_eps, scale);
+                       eobj, escore, out, N, Km, R / 4, cos_eps, miei_eps, scale, e_index);
+  } else if (e_index != nullptr) {
+    set_error("miei: table form (entity_index) is built for Ke == 1, R <= 2048 and at most 65535 mentions per call");
+    return DRIN_E_UNSUPPORTED;
   } else {
     hipLaunchKernelGGL(k_miei, dim3((unsigned)cdiv(pairs, 4)), dim3(256), 0, st, mobj, mscore, eobj, escore, out, pairs,
                        N, Km, Ke, R / 4, cos_eps, miei_eps, scale);

@@ -171,7 +171,7 @@ class EntityTable:
             raise ValueError("pooled_text: the table already holds pooled text [E, D]")
         if self._pooled is None or self._pooled[0].data_ptr() != self.text.data_ptr():
             text = self.text.contiguous()
-            self._pooled = (self.text, _pool_tokens(text, self.mask), text[:, 0, :])
+            self._pooled = (self.text, _pool_tokens(text, self.mask), text[:, 0, :].contiguous())   # [E, D] each
         return self._pooled[1], self._pooled[2]
 
     def to(self, device) -> "EntityTable":
@@ -298,11 +298,12 @@ class _Call:
         else:
             emask = None
         if entity_text_cls is not None:
-            if token_level or table:
-                raise ValueError("entity_text_cls goes with pooled per-pair entity text [B, N, D]")
+            if token_level:
+                raise ValueError("entity_text_cls goes with pooled entity text")
             entity_text_cls = f32(entity_text_cls)
-            if tuple(entity_text_cls.shape) != (B, N, D):
-                raise ValueError(f"entity_text_cls has shape {tuple(entity_text_cls.shape)}, expected {(B, N, D)}")
+            want = (etf.shape[0], D) if table else (B, N, D)       # a table of token-0 rows, or per-pair rows
+            if tuple(entity_text_cls.shape) != want:
+                raise ValueError(f"entity_text_cls has shape {tuple(entity_text_cls.shape)}, expected {want}")
         self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei, entity_index,
                      entity_text_cls]
         self.device = dev
@@ -454,7 +455,13 @@ class Model(nn.Module):
                     if planes:
                         return _DrinScore.apply(call, self._prepared, False, *params)
             if not inference and t.text.dim() == 3:
-                # training on a token-level table: pool per entity once, gather pooled rows
+                # training on a token-level table: every entity's tokens pooled once; the step then reads the pooled /
+                # token-0 / image / object tables through the candidate index inside the kernels, or gathers those rows
+                call = self._indexed_training_call(batch, planes)
+                if call is not None:
+                    if call.B == 0:
+                        return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
+                    return _DrinScore.apply(call, None, True, *params)
                 batch, cls = batch.gathered_pooled(self.cfg)
             else:
                 batch = batch.gathered()
@@ -488,6 +495,23 @@ class Model(nn.Module):
         if call.B == 0:
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         return _DrinScore.apply(call, self._prepared, training, *params)
+
+    def _indexed_training_call(self, batch: "IndexedBatch", planes: bool) -> Optional[_Call]:
+        """The table form of `drin_forward` / `drin_backward` (`drin_batch.entity_index` over tables pooled ahead of time),
+        when the library builds it for this geometry (`indexed_supported` in csrc/api.hip); None: gather the rows."""
+        t, cand = batch.table, batch.candidates
+        D, R = self.cfg.bert_embed_dim, self.cfg.resnet_embed_dim
+        ok = (planes and self.precision != _lib.PREC_BF16 and self.cfg.gcn_edge_feature != "vector"
+              and t.text.dtype == torch.float32 and t.image.dtype == torch.float32 and t.object.dtype == torch.float32
+              and cand.numel() >= 1024 and cand.shape[0] <= 65535 and D % 32 == 0 and R % 32 == 0 and D >= 128
+              and 128 <= R <= 2048 and t.object.shape[1] == 1 and t.image.dim() in (2, 3) and t.object.dim() in (3, 4)
+              and (t.image.dim() == 2 or t.image.shape[1] == 1) and (t.object.dim() == 3 or t.object.shape[2] == 1))
+        if not ok:
+            return None
+        pooled, cls = t.pooled_text(self.cfg)
+        dummy = torch.zeros(cand.shape[0], dtype=torch.int64, device=cand.device)
+        seq = batch.mention + [pooled, dummy, t.image, t.object, t.object_score, batch.miet_similarity, batch.mtei_similarity]
+        return _Call(self.cfg, seq, self.precision, entity_index=cand, entity_text_cls=cls)
 
     @torch.no_grad()
     def _forward_cached(self, call: _Call, table: EntityTable, params) -> torch.Tensor:

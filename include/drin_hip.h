@@ -113,8 +113,11 @@ typedef struct {
   /* Optional on-device form of the WikiMEL entity-table gather (drin/data.py:87-93).  When non-NULL,
    * entity_text / entity_text_mask / entity_image / entity_object / entity_object_score are TABLES with
    * cfg.num_entities rows ([E, T, D], [E, T], [E, (inner,) R], ...) and candidate (b, n) reads row
-   * entity_index[b, n] (clamped to [0, E-1]) instead of row b*N + n.  Taken by drin_forward_prepared;
-   * drin_forward / drin_backward need the gathered per-pair tensors. */
+   * entity_index[b, n] (clamped to [0, E-1] by drin_forward_prepared) instead of row b*N + n.  Taken by
+   * drin_forward_prepared (token-level or pooled tables) and, for training over tables pooled ahead of time
+   * (entity_tokens = 0, entity_text_cls set or not, one object per entity, inner dims <= 1, scalar edges, split-bf16
+   * precision, >= 1024 pairs), by drin_forward / drin_backward: the static-edge kernels and the vertex-encoder GEMMs
+   * (forward x W^T, backward dY^T x) address the table rows through the index - indices must lie in [0, E-1]. */
   const int64_t* entity_index;        /* [B, N] or NULL                                          */
   /* Optional, T == 0 only: the rows the text-text edge compares the mention span with (model.py:73-75: token 0 of
    * the WikiMEL token block) when entity_text carries token means POOLED AHEAD OF TIME - the pooling of

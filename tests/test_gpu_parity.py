@@ -1301,3 +1301,54 @@ def test_training_from_bf16_stored_features_pools_in_place():
     bt.entity_text, bt.entity_text_mask, bt.mention_image = batch[7].data_ptr(), batch[8].data_ptr(), batch[4].data_ptr()
     out = torch.empty(5, cfg.resnet_embed_dim, device=DEV)
     assert lib.drin_pool_fwd(C.byref(c), C.byref(bt), None, out.data_ptr(), None, torch.cuda.current_stream().cuda_stream) == _lib.E_UNSUPPORTED
+
+
+def test_training_reads_entity_tables_through_the_index():
+    """Table-form training at full widths (>= 1024 pairs): the pooled / token-0 / image / object TABLES go to `drin_forward` /
+    `drin_backward` with `entity_index`, and the static-edge kernels and the vertex-encoder GEMMs (forward x W^T, backward
+    dY^T x) address their rows through it - same scores (bit for bit) and gradients as the step on gathered rows."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=100)
+    E, B, N = 300, 12, cfg.num_candidates_model
+    tab = synth.make_device_batch(cfg.with_(num_candidates_data=E - 1), 1, 31, DEV)
+    table = EntityTable(tab[7][0], tab[8][0], tab[9][0], tab[10][0], tab[11][0])
+    men = synth.make_device_batch(cfg, B, 32, DEV)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(4)
+    cand = torch.randint(0, E, (B, N), device=DEV, generator=g)
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    sd = synth.make_state_dict(cfg, 6)
+    model = Model(cfg, precision="bf16x3").to(DEV)
+    model.load_state_dict(sd)
+    assert model._indexed_training_call(ib, True) is not None
+    _lib.profile_begin()
+    a = model(ib)
+    a.sum().backward()
+    prof = _lib.profile_end()
+    assert prof["pool"][1] <= 2 + 1          # span + region means (+ the one-off table pooling): no per-pair token pooling
+    g1 = [p.grad.clone() if p.grad is not None else None for p in model.parameters()]
+    model.zero_grad()
+    seq, cls = ib.gathered_pooled(cfg)
+    from drin_amd.model import _Call, _DrinScore, _param_list
+    call = _Call(cfg, seq, _lib.PREC_BF16X3, entity_text_cls=cls)
+    b = _DrinScore.apply(call, None, True, *_param_list(model))
+    b.sum().backward()
+    assert torch.equal(a, b)
+    for x, p in zip(g1, model.parameters()):
+        assert (x is None) == (p.grad is None)
+        if x is not None:
+            assert torch.allclose(x, p.grad, rtol=1e-4, atol=1e-6)
+    ref = O.forward(sd, [t[:2].cpu() for t in ib.gathered()])
+    assert (a[:2].detach().cpu() - ref).abs().max().item() <= 1e-5
+    # the C side refuses what it does not build (here: exact-fp32 precision)
+    bad = _Call(cfg, ib.mention + [table.pooled_text(cfg)[0], torch.zeros(B, dtype=torch.int64, device=DEV), table.image, table.object,
+                                   table.object_score, men[12], men[13]], _lib.PREC_F32, entity_index=cand,
+                entity_text_cls=table.pooled_text(cfg)[1])
+    lib = _lib.load()
+    ws = bad.workspace(True)
+    sc = torch.empty(B, N, device=DEV)
+    pc = _lib.DrinParamsC()
+    from drin_amd.model import _fill_params
+    _fill_params(pc, tuple(p.detach().contiguous() for p in _param_list(model)), bad.per_layer)
+    assert lib.drin_forward(C.byref(bad.cfg), C.byref(bad.batch), C.byref(pc), ws.data_ptr(), ws.numel(), sc.data_ptr(), 1, None,
+                            torch.cuda.current_stream().cuda_stream) == _lib.E_UNSUPPORTED

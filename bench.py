@@ -465,6 +465,8 @@ def main():
             # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
             if dom == "gemm_planes":
                 step_flops = pairs_per_step * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
+                if not cached and (args.workload == "table" or args.features == "bf16"):
+                    step_flops += pairs_per_step * 2.0 * R * D   # x_i C_i^T runs on this kernel too (gathered / bf16 image planes)
             elif dom == "gemm_x3" and fused:
                 # x_i C_i^T plus the mention-sized products, which run on the same kernel from 256 rows up
                 step_flops = pairs_per_step * 2.0 * R * D + (mention_flops(D, R, fused) * B if (x3 and B >= 256) else 0.0)

@@ -511,7 +511,9 @@ class Model(nn.Module):
         pooled, cls = t.pooled_text(self.cfg)
         dummy = torch.zeros(cand.shape[0], dtype=torch.int64, device=cand.device)
         seq = batch.mention + [pooled, dummy, t.image, t.object, t.object_score, batch.miet_similarity, batch.mtei_similarity]
-        return _Call(self.cfg, seq, self.precision, entity_index=cand, entity_text_cls=cls)
+        # the layer-by-layer kernels trust the index (the stream kernel of the fused path clamps it): clamp here, so that a
+        # bad candidate row can never become an out-of-bounds read on the device
+        return _Call(self.cfg, seq, self.precision, entity_index=cand.clamp(0, t.num_entities - 1), entity_text_cls=cls)
 
     @torch.no_grad()
     def _forward_cached(self, call: _Call, table: EntityTable, params) -> torch.Tensor:

@@ -61,6 +61,23 @@ __global__ void __launch_bounds__(256) k_regs(const float* __restrict__ src, flo
   }
 }
 
+// the same bytes with the four waves of a workgroup sharing each run: wave w takes rows w, w + 4, ... (partial sums per wave)
+__global__ void __launch_bounds__(256) k_regs_shared(const float* __restrict__ src, float* __restrict__ out, int64_t pairs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int q = 0; q < PAIRS_PER_WG; ++q) {
+    const int64_t p = (int64_t)blockIdx.x * PAIRS_PER_WG + q;
+    if (p >= pairs) return;
+    const float* base = src + p * (int64_t)ROWS_PER_PAIR * ROW_FLOATS + lane * 4;
+    float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    for (int r = wave; r < ROWS_PER_PAIR; r += 4)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = add4(acc[j], ldnt(base + (int64_t)r * ROW_FLOATS + j * 256));
+    if (wave == 0)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(out + p * ROW_FLOATS + lane * 4 + j * 256) = acc[j];
+  }
+}
+
 // per wave: ring of 2 * IN_FLIGHT rows of 3 KB.  Half h is requested while half h ^ 1 is summed.
 template <int AUX>
 __global__ void __launch_bounds__(256) k_dma(const float* __restrict__ src, float* __restrict__ out, int64_t pairs) {
@@ -142,7 +159,9 @@ int main(int argc, char** argv) {
   const double t_dma2 = time_ms([&] { hipLaunchKernelGGL(k_dma<2>, dim3(grid), dim3(256), lds, 0, src, out, pairs); }, 5);
   printf("%.1f GiB, %lld pairs of %d rows x 3 KB, %d rows in flight per wave\n", bytes / (1ll << 30), (long long)pairs, ROWS_PER_PAIR,
          IN_FLIGHT);
+  const double t_shared = time_ms([&] { hipLaunchKernelGGL(k_regs_shared, dim3(grid), dim3(256), 0, 0, src, out, pairs); }, 5);
   printf("registers (nt loads)     : %7.3f ms  %7.1f GB/s\n", t_regs, bytes / t_regs / 1e6);
+  printf("registers, runs shared by the 4 waves: %7.3f ms  %7.1f GB/s\n", t_shared, bytes / t_shared / 1e6);
   printf("LDS-DMA (default policy) : %7.3f ms  %7.1f GB/s\n", t_dma0, bytes / t_dma0 / 1e6);
   printf("LDS-DMA (aux = 2, nt)    : %7.3f ms  %7.1f GB/s\n", t_dma2, bytes / t_dma2 / 1e6);
   CHECK(hipFree(src));

@@ -1352,3 +1352,35 @@ def test_training_reads_entity_tables_through_the_index():
     _fill_params(pc, tuple(p.detach().contiguous() for p in _param_list(model)), bad.per_layer)
     assert lib.drin_forward(C.byref(bad.cfg), C.byref(bad.batch), C.byref(pc), ws.data_ptr(), ws.numel(), sc.data_ptr(), 1, None,
                             torch.cuda.current_stream().cuda_stream) == _lib.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_full_width_random_batches_three_paths_agree(seed):
+    """D = 768 / R = 2048 with random layout, batch and candidate counts (1 ... 20 000 pairs): every size lands on a different mix
+    of tile shapes, whole-product K splits and tail splits of the split-bf16 kernels.  The folded split-bf16 path, the
+    layer-by-layer split-bf16 path and the folded exact-fp32 path agree within fp32 re-association, and a slice of the batch
+    agrees with the CPU oracle."""
+    g = np.random.default_rng(1000 + seed)
+    wm = bool(g.integers(0, 2))
+    N = int(g.integers(1, 140))
+    B = int(g.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 300]))
+    if B * N > 20000:
+        B = max(1, 20000 // N)
+    cfg = DrinConfig(dataset_name="wikimel" if wm else "wikidiverse", num_candidates_data=N - 1,
+                     max_entity_attr_token_len=int(g.integers(3, 20)))
+    sd = synth.make_state_dict(cfg, 100 + seed)
+    batch = synth.make_device_batch(cfg, B, 500 + seed, DEV)[:14]
+    outs = {}
+    with torch.no_grad():
+        for name, kw in (("folded", dict(precision="bf16x3")), ("layerwise", dict(precision="bf16x3", fused=False)),
+                         ("exact", dict(precision="f32"))):
+            m = Model(cfg, **kw).to(DEV).eval()
+            m.load_state_dict(sd)
+            outs[name] = m(batch)
+    a = outs["folded"]
+    assert torch.isfinite(a).all()
+    assert (a - outs["layerwise"]).abs().max().item() <= 1e-5, (B, N, wm)
+    assert (a - outs["exact"]).abs().max().item() <= 1e-5, (B, N, wm)
+    k = min(B, 2)
+    ref = O.forward(sd, [t[:k].cpu() for t in batch])
+    assert (a[:k].cpu() - ref).abs().max().item() <= 1e-5

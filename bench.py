@@ -1,22 +1,32 @@
 """bench.py - mention x candidate pairs scored per second on WikiMEL-shaped synthetic batches.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload wikimel|wikidiverse] [--batch B]
+    python bench.py [--gpus N --steps K --warmup W] [--workload wikimel|wikidiverse|table] [--mode score|train] ...
 
-One "step" = one pass of the DRIN scoring path (Model.forward, drin/model.py:164-209) over one
-batch of B mentions x N candidates of seeded synthetic features that are already resident in HBM.
-N>1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; every rank scores
-its own shard of mentions (weak scaling, no data-path collective - mentions are independent,
-SURVEY.md 8e); the timed region is bracketed by barrier + synchronize and the max over ranks is used.
+One "step" = one pass of the DRIN scoring path (Model.forward, drin/model.py:164-209) over one batch of B mentions
+x N candidates of seeded synthetic features that are already resident in HBM.
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : dominant kernel class, HIP-event timed inside this process
-  cpu_baseline : the CPU oracle (oracle/drin_oracle.py) timed on this host's cores on a bounded sample
+N > 1: started as a plain process (`python bench.py --gpus N ...`, WORLD_SIZE unset) this file spawns
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` of ITSELF before it
+makes any GPU call and relays rank 0's JSON line and the children's exit code; started by torch.distributed.run it
+is a rank.  Every rank scores its own shard of mentions (weak scaling, no data-path collective - mentions are
+independent); the timed region is bracketed by barrier + synchronize and the max over ranks is used.
+
+Prints ONE JSON line (rank 0): the contract fields of the headline (BASELINE.json's metric on its WikiMEL-100 config) plus
+  roofline     : dominant kernel of the headline, HIP-event timed inside this process on the launch stream
+  cpu_baseline : the CPU oracle (oracle/drin_oracle.py) timed on this host's cores on a bounded sample (N = 1)
+  parity       : slices of the TIMED batch re-scored by the oracle (N = 1)
+  legs         : the other BASELINE configs under the same clock - f32_exact, train_step (configs 3 / 4; the only leg
+                 that also runs at N > 1: one RCCL all-reduce of the flat gradient bucket per step), wikidiverse (config 2,
+                 fp32- and bf16-stored features), table_cache (config 5: 1 M-entity table, 1000 candidates gathered on the
+                 device, mention chunks streamed)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,15 +35,117 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from drin_amd import _lib, synth  # noqa: E402
+from drin_amd import synth  # noqa: E402
 from drin_amd.config import DrinConfig, wikimel_config  # noqa: E402
-from drin_amd.model import Model  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+TRAFFIC_FILE = os.path.join("profiles", "r2_hbm_traffic.json")
+FEAT_SLOTS = (0, 4, 5, 7, 9, 10)  # the six feature tensors of the 14-sequence
 
 
+# =====================================================================================================================
+# launcher: N > 1 from a plain process
+# =====================================================================================================================
+def launch_children(args) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run around it: start the N ranks as child processes of a
+    torch.distributed.run we spawn (this process has made no GPU call and makes none), relay rank 0's JSON line, return the
+    children's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=REPO)
+    lines = []
+    for ln in proc.stdout:                                 # children print little: rank 0's one JSON line
+        if ln.lstrip().startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    for ln in lines:
+        print(ln, flush=True)
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: the ranks exited 0 without printing a JSON line\n")
+        rc = 1
+    return rc
+
+
+class Ctx:
+    """Rank bookkeeping + the contract's timing bracket."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.stub = args.stub
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: WORLD_SIZE={self.world} but --gpus {args.gpus}: start N ranks with "
+                             f"`python bench.py --gpus N` (self-launching) or torch.distributed.run --nproc-per-node N ... --gpus N")
+        if self.stub:
+            self.dev = torch.device("cpu")
+        else:
+            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.stub:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+
+    def sync(self):
+        if not self.stub:
+            torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        self.sync()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.sync()
+
+    def timed(self, run, steps, warmup):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs; returns (max over ranks of the
+        bracketed seconds, [per-rank seconds until the rank's own work had drained], last result)."""
+        out = None
+        for _ in range(warmup):
+            out = run()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = run()
+        self.sync()
+        local = time.perf_counter() - t0
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed, local], dtype=torch.float64, device=self.dev)
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t)
+            elapsed = max(float(p[0]) for p in parts)
+            per_rank = [float(p[1]) for p in parts]
+        else:
+            per_rank = [local]
+        return elapsed, per_rank, out
+
+    def finish(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+# =====================================================================================================================
+# algorithmic work
+# =====================================================================================================================
 def path_flops_per_pair(D, R, layers, dynamic, fused):
     """Pair-sized contraction FLOPs per pair the HIP path executes.
 
@@ -59,34 +171,41 @@ def mention_flops(D, R, fused):
     return 2.0 * D * D + 2.0 * R * D + 2 * 2.0 * D * D * 2 + 2.0 * D * D
 
 
-def algorithmic_bytes_per_pair(cfg, batch):
-    """Compulsory input bytes per pair: entity-side rows that are actually needed
-    + the mention-side bytes amortised over the N candidates + the 4-byte score."""
-    if not isinstance(batch, (list, tuple)):          # table form: 8-byte candidate index + the gathered pooled row
-        D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
-        men = 3 * D * 4 + cfg.resnet_num_region * R * 4 + cfg.object_topk_mention * (R + 1) * 4 + 16
-        return 8 + D * 4 + R * 4 + cfg.object_topk_entity * (R + 1) * 4 + 8 + men / N + 4
-    B, N = batch[0].shape[0], cfg.num_candidates_model
-    D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
-    es = batch[0].element_size()                         # feature storage: 4 (fp32) or 2 (bf16) bytes
-    if cfg.token_level_entities:
-        ntok = batch[8].sum(-1).float()
-        rows = (ntok - 2).clamp(min=0) + 1              # pooled tokens 1..ntok-2 plus the CLS row
-        ent_text = float(rows.mean()) * D * es + batch[8].shape[-1] * 8
+def algorithmic_bytes(cfg, batch):
+    """Compulsory input bytes per pair, split by who reads them:
+      entity  - the entity-side rows one pair needs: pooled tokens 1..ntok-2 plus the CLS row (token form) or the pooled
+                row, the mask, image and object rows, object scores, the two similarities (+ the 8-byte candidate index in
+                table form);
+      mention_stream - mention-side rows the entity pass itself reads once per mention (object rows + scores), / N;
+      mention_pool   - mention-side rows the pooling kernels read (span rows, image regions), / N.
+    whole path = entity + mention_stream + mention_pool + the 4-byte score."""
+    D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
+    Km, Ke = cfg.object_topk_mention, cfg.object_topk_entity
+    if not isinstance(batch, (list, tuple)):              # table form (IndexedBatch): gathered pooled rows
+        es = batch.table.text.element_size()
+        ent = 8 + D * es + R * es + Ke * R * es + Ke * 4 + 8
+        span, mes = 3.0, batch.mention[0].element_size()
     else:
-        ent_text = D * es
-    ent = ent_text + R * es + cfg.object_topk_entity * R * es + (cfg.object_topk_entity + 2) * 4
-    span = float((batch[3] - batch[2]).float().mean())
-    men = span * D * es + cfg.resnet_num_region * R * es + cfg.object_topk_mention * (R * es + 4) + 16
-    return ent + men / N + 4
+        es = mes = batch[0].element_size()                # feature storage: 4 (fp32) or 2 (bf16) bytes
+        if cfg.token_level_entities:
+            ntok = batch[8].sum(-1).float()
+            rows = (ntok - 2).clamp(min=0) + 1            # pooled tokens 1..ntok-2 plus the CLS row
+            ent_text = float(rows.mean()) * D * es + batch[8].shape[-1] * 8
+        else:
+            ent_text = D * es
+        ent = ent_text + R * es + Ke * R * es + Ke * 4 + 8
+        span = float((batch[3] - batch[2]).float().mean())
+    men_stream = (Km * R * mes + Km * 4) / N
+    men_pool = (span * D * mes + cfg.resnet_num_region * R * mes + 16) / N
+    return {"entity": ent, "mention_stream": men_stream, "mention_pool": men_pool,
+            "whole_path": ent + men_stream + men_pool + 4}
 
 
-def measured_traffic(kernel_prefix, B, precision, fused, features="f32", section="kernels"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_pmc.py),
-    valid only for the configuration they were taken on (default workload, or the cached-table one); None otherwise."""
-    path = os.path.join(REPO, "profiles", "r1_hbm_traffic.json")
-    want_b = 4096 if section == "kernels" else 256
-    if not (os.path.exists(path) and B == want_b and precision == "bf16x3" and fused and features == "f32"):
+def measured_traffic(kernel_prefix, section, matches):
+    """HBM bytes per launch of a kernel from the committed PMC passes (tools/collect_pmc.py) - NOT re-measured in this
+    run: valid only for the configuration the passes were taken on (`matches`), None otherwise."""
+    path = os.path.join(REPO, TRAFFIC_FILE)
+    if not (matches and os.path.exists(path)):
         return None
     try:
         for k, v in json.load(open(path)).get(section, {}).items():
@@ -97,83 +216,326 @@ def measured_traffic(kernel_prefix, B, precision, fused, features="f32", section
     return None
 
 
-def host_cores() -> int:
-    """CPU cores this process may actually use (affinity and cgroup quota, not the node's total)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+KERNEL_NAMES = {"stream": "k_entity_stream", "gemm_planes": "k_gemm_x3_planes", "gemm_x3": "k_gemm_bf16x3", "gemm": "k_gemm_f32",
+                "gcn": "row kernels (k_pair_layer1, k_pair_final, ...)", "pool": "pooling kernels", "edge": "edge kernels"}
+
+
+def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused):
+    """Roofline object of the dominant kernel class of an instrumented pass + the whole-path fractions' inputs."""
+    D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
+    pairs = B * N
+    dom = max(prof, key=lambda k: prof[k][0])
+    ms, launches = prof[dom]
+    per_launch_ms = ms / max(launches, 1)
+    x3 = precision in ("bf16x3", "bf16")
+    flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
+    ab = algorithmic_bytes(cfg, batch)
+    stream_bytes_pair = ab["entity"] + ab["mention_stream"]          # what k_entity_stream itself has to read
+    if cached:
+        # k_cached_pairs: one gathered cache row in (h_t, h_i, c^, o^, sg and, with dynamic edges, fv_t, fv_i),
+        # the candidate index and two similarities; et' planes and the four layer-2 edges out
+        row = ((5 if cfg.gcn_edge_type == "dynamic" else 3) * D + R + 4) * 4
+        stream_bytes_pair = row + 8 + 8 + D * 4 + 16
+        flops_pair = 2.0 * D * D
+    names = dict(KERNEL_NAMES)
+    if cached:
+        names["stream"] = "k_cached_pairs"
+    if dom == "stream":
+        work = stream_bytes_pair * pairs * steps / max(launches, 1)
+        achieved = work / (per_launch_ms * 1e-3) / 1e9
+        default_cfg = B == 4096 and precision == "bf16x3" and fused and features == "f32" and workload == "wikimel"
+        traffic = (measured_traffic("k_cached_pairs", "kernels_table_cache", B == 4096 and features == "f32") if cached
+                   else measured_traffic("k_entity_stream", "kernels", default_cfg))
+        roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                "traffic_source": (f"{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration "
+                                   "(tools/collect_pmc.py), replayed - not re-measured in this run") if traffic else None,
+                "launches": int(launches), "avg_launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": work}
+    else:
+        # algorithmic FLOPs the kernel's launches cover in one step / their summed time.  In split-bf16
+        # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
+        if dom == "gemm_planes":
+            step_flops = pairs * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
+            if not cached and (workload == "table" or features == "bf16"):
+                step_flops += pairs * 2.0 * R * D   # x_i C_i^T runs on this kernel too (gathered / bf16 image planes)
+        elif dom == "gemm_x3" and fused:
+            # x_i C_i^T plus the mention-sized products, which run on the same kernel from 256 rows up
+            step_flops = pairs * 2.0 * R * D + (mention_flops(D, R, fused) * B if (x3 and B >= 256) else 0.0)
+        else:
+            step_flops = flops_pair * pairs + mention_flops(D, R, fused) * B
+        achieved = step_flops * steps / (ms * 1e-3) / 1e12
+        peak = PEAK_F32_MATRIX_TFLOPS if dom == "gemm" else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(launches),
+                "avg_launch_ms": per_launch_ms}
+        if dom != "gemm":
+            passes = 1 if precision == "bf16" else 3
+            roof["executed_bf16_tflops"] = passes * achieved
+            roof["executed_frac"] = passes * achieved / peak
+    return roof, ab, stream_bytes_pair, flops_pair
+
+
+def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision):
+    D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
+    x3 = precision in ("bf16x3", "bf16")
+    peak = (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12
+    ref_flops = 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D
+    return {
+        "hbm_fraction_whole_path": ab["whole_path"] * rate_per_gpu / (PEAK_HBM_GBS * 1e9),
+        # matrix-core work the path executes (split-bf16: three bf16 MFMA passes per algorithmic product) and the
+        # reference-faithful operation count at the same rate, both against the dense peak of the arithmetic type
+        "mfma_fraction_whole_path": ((1 if precision == "bf16" else 3) if x3 else 1) * flops_pair * rate_per_gpu / peak,
+        "mfma_fraction_reference_flops": ref_flops * rate_per_gpu / peak,
+    }, ref_flops
+
+
+# =====================================================================================================================
+# host baseline + parity
+# =====================================================================================================================
+def host_threads():
+    """Threads the CPU baseline uses and where the number comes from: the cores this process may run on
+    (affinity intersected with the cgroup quota), unless DRIN_CPU_THREADS overrides it - then that is stated."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else info["os_cpu_count"]
+    info["affinity"] = n
+    info["cgroup_quota_cpus"] = None
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
+            info["cgroup_quota_cpus"] = int(quota) / int(period)
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("DRIN_CPU_THREADS", "16"))))
+    info["capped_by"] = None
+    env = os.environ.get("DRIN_CPU_THREADS")
+    if env:
+        n, info["capped_by"] = max(1, min(n, int(env))), "DRIN_CPU_THREADS"
+    info["threads_used"] = max(1, n)
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                info["cpu_model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return info
 
 
-def cpu_baseline(cfg, sd, seconds=12.0, model=None, dev=None, features="f32"):
-    """The CPU oracle timed on the host cores this process may use; with `model`, the same sample batches are also
-    scored by the HIP path and compared (max |score error|, top-1 agreement) - the checker, never the thing measured."""
+def _time_oracle(fn, seconds, max_iter):
+    fn()                                                   # warm-up
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        fn()
+        it += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or it >= max_iter:
+            return it, el
+
+
+def cpu_baseline(cfg, sd, seconds=10.0):
+    """The CPU oracle (the reference restated, pinned by tests/golden) timed on this host's cores on bounded samples:
+    the headline shape at B=8 (20 MB of fp32 tokens per mention make larger host batches pointless), the same with the
+    reference's own Python loops kept, and the WikiDiverse B=64 sample SURVEY.md 8d names."""
     from oracle import drin_oracle as O
 
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    host = host_threads()
+    torch.set_num_threads(host["threads_used"])
     B = 8 if cfg.token_level_entities else 64
     batch = synth.make_batch(cfg, B, 3)
-    parity = None
-    if model is not None:
-        err, agree, total, err32, agree32 = 0.0, 0, 0, 0.0, 0
-        feat_slots = (0, 4, 5, 7, 9, 10)    # the six feature tensors of the 14-sequence
-        with torch.no_grad():
-            for seed in range(3, 3 + (8 if cfg.token_level_entities else 2)):   # 64 / 128 mentions
-                b = synth.make_batch(cfg, B, seed)
-                ref32 = O.forward(sd, b)
-                if features == "bf16":   # stored as bf16 on the device; the oracle scores the same values widened
-                    stored = [t.to(torch.bfloat16) if i in feat_slots else t for i, t in enumerate(b[:14])]
-                    ref = O.forward(sd, [t.float() if t.dtype == torch.bfloat16 else t for t in stored])
-                else:
-                    stored, ref = b[:14], ref32
-                got = model([t.to(dev) for t in stored]).cpu()
-                err = max(err, (got - ref).abs().max().item())
-                agree += int((got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).sum())
+    N = cfg.num_candidates_model
+    with torch.no_grad():
+        it, el = _time_oracle(lambda: O.forward(sd, batch), seconds, 2000)
+        # the same arithmetic with the reference's own Python loops over mentions and candidates kept
+        # (baselines/ghmfc.py:58-59,246-249; model.py:86-91): its cost profile, ~4 s sample
+        it_r, el_r = _time_oracle(lambda: O.reference_style_forward(sd, batch), 4.0, 500)
+        wd = DrinConfig()
+        wd_sd = synth.make_state_dict(wd, 7)
+        wd_batch = synth.make_batch(wd, 64, 3)
+        it_w, el_w = _time_oracle(lambda: O.forward(wd_sd, wd_batch), 4.0, 2000)
+    return {"value": it * B * N / el, "unit": "pairs/s", "cores": host["threads_used"], "kind": "port",
+            "host": host,
+            "reference_style_loops_value": it_r * B * N / el_r,
+            "wikidiverse_b64_value": it_w * 64 * wd.num_candidates_model / el_w,
+            "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={N} fp32, torch "
+                      f"{torch.get_num_threads()} threads, {el:.1f} s; reference-style loops {it_r} forwards {el_r:.1f} s; "
+                      f"wikidiverse-shaped B=64 N={wd.num_candidates_model}: {it_w} forwards {el_w:.1f} s"}
+
+
+def slice_batch(batch, rows):
+    """Mentions `rows` (a slice) of a 14-sequence or an IndexedBatch, as the equivalent CPU 14-sequence."""
+    if isinstance(batch, (list, tuple)):
+        return [t[rows].cpu() for t in batch[:14]]
+    from drin_amd.model import IndexedBatch
+    sub = IndexedBatch([t[rows] for t in batch.mention], batch.table, batch.candidates[rows],
+                       batch.miet_similarity[rows], batch.mtei_similarity[rows])
+    return [t.cpu() for t in sub.gathered()]
+
+
+def parity_of_timed_batch(cfg, sd, batch, out, n_slices=8, width=8, fp32_batch=None):
+    """Slices of the TIMED batch (mentions are independent: the timed output rows are the scores of those mentions) scored
+    by the CPU oracle on the same values - the checker, never the thing measured."""
+    from oracle import drin_oracle as O
+
+    B = out.shape[0]
+    width = min(width, B)
+    starts = sorted({int(round(i * (B - width) / max(n_slices - 1, 1))) for i in range(n_slices)})
+    err, agree, total, err32, agree32 = 0.0, 0, 0, 0.0, 0
+    with torch.no_grad():
+        for s in starts:
+            rows = slice(s, s + width)
+            host = [t.float() if t.dtype == torch.bfloat16 else t for t in slice_batch(batch, rows)]
+            ref = O.forward(sd, host)
+            got = out[rows].float().cpu()
+            err = max(err, (got - ref).abs().max().item())
+            agree += int((got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).sum())
+            if fp32_batch is not None:               # what storing the features as bf16 costs against the fp32 inputs
+                ref32 = O.forward(sd, slice_batch(fp32_batch, rows))
                 err32 = max(err32, (got - ref32).abs().max().item())
                 agree32 += int((got[:, :-1].argmax(1) == ref32[:, :-1].argmax(1)).sum())
-                total += B
-        parity = {"max_abs_score_err": err, "top1_agreement": agree / total, "mentions": total,
-                  "against": "CPU oracle (pinned to the reference by tests/golden), same synthetic inputs"
-                             + (" as stored (bf16 values widened)" if features == "bf16" else "")}
-        if features == "bf16":           # what storing the features as bf16 costs against the fp32 inputs (SURVEY.md 8d config 2)
-            parity["vs_fp32_features"] = {"max_abs_score_err": err32, "top1_agreement": agree32 / total}
+            total += width
+    par = {"max_abs_score_err": err, "top1_agreement": agree / total, "mentions": total,
+           "against": "CPU oracle (pinned to the reference by tests/golden) on slices of the timed batch, same stored values"}
+    if fp32_batch is not None:
+        par["vs_fp32_features"] = {"max_abs_score_err": err32, "top1_agreement": agree32 / total}
+    return par
+
+
+# =====================================================================================================================
+# scoring legs
+# =====================================================================================================================
+def make_model(cfg, sd, dev, precision, fused=True):
+    from drin_amd.model import Model
+    model = Model(cfg, precision=precision, fused=fused).to(dev).eval()
+    model.load_state_dict(sd)
+    return model
+
+
+def run_score(ctx, model, batch, steps, warmup, graph=False):
+    """Timed K steps of model(batch) + an instrumented pass (HIP events on the launch stream, per kernel class)."""
+    from drin_amd import _lib
     with torch.no_grad():
-        O.forward(sd, batch)  # warm-up
+        run = lambda: model(batch)  # noqa: E731
+        if graph:
+            # small batches are a chain of ~25 short launches: the library allocates nothing and never synchronises,
+            # so the whole scoring call replays as one hipGraph (the weights' folded products are built before capture)
+            for _ in range(3):
+                model(batch)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(batch)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = model(batch)
+
+            def run():
+                g.replay()
+                return static_out
+        elapsed, per_rank, out = ctx.timed(run, steps, warmup)
+        assert torch.isfinite(out).all()
+        _lib.profile_begin(1 << 16)
+        for _ in range(steps):
+            model(batch)
+        prof = _lib.profile_end()
+    return elapsed, per_rank, out, prof
+
+
+def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup, precision, features, workload, cached, fused, graph=False):
+    D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
+    pairs = B * N
+    roof, ab, stream_bytes_pair, flops_pair = score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused)
+    value = pairs * ctx.world * steps / elapsed
+    fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision)
+    line = {
+        "metric": "mention x candidate pairs scored/sec",
+        "value": value, "unit": "pairs/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": precision, "data": "synthetic",
+        "config": {"workload": f"{cfg.dataset_name}-shaped scoring forward: {N - 1}-cand (+1 answer slot), D={D}, R={R}, "
+                               f"L={cfg.max_mention_sentence_len}, P={cfg.resnet_num_region}"
+                               + (f", T={cfg.max_entity_attr_token_len} token-level entity text" if cfg.token_level_entities else "")
+                               + (", candidates gathered on the device from an entity table" if workload == "table" else ""),
+                   "mentions_per_step_per_gpu": B, "pairs_per_step": pairs * ctx.world,
+                   "parallelism": f"dp{ctx.world} (mentions sharded, no collective)"},
+        "rank_ms_per_step": [t / steps * 1e3 for t in per_rank],
+        "roofline": roof,
+        "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items()},
+        **fr,
+        "launch": "hipGraph replay" if graph else "eager",
+        "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + precision
+                + (", features stored as bf16" if features == "bf16" else ""),
+        "algorithmic": {"bytes_per_pair": ab["whole_path"], "dominant_kernel_bytes_per_pair": stream_bytes_pair,
+                        "bytes_per_pair_split": ab, "flops_per_pair_executed": flops_pair, "flops_per_pair_reference": ref_flops},
+    }
+    return line
+
+
+def compact(line, keep=("value", "unit", "ms_per_step", "steps", "dtype", "path", "roofline", "kernel_ms_per_step", "hbm_fraction_whole_path",
+                        "mfma_fraction_whole_path", "parity")):
+    """A secondary leg's entry of the one JSON line."""
+    out = {"workload": line["config"]["workload"], "mentions_per_step": line["config"]["mentions_per_step_per_gpu"]}
+    out.update({k: line[k] for k in keep if k in line})
+    return out
+
+
+def build_table(cfg, E, dev, seed=7):
+    from drin_amd.model import EntityTable
+    D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return EntityTable(torch.randn(E, D, device=dev, generator=g), None, torch.randn(E, R, device=dev, generator=g),
+                       torch.randn(E, 1, R, device=dev, generator=g), torch.rand(E, 1, device=dev, generator=g)), g
+
+
+def make_table_chunk(cfg, table, B, seed, dev, g):
+    from drin_amd.model import IndexedBatch
+    N, E = cfg.num_candidates_model, table.num_entities
+    men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, seed, dev)
+    cand = torch.randint(0, E, (B, N), device=dev, generator=g)
+    sims = 20.0 + 5.0 * torch.randn(2, B, N, device=dev, generator=g)
+    return IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+
+
+def stream_table(ctx, model, cfg, table, g, mentions, chunk, seed0=1000):
+    """BASELINE config 5 as SURVEY.md 8d words it: `mentions` mentions x N candidates streamed through the scoring path in
+    chunks of `chunk` mentions - the mention side of chunk c+1 and its candidate rows are drawn on a second HIP stream while
+    chunk c is being scored; nothing but the current and the next chunk is resident.  Returns (seconds, chunks, last scores, last chunk)."""
+    main = torch.cuda.current_stream(ctx.dev)
+    side = torch.cuda.Stream(ctx.dev)
+    n_chunks = (mentions + chunk - 1) // chunk
+
+    def draw(c):
+        b = min(chunk, mentions - c * chunk)
+        with torch.cuda.stream(side):
+            ib = make_table_chunk(cfg, table, b, seed0 + c, ctx.dev, g)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in ib.mention + [ib.candidates, ib.miet_similarity, ib.mtei_similarity]:
+            t.record_stream(main)
+        return ib, ev
+
+    with torch.no_grad():
+        nxt = draw(0)
+        ctx.barrier()
         t0 = time.perf_counter()
-        it = 0
-        while True:
-            O.forward(sd, batch)
-            it += 1
-            el = time.perf_counter() - t0
-            if el >= seconds or it >= 2000:
-                break
-    pairs = it * B * cfg.num_candidates_model
-    # the same arithmetic with the reference's own Python loops over mentions and candidates kept
-    # (baselines/ghmfc.py:58-59,246-249; model.py:86-91): its cost profile, ~5 s sample
-    with torch.no_grad():
-        O.reference_style_forward(sd, batch)  # warm-up
-        t1 = time.perf_counter()
-        it_ref = 0
-        while True:
-            O.reference_style_forward(sd, batch)
-            it_ref += 1
-            el_ref = time.perf_counter() - t1
-            if el_ref >= 5.0 or it_ref >= 500:
-                break
-    ref_style = it_ref * B * cfg.num_candidates_model / el_ref
-    out = {"value": pairs / el, "unit": "pairs/s", "cores": cores, "kind": "port",
-           "reference_style_loops_value": ref_style,
-           "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={cfg.num_candidates_model} fp32, "
-                     f"torch {torch.get_num_threads()} threads, {el:.1f} s"}
-    return out, parity
+        out = None
+        for c in range(n_chunks):
+            ib, ev = nxt
+            main.wait_event(ev)
+            if c + 1 < n_chunks:
+                side.wait_stream(main)                      # at most one chunk ahead: bounds the resident set
+                nxt = draw(c + 1)
+            out = model(ib)
+        ctx.barrier()
+        return time.perf_counter() - t0, n_chunks, out, ib
 
 
-def train_roofline(cfg, B, N, prof, args):
+# =====================================================================================================================
+# training leg (BASELINE configs 3 / 4)
+# =====================================================================================================================
+def train_roofline(cfg, B, N, prof, steps, precision):
     """The dominant kernel class of a training step is the split-bf16 GEMM family (k_gemm_bf16x3 + k_gemm_tn_bf16x3):
     algorithmic FLOPs of the pair-sized contractions (forward with the dead work of the last layer removed, dX and dW of
     backward: 17 D^2 + 2 . 2 R D multiply-adds per pair for two dynamic layers) over its summed launch time."""
@@ -191,8 +553,8 @@ def train_roofline(cfg, B, N, prof, args):
     ms, launches = prof.get("gemm_x3", (0.0, 0))
     if ms <= 0:
         return None
-    tf = (fwd + bwd) * B * N * args.steps / (ms * 1e-3) / 1e12
-    x3 = args.precision in ("bf16x3", "bf16")
+    tf = (fwd + bwd) * B * N * steps / (ms * 1e-3) / 1e12
+    x3 = precision in ("bf16x3", "bf16")
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS
     out = {"bound": "mfma", "kernel": "k_gemm_bf16x3 + k_gemm_tn_bf16x3", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
            "frac": tf / peak, "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
@@ -202,23 +564,30 @@ def train_roofline(cfg, B, N, prof, args):
     return out
 
 
-def bench_train(args, cfg, model, dev, world, rank, B, barrier):
+def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f32", train_form="gathered", train_entities=50_000,
+                graph=False, fused_adam=False, torch_loss=False, library_adam=True):
     """One optimisation step of train.py:30-56 per "step": forward (intermediates kept), TripletLoss, backward
     through the HIP kernels, one RCCL all-reduce of the flat gradient bucket (world > 1), Adam."""
+    from drin_amd import _lib
     from drin_amd.metrics import DeviceLossMetric
-    from drin_amd.train import GradBucket
+    from drin_amd.model import Model
+    from drin_amd.train import GradBucket, make_adam
 
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
+    model = Model(cfg, precision=precision).to(dev)
+    model.load_state_dict(sd)
     model.train()
-    full = synth.make_device_batch(cfg, B, 200 + rank, dev, dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)
+    fdt = torch.bfloat16 if features == "bf16" else torch.float32
+    full = synth.make_device_batch(cfg, B, 200 + rank, dev, dtype=fdt)
     batch, y = full[:14], full[14]
-    if args.train_form != "gathered":
+    ib = None
+    if train_form != "gathered":
         # table form (SURVEY.md 8f-1): the entity tables live on the device, a step carries candidate indices.
         # "table": the library pools every entity's tokens once and gathers pooled rows; "table-tokens": the token
         # blocks are gathered with torch indexing every step (what the reference's loader does on the host)
         from drin_amd.model import EntityTable, IndexedBatch
-        E = args.train_entities
-        tab = synth.make_device_batch(cfg.with_(num_candidates_data=E - 1), 1, 300 + rank, dev,
-                                      dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)
+        E = train_entities
+        tab = synth.make_device_batch(cfg.with_(num_candidates_data=E - 1), 1, 300 + rank, dev, dtype=fdt)
         table = EntityTable(tab[7][0], tab[8][0] if cfg.token_level_entities else None, tab[9][0], tab[10][0], tab[11][0])
         del tab
         g = torch.Generator(device=dev)
@@ -226,24 +595,32 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
         cand = torch.randint(0, E, (B, cfg.num_candidates_model), device=dev, generator=g)
         ib = IndexedBatch(batch[:7], table, cand, batch[12], batch[13])
         full = None
-        batch = ib if args.train_form == "table" else None
+        batch = ib if train_form == "table" else None
     loss_fn = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk, dev)   # loss + top-k counters in one library call, as MELRunner
-    if args.torch_loss:
+    if torch_loss:
         from drin_amd.metrics import TripletLoss
         loss_fn = TripletLoss(cfg.triplet_margin)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=args.graph, **({"fused": True} if args.fused_adam else {}))   # default: as train.py:55-56
+    opt = make_adam(model, cfg.learning_rate, library=library_adam and not graph and not fused_adam, capturable=graph, fused=fused_adam)
     bucket = GradBucket(list(model.parameters()))
+    ar_events = []
 
-    def eager_step():
+    def eager_step(record=False):
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(y, model(batch if batch is not None else ib.gathered()))
         loss.backward()
-        bucket.allreduce_mean()
+        if record and world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.allreduce_mean()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            bucket.allreduce_mean()
         opt.step()
         return loss
 
     step = eager_step
-    if args.graph:
+    if graph:
         # the library allocates nothing and never synchronises, so the step is capture-safe: ~100 launches
         # (forward, loss, backward, Adam) become one hipGraph replay and the host drops out of the loop
         side = torch.cuda.Stream()
@@ -252,54 +629,78 @@ def bench_train(args, cfg, model, dev, world, rank, B, barrier):
             for _ in range(3):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        cg = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(cg):
             static_loss = eager_step()
 
         def step():
-            graph.replay()
+            cg.replay()
             return static_loss
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, per_rank, loss = ctx.timed(step, steps, warmup)
     _lib.profile_begin(1 << 16)
-    for _ in range(args.steps):
-        eager_step()
+    for _ in range(steps):
+        eager_step(record=True)
     prof = _lib.profile_end()
-    if rank == 0:
-        N = cfg.num_candidates_model
-        print(json.dumps({
-            "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)" + (" [hipGraph replay]" if args.graph else ""),
-            "value": B * N * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)"
-                                   + (", features stored as bf16 (token blocks pooled in place, the rest widened)" if args.features == "bf16" else "")
-                                   + ({"gathered": "", "table": f", candidates indexed into a device-resident table of {args.train_entities} entities (tokens pooled once per entity)",
-                                       "table-tokens": f", candidates gathered from a device-resident table of {args.train_entities} entities with torch indexing every step"}[args.train_form]),
-                       "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
-            "roofline": train_roofline(cfg, B, N, prof, args),
-            "final_loss": float(loss)}))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.sync()
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
+    N = cfg.num_candidates_model
+    return {
+        "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)" + (" [hipGraph replay]" if graph else ""),
+        "value": B * N * world * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
+        "config": {"workload": f"{cfg.dataset_name}-shaped training step, {N - 1}-cand, per-GPU batch {B} (args.py:118)"
+                               + (", features stored as bf16 (token blocks pooled in place, the rest widened)" if features == "bf16" else "")
+                               + ({"gathered": "", "table": f", candidates indexed into a device-resident table of {train_entities} entities (tokens pooled once per entity)",
+                                   "table-tokens": f", candidates gathered from a device-resident table of {train_entities} entities with torch indexing every step"}[train_form]),
+                   "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
+        "rank_ms_per_step": [t / steps * 1e3 for t in per_rank],
+        "allreduce_ms": ar_ms, "allreduce_bytes": bucket.nbytes(),
+        "optimizer": opt.describe() if hasattr(opt, "describe") else type(opt).__name__,
+        "library_launches_per_step": sum(v[1] for v in prof.values()) / steps,
+        "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items()},
+        "roofline": train_roofline(cfg, B, N, prof, steps, precision),
+        "final_loss": float(loss)}
 
 
-def main():
+# =====================================================================================================================
+# stub worker: the launcher / timing / reporting plumbing on CPU + gloo (tests/test_bench_launcher.py)
+# =====================================================================================================================
+def stub_worker(ctx, args):
+    """No GPU, no library: a "step" sleeps (rank r: (r + 1) ms) so that the barrier / max-over-ranks / per-rank
+    reporting and - in train mode - the flat-bucket all-reduce can be exercised with gloo."""
+    from drin_amd.train import GradBucket
+    if os.environ.get("DRIN_BENCH_STUB_FAIL_RANK") == str(ctx.rank):    # tests: a rank that dies must fail the parent
+        raise SystemExit(3)
+    params = [torch.nn.Parameter(torch.zeros(257)), torch.nn.Parameter(torch.zeros(31, 3))]
+    bucket = GradBucket(params)
+
+    def step():
+        time.sleep(1e-3 * (ctx.rank + 1))
+        if args.mode == "train":
+            for p in params:
+                p.grad = torch.full_like(p, float(ctx.rank + 1))
+            bucket.allreduce_mean()
+        return None
+
+    elapsed, per_rank, _ = ctx.timed(step, args.steps, args.warmup)
+    if args.mode == "train":
+        want = sum(range(1, ctx.world + 1)) / ctx.world
+        assert all(torch.allclose(p.grad, torch.full_like(p, want)) for p in params), "stub all-reduce mean is wrong"
+    if ctx.rank == 0:
+        print(json.dumps({"metric": "stub steps/sec (launcher plumbing only, no GPU work)", "stub": True,
+                          "value": args.steps * ctx.world / elapsed, "unit": "steps/s", "n_gpus": ctx.world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": f"stub {args.mode}"},
+                          "rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}), flush=True)
+    ctx.finish()
+
+
+# =====================================================================================================================
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -312,6 +713,10 @@ def main():
     ap.add_argument("--entities", type=int, default=1_000_000)
     ap.add_argument("--entity-cache", action="store_true",
                     help="table workload: score from the per-entity precompute cache (SURVEY.md 8f-2; built during warm-up)")
+    ap.add_argument("--mentions", type=int, default=0,
+                    help="table workload: stream this many mentions through the path in chunks of --chunk (SURVEY.md 8d config 5: "
+                         "--mentions 1000000 --chunk 4096); a step is one chunk")
+    ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 4096 wikimel / 16384 wikidiverse / 512 table)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
@@ -329,194 +734,191 @@ def main():
     ap.add_argument("--train-entities", type=int, default=50_000, help="rows of the entity tables of --train-form table")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (score: the scoring call; train: forward, loss, backward, Adam) in one hipGraph and replay it")
-    ap.add_argument("--fused-adam", action="store_true", help="train mode: torch's fused single-kernel Adam instead of its default multi-tensor one (7 launches): -0.27 ms per step, different rounding")
+    ap.add_argument("--fused-adam", action="store_true", help="train mode: torch's fused single-kernel Adam (different rounding)")
+    ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.optim.Adam (multi-tensor, ~9 launches) instead of the library's one-launch Adam over the flat parameter bucket")
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--legs", default="auto",
+                    help="secondary legs of the default run, comma separated: f32_exact,train_step,wikidiverse,table_cache | all | none "
+                         "(auto: all for the default headline at N = 1, train_step at N > 1, none when a non-default workload / mode / batch is asked for)")
+    ap.add_argument("--stub", action="store_true", help="CPU + gloo stand-in step (no GPU, no library): exercises the launcher and the timing plumbing only")
+    args = ap.parse_args(argv)
     if args.warmup is None:
         args.warmup = 30 if args.mode == "train" else 3
+    return args
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+
+def wanted_legs(args, world):
+    names = ("f32_exact", "train_step", "wikidiverse", "table_cache")
+    default_headline = (args.workload == "wikimel" and args.mode == "score" and not args.batch and not args.generic
+                        and args.precision == "bf16x3" and args.features == "f32" and not args.graph)
+    if args.legs == "auto":
+        if not default_headline:
+            return ()
+        return names if world == 1 else ("train_step",)
+    if args.legs == "none":
+        return ()
+    if args.legs == "all":
+        return names
+    legs = tuple(x for x in args.legs.split(",") if x)
+    for x in legs:
+        if x not in names:
+            raise SystemExit(f"unknown leg {x!r}; choose from {names}")
+    return legs
+
+
+def leg_guard(name, fn):
+    """A secondary leg must never take the headline line down with it."""
+    try:
+        t0 = time.perf_counter()
+        out = fn()
+        out["leg_wall_s"] = time.perf_counter() - t0
+        return out
+    except Exception as e:  # noqa: BLE001 - reported in the line, not swallowed silently
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_children(args))                     # before anything touches the GPU in this process
+    ctx = Ctx(args)
+    if args.stub:
+        return stub_worker(ctx, args)
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
 
     if args.workload == "table":
         cfg = DrinConfig(num_candidates_data=1000)       # pooled-text entity rows: 19.7 KB per entity in fp32
     else:
         cfg = wikimel_config() if args.workload == "wikimel" else DrinConfig()
+    sd = synth.make_state_dict(cfg, 7)
+
+    if args.mode == "train":
+        line = bench_train(ctx, cfg, sd, args.batch or 64, args.steps, args.warmup, args.precision, args.features, args.train_form,
+                           args.train_entities, args.graph, args.fused_adam, args.torch_loss, not args.torch_adam)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return ctx.finish()
+
     # WikiMEL: 4096 mentions = 413 696 pairs and 92 GB of resident inputs per step (of 288 GB): large steps
     # amortise the latency-bound mention-side kernels and the GEMM tile quantisation (22.6 vs 20.0 M pairs/s
     # at 1024 mentions)
     default_b = {"wikimel": 4096, "wikidiverse": 16384, "table": 512}[args.workload]
-    B = args.batch or (default_b if args.mode == "score" else 64)
-    sd = synth.make_state_dict(cfg, 7)
-    model = Model(cfg, precision=args.precision, fused=not args.generic).to(dev).eval()
-    model.load_state_dict(sd)
-    N = cfg.num_candidates_model
+    B = args.batch or default_b
+    fused = not args.generic and cfg.num_gcn_layers == 2
+    model = make_model(cfg, sd, dev, args.precision, fused=not args.generic)
+    legs = wanted_legs(args, world)
+    extra = {}
+
     if args.workload == "table":
-        from drin_amd.model import EntityTable, IndexedBatch
-        E, D, R = args.entities, cfg.bert_embed_dim, cfg.resnet_embed_dim
-        g = torch.Generator(device=dev)
-        g.manual_seed(7)
-        table = EntityTable(torch.randn(E, D, device=dev, generator=g), None, torch.randn(E, R, device=dev, generator=g),
-                            torch.randn(E, 1, R, device=dev, generator=g), torch.rand(E, 1, device=dev, generator=g))
-        men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 100 + rank, dev)
-        cand = torch.randint(0, E, (B, N), device=dev, generator=g)
-        sims = 20.0 + 5.0 * torch.randn(2, B, N, device=dev, generator=g)
-        batch = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+        table, g = build_table(cfg, args.entities, dev)
         if args.entity_cache:
             table.enable_cache()
+        if args.mentions:
+            # config 5 streamed: a step is one chunk; K is fixed by --mentions / --chunk
+            with torch.no_grad():
+                model(make_table_chunk(cfg, table, min(args.chunk, 64), 99, dev, g))    # folds the weights / builds the cache
+            el, n_chunks, out, last = stream_table(ctx, model, cfg, table, g, args.mentions, args.chunk)
+            assert torch.isfinite(out).all()
+            N = cfg.num_candidates_model
+            line = {"metric": "mention x candidate pairs scored/sec", "value": args.mentions * N * world / el, "unit": "pairs/s",
+                    "n_gpus": world, "steps": n_chunks, "warmup": 1, "ms_per_step": el / n_chunks * 1e3, "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": f"BASELINE config 5: {args.mentions} mentions x {N - 1} candidates (+1 answer slot) gathered on the device from a "
+                                           f"{args.entities}-entity table, streamed in chunks of {args.chunk} mentions (next chunk drawn on a second stream)",
+                               "mentions_per_step_per_gpu": args.chunk, "pairs_per_step": args.chunk * N * world,
+                               "parallelism": f"dp{world} (mentions sharded, no collective)"},
+                    "path": ("per-entity cache + layer 2" if args.entity_cache else "fused two-layer") + ", " + args.precision}
+            if rank == 0:
+                line["parity"] = parity_of_timed_batch(cfg, sd, last, out, n_slices=2, width=1)
+                print(json.dumps(line), flush=True)
+            return ctx.finish()
+        batch = make_table_chunk(cfg, table, B, 100 + rank, dev, g)
     else:
-        batch = synth.make_device_batch(cfg, B, 100 + rank, dev,
-                                        dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)[:14]
-    pairs_per_step = B * N
+        batch = synth.make_device_batch(cfg, B, 100 + rank, dev, dtype=torch.bfloat16 if args.features == "bf16" else torch.float32)[:14]
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    elapsed, per_rank, out, prof = run_score(ctx, model, batch, args.steps, args.warmup, args.graph)
+    cached = args.workload == "table" and args.entity_cache
+    line = score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, args.steps, args.warmup, args.precision, args.features,
+                      args.workload, cached, fused, args.graph)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["parity"] = parity_of_timed_batch(cfg, sd, batch, out, n_slices=(2 if args.workload == "table" else 8),
+                                               width=(1 if args.workload == "table" else 8 if cfg.token_level_entities else 16))
 
-    if args.mode == "train":
-        return bench_train(args, cfg, model, dev, world, rank, B, barrier)
+    # ---- secondary legs: the other BASELINE configs under the same clock -------------------------------------------------
+    if "f32_exact" in legs:
+        def f32_leg():
+            m = make_model(cfg, sd, dev, "f32")
+            st = max(2, min(args.steps, 5))
+            e, pr, o, pf = run_score(ctx, m, batch, st, 1)
+            ln = score_line(ctx, cfg, args, B, batch, e, pr, pf, st, 1, "f32", args.features, args.workload, False, True)
+            ln["parity"] = parity_of_timed_batch(cfg, sd, batch, o, n_slices=4, width=8)
+            ln["max_abs_diff_vs_headline_scores"] = float((o - out).abs().max())
+            return compact(ln, keep=("value", "unit", "ms_per_step", "steps", "dtype", "path", "roofline", "kernel_ms_per_step",
+                                     "parity", "max_abs_diff_vs_headline_scores"))
+        extra["f32_exact"] = leg_guard("f32_exact", f32_leg)
+    del batch, out, model
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
 
-    with torch.no_grad():
-        run = lambda: model(batch)  # noqa: E731
-        if args.graph:
-            # small batches are a chain of ~25 short launches: the library allocates nothing and never synchronises,
-            # so the whole scoring call replays as one hipGraph (the weights' folded products are built before capture)
-            for _ in range(3):
-                model(batch)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                model(batch)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = model(batch)
+    if "train_step" in legs:
+        extra["train_step"] = leg_guard("train_step", lambda: bench_train(ctx, cfg, sd, 64, 20, 30))
 
-            def run():
-                graph.replay()
-                return static_out
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = run()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        assert torch.isfinite(out).all()
+    if "wikidiverse" in legs and world == 1:
+        def wd_leg():
+            wd = DrinConfig()
+            wsd = synth.make_state_dict(wd, 7)
+            m = make_model(wd, wsd, dev, "bf16x3")
+            Bw, st = 16384, min(args.steps, 20)
+            b32 = synth.make_device_batch(wd, Bw, 100, dev)[:14]
+            e, pr, o, pf = run_score(ctx, m, b32, st, 3)
+            l32 = score_line(ctx, wd, args, Bw, b32, e, pr, pf, st, 3, "bf16x3", "f32", "wikidiverse", False, True)
+            l32["parity"] = parity_of_timed_batch(wd, wsd, b32, o, n_slices=8, width=16)
+            b16 = [t.to(torch.bfloat16) if i in FEAT_SLOTS else t for i, t in enumerate(b32)]
+            e, pr, o, pf = run_score(ctx, m, b16, st, 3)
+            l16 = score_line(ctx, wd, args, Bw, b16, e, pr, pf, st, 3, "bf16x3", "bf16", "wikidiverse", False, True)
+            l16["parity"] = parity_of_timed_batch(wd, wsd, b16, o, n_slices=8, width=16, fp32_batch=b32)
+            return {"fp32_features": compact(l32), "bf16_features": compact(l16)}
+        extra["wikidiverse"] = leg_guard("wikidiverse", wd_leg)
 
-        # instrumented pass: per-kernel-class GPU time from HIP events on the launch stream
-        _lib.profile_begin(1 << 16)
-        for _ in range(args.steps):
-            model(batch)
-        prof = _lib.profile_end()
+    if "table_cache" in legs and world == 1:
+        def table_leg():
+            tc = DrinConfig(num_candidates_data=1000)
+            tsd = synth.make_state_dict(tc, 7)
+            m = make_model(tc, tsd, dev, "bf16x3")
+            table, g = build_table(tc, 1_000_000, dev)
+            table.enable_cache()
+            with torch.no_grad():
+                m(make_table_chunk(tc, table, 64, 99, dev, g))              # folds the weights, builds the 23.5 GB cache
+            chunk, mentions = 4096, 8 * 4096
+            el, n_chunks, o, last = stream_table(ctx, m, tc, table, g, mentions, chunk)
+            N = tc.num_candidates_model
+            # one resident chunk, instrumented: the dominant kernel's roofline
+            st = 5
+            e, pr, o2, pf = run_score(ctx, m, last, st, 1)
+            ln = score_line(ctx, tc, args, chunk, last, e, pr, pf, st, 1, "bf16x3", "f32", "table", True, True)
+            res = compact(ln)
+            res.update({"workload": f"BASELINE config 5 (SURVEY.md 8d): {N - 1} candidates (+1) per mention gathered on the device from a 1 000 000-entity table, "
+                                    f"per-entity cache, {mentions} mentions streamed in chunks of {chunk} (python bench.py --workload table --entity-cache "
+                                    f"--mentions 1000000 --chunk 4096 runs the full 1 M)",
+                        "value": mentions * N / el, "ms_per_step": el / n_chunks * 1e3, "steps": n_chunks,
+                        "resident_chunk_value": ln["value"],
+                        "parity": parity_of_timed_batch(tc, tsd, last, o2, n_slices=2, width=1)})
+            return res
+        extra["table_cache"] = leg_guard("table_cache", table_leg)
 
     if rank == 0:
-        D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
-        # dominant kernel of the instrumented pass.  stream / gemm_planes / gemm_x3 are single kernels
-        # (k_entity_stream, k_gemm_x3_planes, k_gemm_bf16x3); "gemm" is k_gemm_f32
-        dom = max(prof, key=lambda k: prof[k][0])
-        ms, launches = prof[dom]
-        per_launch_ms = ms / max(launches, 1)
-        fused = not args.generic and cfg.num_gcn_layers == 2
-        x3 = args.precision in ("bf16x3", "bf16")
-        flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
-        bytes_pair = algorithmic_bytes_per_pair(cfg, batch)
-        cached = args.workload == "table" and args.entity_cache
-        stream_bytes_pair = bytes_pair
-        if cached:
-            # k_cached_pairs: one gathered cache row in (h_t, h_i, c^, o^, sg and, with dynamic edges, fv_t, fv_i),
-            # the candidate index and two similarities; et' planes and the four layer-2 edges out
-            row = ((5 if cfg.gcn_edge_type == "dynamic" else 3) * D + R + 4) * 4
-            stream_bytes_pair = row + 8 + 8 + D * 4 + 16
-            flops_pair = 2.0 * D * D
-        kernel_names = {"stream": "k_cached_pairs" if cached else "k_entity_stream", "gemm_planes": "k_gemm_x3_planes", "gemm_x3": "k_gemm_bf16x3",
-                        "gemm": "k_gemm_f32"}
-        if dom == "stream":
-            # algorithmic = compulsory input bytes of the step; traffic = PMC-measured HBM bytes
-            work = stream_bytes_pair * pairs_per_step * args.steps / max(launches, 1)
-            achieved = work / (per_launch_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": (measured_traffic("k_cached_pairs", B, args.precision, fused, args.features, "kernels_table_cache")
-                                if cached else (measured_traffic("k_entity_stream", B, args.precision, fused, args.features)
-                                                if args.workload == "wikimel" else None)),
-                    "launches": int(launches), "avg_launch_ms": per_launch_ms}
-        else:
-            # algorithmic FLOPs the kernel's launches cover in one step / their summed time.  In split-bf16
-            # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
-            if dom == "gemm_planes":
-                step_flops = pairs_per_step * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
-                if not cached and (args.workload == "table" or args.features == "bf16"):
-                    step_flops += pairs_per_step * 2.0 * R * D   # x_i C_i^T runs on this kernel too (gathered / bf16 image planes)
-            elif dom == "gemm_x3" and fused:
-                # x_i C_i^T plus the mention-sized products, which run on the same kernel from 256 rows up
-                step_flops = pairs_per_step * 2.0 * R * D + (mention_flops(D, R, fused) * B if (x3 and B >= 256) else 0.0)
-            else:
-                step_flops = flops_pair * pairs_per_step + mention_flops(D, R, fused) * B
-            achieved = step_flops * args.steps / (ms * 1e-3) / 1e12
-            peak = PEAK_F32_MATRIX_TFLOPS if dom == "gemm" else PEAK_BF16_MFMA_TFLOPS
-            roof = {"bound": "mfma", "kernel": kernel_names.get(dom, dom), "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(launches),
-                    "avg_launch_ms": per_launch_ms}
-            if dom != "gemm":
-                passes = 1 if args.precision == "bf16" else 3
-                roof["executed_bf16_tflops"] = passes * achieved
-                roof["executed_frac"] = passes * achieved / peak
-        value = pairs_per_step * world * args.steps / elapsed
-        line = {
-            "metric": "mention x candidate pairs scored/sec",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{cfg.dataset_name}-shaped scoring forward: {N - 1}-cand (+1 answer slot), D={D}, R={R}, "
-                                   f"L={cfg.max_mention_sentence_len}, P={cfg.resnet_num_region}"
-                                   + (f", T={cfg.max_entity_attr_token_len} token-level entity text" if cfg.token_level_entities else ""),
-                       "mentions_per_step_per_gpu": B, "pairs_per_step": pairs_per_step * world,
-                       "parallelism": f"dp{world} (mentions sharded, no collective)"},
-            "roofline": roof,
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
-            "hbm_fraction_whole_path": bytes_pair * value / world / (PEAK_HBM_GBS * 1e9),
-            # matrix-core work the path executes (split-bf16: three bf16 MFMA passes per algorithmic product) and the
-            # reference-faithful operation count at the same rate, both against the dense bf16 peak
-            "mfma_fraction_whole_path": ((1 if args.precision == "bf16" else 3) if x3 else 1) * flops_pair * value / world
-                                        / ((PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12),
-            "mfma_fraction_reference_flops": (2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D) * value / world
-                                             / ((PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12),
-            "launch": "hipGraph replay" if args.graph else "eager",
-            "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + args.precision
-                    + (", features stored as bf16" if args.features == "bf16" else ""),
-            "algorithmic": {"bytes_per_pair": bytes_pair, "dominant_kernel_bytes_per_pair": stream_bytes_pair, "flops_per_pair_executed": flops_pair,
-                            "flops_per_pair_reference": 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D},
-        }
+        if extra:
+            line["legs"] = extra
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], line["parity"] = cpu_baseline(cfg, sd, model=model if args.workload != "table" else None, dev=dev,
-                                                                   features=args.features)
-            if line["parity"] is None:
-                del line["parity"]
-        print(json.dumps(line))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(line), flush=True)
+    ctx.finish()
 
 
 if __name__ == "__main__":

@@ -77,6 +77,47 @@ class DrinConfig:
             raise ValueError("gcn_edge_enabled has one entry per edge type (tt, ti, it, ii)")
 
 
+# names of common/args.py the scoring path and its caller read, -> DrinConfig fields of the same name
+_ARGS_FIELDS = ("dataset_name", "num_candidates_data", "bert_embed_dim", "resnet_embed_dim", "resnet_num_region",
+                "max_mention_sentence_len", "max_entity_attr_token_len", "gcn_embed_dim", "num_gcn_layers", "gcn_edge_type",
+                "gcn_edge_feature", "gcn_vertex_activation", "gcn_edge_activation", "seed", "num_epoch", "test_epoch_interval",
+                "learning_rate", "triplet_margin", "batch_size", "shuffle_train_data")
+
+
+def config_from_reference_args(args=None) -> DrinConfig:
+    """The `DrinConfig` a reference checkout's `common.args` module describes (`common/args.py:24-40,45,52-57,72,77,83-101,
+    109-126`): what the reference's no-argument `Model()` (`drin/model.py:157-162`, `train.py:136`) reads as star-imported
+    globals.  `args`: the module (default: `import common.args`).  `model_type` must be "drin" (`args.py:7`)."""
+    if args is None:
+        import importlib
+        args = importlib.import_module("common.args")
+    if getattr(args, "model_type", "drin") != "drin":
+        raise ValueError(f"common.args.model_type = {args.model_type!r}: this library is the 'drin' model only (train.py:9-14)")
+    kw = {k: getattr(args, k) for k in _ARGS_FIELDS if hasattr(args, k)}
+    if hasattr(args, "object_topk"):                                   # args.py:57
+        kw["object_topk_mention"], kw["object_topk_entity"] = args.object_topk["mention"], args.object_topk["entity"]
+    for k in ("gcn_edge_enabled", "metrics_topk", "acc_correction"):   # lists there, tuples here (frozen dataclass)
+        if hasattr(args, k):
+            kw[k] = tuple(getattr(args, k))
+    cfg = DrinConfig(**kw)
+    if hasattr(args, "num_candidates_model") and args.num_candidates_model != cfg.num_candidates_model:
+        raise ValueError("common.args.num_candidates_model != num_candidates_data + 1 (args.py:101)")
+    cfg.validate()
+    return cfg
+
+
+def default_config() -> DrinConfig:
+    """What `Model()` without arguments builds: the configuration of an importable reference `common.args` (the drop-in
+    case: this package sits in a checkout of the reference, `INTEGRATION.md`), else the reference's WikiDiverse defaults."""
+    import sys
+    if "common.args" in sys.modules:
+        return config_from_reference_args(sys.modules["common.args"])
+    try:
+        return config_from_reference_args()
+    except ImportError:
+        return DrinConfig()
+
+
 def wikidiverse_config(**kw) -> DrinConfig:
     """Reference defaults for WikiDiverse (args.py:92-100,119-126)."""
     return DrinConfig(**kw)

@@ -680,7 +680,7 @@ int drin_profile_end(double* ms_by_class, int64_t* launches_by_class) {
 }
 
 const char* drin_kernel_class_name(int kernel_class) {
-  static const char* names[DRIN_KC_COUNT] = {"gemm", "pool", "edge", "gcn", "stream", "gemm_x3", "gemm_planes"};
+  static const char* names[DRIN_KC_COUNT] = {"gemm", "pool", "edge", "gcn", "stream", "gemm_x3", "gemm_planes", "optim"};
   return (kernel_class >= 0 && kernel_class < DRIN_KC_COUNT) ? names[kernel_class] : "?";
 }
 

@@ -425,13 +425,9 @@ static int launch_cached_pairs_t(const CachedArgs& a, hipStream_t st) {
   const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;
   const size_t lds = sizeof(float) * (9 * D + R + 32 + 12 * D);
   auto kern = k_cached_pairs<DV, RV, EXACT>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cached_pairs)");
-    attr_done = true;
-  }
+  static DynLdsOptIn opt_in;  // one per template instantiation
+  if (lds > 48 * 1024)
+    DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(cached_pairs)"));
   KernelTimer timer(DRIN_KC_STREAM, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), lds, st, a);
   DRIN_CHECK_LAUNCH("k_cached_pairs");

@@ -261,13 +261,9 @@ template <int DV, int RV, bool TOKENS, bool EXACT, typename FT>
 static int launch_stream_ft(const StreamArgs& a, hipStream_t st) {
   const size_t lds = entity_stream_lds_bytes(a);
   auto kern = k_entity_stream<DV, RV, TOKENS, EXACT, FT>;
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(entity_stream)");
-    attr_done = true;
-  }
+  static DynLdsOptIn opt_in;  // one per template instantiation
+  if (lds > 48 * 1024)
+    DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(entity_stream)"));
   KernelTimer timer(DRIN_KC_STREAM, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), lds, st, a);
   DRIN_CHECK_LAUNCH("k_entity_stream");

@@ -326,13 +326,8 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
     return DRIN_E_SHAPE;
   }
   auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES, ONE_PASS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       G::LDS_BYTES);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16x3)");
-    attr_done = true;
-  }
+  static DynLdsOptIn opt_in;  // one per template instantiation
+  DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), G::LDS_BYTES, "hipFuncSetAttribute(gemm_bf16x3)"));
   // tail split (one workgroup per CU tiles only): the last round holds `frac` tiles; split K so that it fills the chip
   const unsigned tiles = (unsigned)(mt * nt);
   unsigned full = tiles;

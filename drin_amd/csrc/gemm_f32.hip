@@ -222,14 +222,9 @@ static int launch(const float* A, int64_t lda, const float* B, int64_t ldb, cons
   if (K <= 0) splits = 1;
   if (splits_used) *splits_used = splits;
   const size_t lds = sizeof(float) * 2 * (Tile<BM>::FLOATS + Tile<BN>::FLOATS);
-  static bool attr_done = false;  // one flag per template instantiation
+  static DynLdsOptIn opt_in;  // one per template instantiation; > 64 KiB of dynamic LDS needs the opt-in
   auto kern = k_gemm_f32<BM, BN, A_KMAJOR, B_KMAJOR>;
-  if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in; idempotent, so a race is harmless
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm)");
-    attr_done = true;
-  }
+  DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(gemm)"));
   dim3 grid((unsigned)cdiv(N, BN), (unsigned)mt, (unsigned)splits);
   KernelTimer timer(DRIN_KC_GEMM, st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kps, flags, part_stride);

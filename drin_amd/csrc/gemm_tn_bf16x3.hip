@@ -259,15 +259,12 @@ int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t l
     set_error("gemm_tn_bf16x3: %lld reduction slices exceed the grid limit", (long long)slices);
     return DRIN_E_SHAPE;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3tn::LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, x3tn::LDS_BYTES);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_tn_bf16x3)");
-    attr_done = true;
+  {
+    static DynLdsOptIn opt_in[2];
+    DRIN_TRY(ensure_dynamic_lds(opt_in[0], reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<false>), x3tn::LDS_BYTES,
+                                "hipFuncSetAttribute(gemm_tn_bf16x3)"));
+    DRIN_TRY(ensure_dynamic_lds(opt_in[1], reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<true>), x3tn::LDS_BYTES,
+                                "hipFuncSetAttribute(gemm_tn_bf16x3)"));
   }
   const bool two_stage = scratch != nullptr && slices > 1 && (size_t)slices * N * K <= scratch_floats && (ldy % 4) == 0 &&
                          aligned16(y) && aligned16(scratch);

@@ -341,16 +341,13 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
     set_error("gemm_x3_planes: %lld row tiles exceed the grid limit; split the batch", (long long)mt);
     return DRIN_E_SHAPE;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipSuccess;
+  {
+    static DynLdsOptIn opt_in[3];
     const void* kernels[3] = {reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<true, true>),
                               reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, true>),
                               reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, false>)};
-    for (const void* k : kernels)
-      if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, x3p::LDS_BYTES);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_x3_planes)");
-    attr_done = true;
+    for (int i = 0; i < 3; ++i)
+      DRIN_TRY(ensure_dynamic_lds(opt_in[i], kernels[i], x3p::LDS_BYTES, "hipFuncSetAttribute(gemm_x3_planes)"));
   }
   // A handful of mentions is a handful of tiles walking K serially (101 rows x 768 x 768: 3 workgroups, 50 us): split K
   // over workgroups into scratch and add the slices in order (deterministic), as the mention-sized fp32 products do.

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/drin_hip.h"
 
 namespace drin {
@@ -31,6 +33,23 @@ struct KernelTimer {
   int slot;
   hipStream_t stream;
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: one high-water mark per (call site,
+// device), so a process that runs on cuda:0 and later on cuda:1 opts in on both, and a later call that needs more LDS
+// than the first one raises it.  Atomics: the caller's thread and autograd's may race here harmlessly (idempotent call).
+struct DynLdsOptIn {
+  std::atomic<int> bytes[64] = {};
+};
+inline int ensure_dynamic_lds(DynLdsOptIn& s, const void* kernel, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::atomic<int>& mark = s.bytes[dev & 63];
+  if (mark.load(std::memory_order_relaxed) >= bytes) return DRIN_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return hip_fail(e, what);
+  mark.store(bytes, std::memory_order_relaxed);
+  return DRIN_OK;
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -102,9 +102,12 @@ def create_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int] = None
                     entity_mmap: Optional[str] = None) -> List[DataLoader]:
     """`create_datasets()` of `drin/data.py:158-200`: [train, valid, test] loaders.
 
-    With `world_size > 1` every rank iterates its own contiguous shard of each split (mentions are
-    independent); shuffling of the train split uses the same seeded permutation on all
-    ranks so the shards stay disjoint.
+    With `world_size > 1` every rank iterates its own strided shard `perm[rank::world]` of each split (mentions
+    are independent); shuffling of the train split uses the same seeded permutation on all ranks so
+    the shards stay disjoint.  The TRAIN shards are padded with wrapped-around mentions to one common length
+    (like `DistributedSampler`): every rank then runs the same number of steps with the same batch sizes, which the
+    per-step gradient all-reduce (and the gathered global-batch loss) need.  Evaluation shards are not padded - every
+    mention counts exactly once in the metrics - and evaluation makes no per-step collective.
     """
     N = cfg.num_candidates_model
     onehot = np.concatenate([np.eye(N - 1, dtype=np.uint8), np.zeros((1, N - 1), dtype=np.uint8)], 0)   # data.py:159-161
@@ -126,7 +129,7 @@ def create_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int] = None
     for s in SPLITS:
         ds = MELData(cfg, root, s, shared, mention_mmap)
         shuffle = s == "train" and cfg.shuffle_train_data                                           # data.py:155
-        sampler = ShardSampler(len(ds), rank, world_size, shuffle, cfg.seed) if (world_size > 1 or shuffle) else None
+        sampler = ShardSampler(len(ds), rank, world_size, shuffle, cfg.seed, pad=s == "train") if (world_size > 1 or shuffle) else None
         loaders.append(DataLoader(ds, batch_size or cfg.batch_size, shuffle=False, sampler=sampler, num_workers=num_workers))
     return loaders
 
@@ -175,7 +178,7 @@ def create_indexed_datasets(cfg: DrinConfig, root: str, batch_size: Optional[int
     for s in SPLITS:
         ds = IndexedMELData(cfg, root, s, shared, mention_mmap)
         shuffle = s == "train" and cfg.shuffle_train_data
-        sampler = ShardSampler(len(ds), rank, world_size, shuffle, cfg.seed) if (world_size > 1 or shuffle) else None
+        sampler = ShardSampler(len(ds), rank, world_size, shuffle, cfg.seed, pad=s == "train") if (world_size > 1 or shuffle) else None
         loaders.append(DataLoader(ds, batch_size or cfg.batch_size, shuffle=False, sampler=sampler, num_workers=num_workers))
     return loaders
 
@@ -239,10 +242,13 @@ def create_device_splits(cfg: DrinConfig, root: str, device, batch_size: Optiona
 
 
 class ShardSampler(torch.utils.data.Sampler):
-    """Rank r of w draws indices perm[r::w] of one permutation shared by all ranks (re-seeded per epoch)."""
+    """Rank r of w draws indices `order[r::w]` of one permutation shared by all ranks (re-seeded per epoch).
+    `pad`: `order` is first extended with its own head to a multiple of w (as `DistributedSampler` does), so that all
+    ranks draw the same number of indices - required wherever ranks meet in a collective every step."""
 
-    def __init__(self, n: int, rank: int, world: int, shuffle: bool, seed: int):
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool, seed: int, pad: bool = False):
         self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+        self.pad = pad and world > 1
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -250,13 +256,20 @@ class ShardSampler(torch.utils.data.Sampler):
     def _order(self):
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
-            return torch.randperm(self.n, generator=g).tolist()
-        return list(range(self.n))
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        if self.pad and self.n % self.world:
+            extra = self.world - self.n % self.world
+            order += (order * (extra // max(self.n, 1) + 1))[:extra]
+        return order
 
     def __iter__(self):
         return iter(self._order()[self.rank::self.world])
 
     def __len__(self) -> int:
+        if self.pad:
+            return (self.n + self.world - 1) // self.world if self.n else 0
         return len(range(self.rank, self.n, self.world))
 
 

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .config import DrinConfig
+from .config import DrinConfig, default_config
 
 
 # ---- parameter containers mirroring the reference's module tree (keys of SURVEY.md §8b) -------------
@@ -140,8 +140,19 @@ class EntityTable:
             self._cache, self._cache_key = None, None
         return self
 
+    def invalidate(self) -> "EntityTable":
+        """Drop the per-entity cache and the pooled-text copy.  Needed only after the tables were edited through a path
+        PyTorch's version counters do not see (`t.data.copy_(...)`, an external kernel writing the storage): in-place torch
+        ops on the tensors and replaced tensors are detected by themselves."""
+        self._cache, self._cache_key, self._pooled = None, None, None
+        return self
+
+    def _table_key(self):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.text, self.mask, self.image, self.object, self.object_score)
+                     if t is not None)
+
     def _get_cache(self, call: "_Call", key, pc, prepared: torch.Tensor) -> torch.Tensor:
-        key = (key, call.cfg.precision, call.cfg.num_entities, self.text.data_ptr())
+        key = (key, call.cfg.precision, call.cfg.num_entities, self._table_key())
         if key != self._cache_key or self._cache is None:
             lib = _lib.load()
             n = lib.drin_entity_cache_bytes(C.byref(call.cfg))
@@ -169,9 +180,10 @@ class EntityTable:
         values) instead of gathering and pooling 197 KB of tokens per candidate per step."""
         if self.text.dim() != 3:
             raise ValueError("pooled_text: the table already holds pooled text [E, D]")
-        if self._pooled is None or self._pooled[0].data_ptr() != self.text.data_ptr():
+        key = (self.text.data_ptr(), self.text._version, self.mask.data_ptr(), self.mask._version)
+        if self._pooled is None or self._pooled[0] != key:
             text = self.text.contiguous()
-            self._pooled = (self.text, _pool_tokens(text, self.mask), text[:, 0, :].contiguous())   # [E, D] each
+            self._pooled = (key, _pool_tokens(text, self.mask), text[:, 0, :].contiguous())   # [E, D] each
         return self._pooled[1], self._pooled[2]
 
     def to(self, device) -> "EntityTable":
@@ -210,6 +222,21 @@ class IndexedBatch:
         seq = self.mention + [pooled[idx], dummy, t.image[idx], t.object[idx], t.object_score[idx],
                               self.miet_similarity, self.mtei_similarity]
         return seq, cls[idx]
+
+
+def _split_mentions(batch, step: int):
+    """Slices of at most `step` mentions of a 14-sequence or an `IndexedBatch` (views, nothing is copied)."""
+    if isinstance(batch, IndexedBatch):
+        B = batch.candidates.shape[0]
+        for b0 in range(0, B, step):
+            sl = slice(b0, min(B, b0 + step))
+            yield IndexedBatch([t[sl] for t in batch.mention], batch.table, batch.candidates[sl],
+                               batch.miet_similarity[sl], batch.mtei_similarity[sl])
+    else:
+        B = batch[0].shape[0]
+        for b0 in range(0, B, step):
+            sl = slice(b0, min(B, b0 + step))
+            yield [t[sl] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == B else t for t in batch]
 
 
 class _Call:
@@ -351,6 +378,9 @@ class _Prepared:
         self.key = None
         self.buf: Optional[torch.Tensor] = None
 
+    def invalidate(self) -> None:
+        self.key = None
+
     def get(self, call: "_Call", params: Sequence[torch.Tensor], pc) -> torch.Tensor:
         key = (call.cfg.embed_dim, call.cfg.image_dim, call.cfg.dynamic_edges) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self.key or self.buf is None or self.buf.device != call.device:
@@ -361,6 +391,29 @@ class _Prepared:
             _lib.check(lib.drin_prepare(C.byref(call.cfg), C.byref(pc), self.buf.data_ptr(), n, stream))
             self.key = key
         return self.buf
+
+
+def _dead_param_indices(n_params: int, per_layer: int, dynamic: bool) -> List[int]:
+    """Positions in `_param_list` order of the parameters the score does not depend on (`.grad is None` in the reference)."""
+    nl = (n_params - 8) // per_layer
+    dead_layers = range(nl - 1, nl) if dynamic else range(nl)
+    return [8 + per_layer * l + j for l in dead_layers for j in (2, 3, 4, 5) + ((8, 9) if per_layer == 10 else ())]
+
+
+def _bucket_layout(params: Sequence[torch.Tensor], per_layer: int, dynamic: bool):
+    """`(offsets, live_floats, total_floats)`: where each parameter of `_param_list` order sits in a flat fp32 bucket - the
+    parameters that receive a gradient first (the all-reduced / Adam-stepped prefix), the dead ones behind them; every
+    slot starts on a 256-byte boundary."""
+    dead = set(_dead_param_indices(len(params), per_layer, dynamic))
+    offsets, off = [0] * len(params), 0
+    for want_dead in (False, True):
+        for i, p in enumerate(params):
+            if (i in dead) == want_dead:
+                offsets[i] = off
+                off += (p.numel() + 63) & ~63
+        if not want_dead:
+            live = off
+    return offsets, live, off
 
 
 class _DrinScore(torch.autograd.Function):
@@ -395,44 +448,142 @@ class _DrinScore(torch.autograd.Function):
     def backward(ctx, grad_scores: torch.Tensor):
         lib = _lib.load()
         call, params = ctx.call, ctx.params
-        grads = [torch.empty_like(p) for p in params]
-        torch._foreach_zero_(grads)                                   # one multi-tensor launch instead of 24 fills
+        owner = getattr(call, "owner", None)
+        if owner is not None and owner.grad_bucket_enabled:
+            # every gradient is a view of ONE flat fp32 bucket, zeroed with one memset: autograd's AccumulateGrad adopts the
+            # views as .grad, so the data-parallel all-reduce and the one-launch Adam run on the bucket itself, copy-free
+            grads = owner._bucket_grads(params)
+        else:
+            grads = [torch.empty_like(p) for p in params]
+            torch._foreach_zero_(grads)                               # one multi-tensor launch instead of 24 fills
         gc = _lib.DrinParamGradsC()
         _fill_params(gc, grads, call.per_layer)
         g = grad_scores.to(torch.float32).contiguous()
         stream = torch.cuda.current_stream(call.device).cuda_stream
         _lib.check(lib.drin_backward(C.byref(call.cfg), C.byref(call.batch), C.byref(ctx.pc), ctx.ws.data_ptr(),
                                      ctx.ws.numel(), g.data_ptr(), C.byref(gc), stream))
-        pl = call.per_layer
-        nl = (len(params) - 8) // pl
         out = list(grads)
         # parameters the score does not depend on get no gradient at all in the reference (.grad is None):
         # the last layer's edge update is dead (model.py:130-134), and static edges never use w_u / w_v (/ w_m)
-        dead_layers = range(nl) if not call.cfg.dynamic_edges else range(nl - 1, nl)
-        for l in dead_layers:
-            for j in (2, 3, 4, 5) + ((8, 9) if pl == 10 else ()):
-                out[8 + pl * l + j] = None
+        for i in _dead_param_indices(len(params), call.per_layer, bool(call.cfg.dynamic_edges)):
+            out[i] = None
         return (None, None, None, *out)
+
+
+def _invalidate_after_load(module, _incompatible_keys) -> None:
+    module.invalidate()
 
 
 class Model(nn.Module):
     """`model_module.Model()` of `train.py:136` (drin/model.py:156-162)."""
 
-    def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "f32", fused: bool = True):
-        """`precision`: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16 MFMA, fp32-equivalent) or "bf16" (opt-in: the
+    # mentions per library call: larger batches are scored in slices of this many (mentions are independent, so the
+    # scores are bit-identical); the one-workgroup-per-(mention, chunk) grids of the row kernels stop at 65 535 mentions
+    MAX_CALL_MENTIONS = 32768
+
+    def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "bf16x3", fused: bool = True,
+                 grad_bucket: bool = True):
+        """`cfg`: None reads an importable reference `common.args` (the no-argument `Model()` of `train.py:136`), else the
+        WikiDiverse defaults (`config.default_config`).
+        `precision`: "bf16x3" (default: split-bf16 MFMA, fp32-equivalent - measured <= 1.4e-6 on the scores against the
+        reference's fp32 forward, bar 1e-4; 2x the rate of exact fp32), "f32" (exact fp32 MFMA) or "bf16" (opt-in: the
         pair-sized contractions of the fused inference path in ONE bf16 MFMA pass - score error ~6e-4, outside the
         1e-4 bar; training and every other path then run "bf16x3");
-        `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path."""
+        `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;
+        `grad_bucket`: backward writes every gradient into one flat bucket the `.grad`s are views of (like DDP's
+        `gradient_as_bucket_view`: a `.grad` kept across `zero_grad(set_to_none=True)` + `backward()` is overwritten)."""
         super().__init__()
-        self.cfg = cfg or DrinConfig()
+        self.cfg = cfg or default_config()
         self.cfg.validate()
         self._prepared = _Prepared() if fused else None
+        self.grad_bucket_enabled = grad_bucket
+        self._grad_flat: Optional[torch.Tensor] = None
+        self._param_flat: Optional[torch.Tensor] = None
+        self._layout = None
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL,
                           "bf16": _lib.PREC_BF16}[precision]
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 
+    def invalidate(self) -> "Model":
+        """Forget the folded weights of the fused inference path (and with them every `EntityTable` cache keyed on them).
+        The folds are keyed on `(data_ptr, _version)` of the parameters, so optimiser steps, `load_state_dict` and in-place
+        torch ops are detected by themselves; writes PyTorch's version counter does not see - `p.data.copy_(...)`,
+        `p.data.mul_(...)`, EMA / weight swapping through `.data`, an external kernel - need this call."""
+        if self._prepared is not None:
+            self._prepared.invalidate()
+        return self
+
+    # ---- flat buckets (SURVEY.md 8e: one all-reduce per step; train.py:55-56: one Adam launch) -------------------------
+    def bucket_layout(self):
+        params = _param_list(self)
+        key = tuple(p.numel() for p in params)
+        if self._layout is None or self._layout[0] != key:
+            pl = 10 if self.cfg.gcn_edge_feature == "vector" else 8
+            self._layout = (key,) + _bucket_layout(params, pl, self.cfg.gcn_edge_type == "dynamic")
+        return self._layout[1:]
+
+    def _bucket_grads(self, params: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+        """Views of the flat gradient bucket for `params` (`_param_list` order; the dead ones get their own slots behind
+        the live prefix and are never returned to autograd), zeroed with one memset.  A bucket some `.grad` still aliases
+        (gradient accumulation over several backward passes) is left alone and a fresh one is taken."""
+        offsets, live, total = self.bucket_layout()
+        dev = params[0].device
+        flat = self._grad_flat
+        if flat is not None and (flat.device != dev or flat.numel() != total):
+            flat = None
+        if flat is not None:
+            base = flat.untyped_storage().data_ptr()
+            if any(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.parameters()):
+                flat = None
+        if flat is None:
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self._grad_flat = flat
+        flat[:live].zero_()
+        return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offsets, params)]
+
+    def grad_bucket(self) -> Optional[torch.Tensor]:
+        """The live prefix of the flat gradient bucket when every current `.grad` is a view of it, else None."""
+        flat = self._grad_flat
+        if flat is None:
+            return None
+        offsets, live, _total = self.bucket_layout()
+        base, seen = flat.data_ptr(), False
+        for o, p in zip(offsets, _param_list(self)):
+            if p.grad is None:
+                continue
+            if p.grad.data_ptr() != base + 4 * o or not p.grad.is_contiguous():
+                return None
+            seen = True
+        return flat[:live] if seen else None
+
+    def flatten_parameters(self) -> torch.Tensor:
+        """Move every parameter into one flat fp32 bucket laid out like the gradient bucket (`p.data` become views; values,
+        `state_dict` keys and `load_state_dict` are unaffected).  Returns the bucket; idempotent; redo after `.to(...)`."""
+        params = _param_list(self)
+        offsets, _live, total = self.bucket_layout()
+        flat = self._param_flat
+        ok = (flat is not None and flat.device == params[0].device and flat.numel() == total
+              and all(p.data_ptr() == flat.data_ptr() + 4 * o and p.is_contiguous() for o, p in zip(offsets, params)))
+        if not ok:
+            flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            with torch.no_grad():
+                for o, p in zip(offsets, params):
+                    view = flat[o:o + p.numel()].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view
+            self._param_flat = flat
+            self.invalidate()
+        return flat
+
     def forward(self, batch) -> torch.Tensor:
+        B = batch.candidates.shape[0] if isinstance(batch, IndexedBatch) else batch[0].shape[0]
+        if B > self.MAX_CALL_MENTIONS:
+            return torch.cat([self._forward(part) for part in _split_mentions(batch, self.MAX_CALL_MENTIONS)], 0)
+        return self._forward(batch)
+
+    def _forward(self, batch) -> torch.Tensor:
         params = _param_list(self)
         cls = None
         if isinstance(batch, IndexedBatch):
@@ -453,7 +604,7 @@ class Model(nn.Module):
                     if t.cache_enabled:                                # per-entity precompute cache
                         return self._forward_cached(call, t, params)
                     if planes:
-                        return _DrinScore.apply(call, self._prepared, False, *params)
+                        return self._apply(call, self._prepared, False, *params)
             if not inference and t.text.dim() == 3:
                 # training on a token-level table: every entity's tokens pooled once; the step then reads the pooled /
                 # token-0 / image / object tables through the candidate index inside the kernels, or gathers those rows
@@ -461,7 +612,7 @@ class Model(nn.Module):
                 if call is not None:
                     if call.B == 0:
                         return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-                    return _DrinScore.apply(call, None, True, *params)
+                    return self._apply(call, None, True, *params)
                 batch, cls = batch.gathered_pooled(self.cfg)
             else:
                 batch = batch.gathered()
@@ -487,14 +638,18 @@ class Model(nn.Module):
             call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec, entity_text_cls=cls)
             if call.B == 0:
                 return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-            return _DrinScore.apply(call, None, training, *params)
+            return self._apply(call, None, training, *params)
         call = _Call(self.cfg, batch, prec, keep_bf16=in_place)
         if ((call.cfg.feature_dtype != _lib.FEAT_F32 or prec == _lib.PREC_BF16)
                 and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK):
             call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec)
         if call.B == 0:
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-        return _DrinScore.apply(call, self._prepared, training, *params)
+        return self._apply(call, self._prepared, training, *params)
+
+    def _apply(self, call: _Call, prepared, training: bool, *params):
+        call.owner = self
+        return _DrinScore.apply(call, prepared, training, *params)
 
     def _indexed_training_call(self, batch: "IndexedBatch", planes: bool) -> Optional[_Call]:
         """The table form of `drin_forward` / `drin_backward` (`drin_batch.entity_index` over tables pooled ahead of time),

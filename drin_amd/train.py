@@ -37,31 +37,152 @@ def _rank() -> int:
 
 
 class GradBucket:
-    """One flat fp32 buffer for the gradients of all parameters that receive one (26.8 MB
-    of the 31.5 MB carry gradients), all-reduced with a single collective per step."""
+    """The gradients of all parameters that receive one (26.8 MB of the 31.5 MB carry gradients),
+    all-reduced with a single collective per step.
+
+    `drin_amd.model.Model` writes its gradients into ONE flat bucket the `.grad`s are views of: the collective then runs
+    on that bucket in place - no gather copy before, no scatter copy after.  Any other set of gradients (a foreign
+    module, `grad_bucket=False`, gradients accumulated over several backward passes) is packed into a staging bucket."""
 
     def __init__(self, params: Sequence[nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
-        self.flat: Optional[torch.Tensor] = None
+        self.flat: Optional[torch.Tensor] = None          # staging bucket of the copy path
+        self._view = None                                 # (storage ptr, lo, hi, flat view) of the in-place path
+        self.in_place = False                             # what the last call did
+
+    def nbytes(self) -> int:
+        live = [p for p in self.params if p.grad is not None]
+        return 4 * sum(p.numel() for p in live) if live else 4 * sum(p.numel() for p in self.params)
+
+    def _aliased_bucket(self, live) -> Optional[torch.Tensor]:
+        """One flat tensor over the storage range the gradients occupy when they all live in a single fp32 storage
+        (gaps - 256-byte slot padding - are all-reduced along: they hold zeros)."""
+        st = live[0].grad.untyped_storage()
+        base = st.data_ptr()
+        lo, hi, elems = None, None, 0
+        for p in live:
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base:
+                return None
+            o = g.storage_offset()
+            lo = o if lo is None else min(lo, o)
+            hi = o + g.numel() if hi is None else max(hi, o + g.numel())
+            elems += g.numel()
+        if hi - lo > elems + 64 * len(live):               # not a bucket: unrelated views of one big storage
+            return None
+        if self._view is None or self._view[:3] != (base, lo, hi):
+            flat = torch.empty(0, dtype=torch.float32, device=live[0].grad.device).set_(st, lo, (hi - lo,))
+            self._view = (base, lo, hi, flat)
+        return self._view[3]
 
     def allreduce_mean(self) -> None:
         world = _world()
         if world == 1:
             return
         live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        avg = dist.get_backend() == "nccl"                 # RCCL averages inside the collective; gloo has no AVG
+        flat = self._aliased_bucket(live)
+        self.in_place = flat is not None
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+            if not avg:
+                flat.div_(world)
+            return
         n = sum(p.numel() for p in live)
-        if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].device:
-            self.flat = torch.empty(n, dtype=torch.float32, device=live[0].device)
-        off = 0
-        for p in live:
-            self.flat[off: off + p.numel()].copy_(p.grad.reshape(-1))
-            off += p.numel()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(world)
-        off = 0
-        for p in live:
-            p.grad.copy_(self.flat[off: off + p.numel()].view_as(p.grad))
-            off += p.numel()
+        if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].grad.device:
+            self.flat = torch.empty(n, dtype=torch.float32, device=live[0].grad.device)
+        torch._foreach_copy_(list(self.flat.split([p.numel() for p in live])), [p.grad.reshape(-1) for p in live])
+        dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+        if not avg:
+            self.flat.div_(world)
+        torch._foreach_copy_([p.grad.reshape(-1) for p in live], list(self.flat.split([p.numel() for p in live])))
+
+
+class LibraryAdam:
+    """`torch.optim.Adam(model.parameters(), lr)` of `train.py:55-56` (torch defaults) for a `drin_amd.model.Model`, as ONE
+    launch of `drin_adam_step` over the model's flat parameter / gradient / moment buckets instead of torch's nine
+    multi-tensor launches.  Same op sequence and per-op fp32 rounding as torch's default implementation, so a loop stepped
+    with it follows the reference's loop bit for bit (`tests/test_gpu_parity.py::test_library_adam_matches_torch_adam_bitwise`).
+    Like torch's Adam it skips parameters whose `.grad` is None and creates its zero moments at the first step."""
+
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, arith: Optional[int] = None):
+        from . import _lib
+        self.model, self.lr, self.betas, self.eps = model, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.arith = _lib.ADAM_ARITH_DEFAULT if arith is None else arith
+        self.t = 0
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        self.one_launch_steps = 0
+        self.param_groups = [{"params": list(model.parameters()), "lr": self.lr}]   # what callers of torch optimisers inspect
+
+    def describe(self) -> str:
+        return "library Adam: one drin_adam_step launch over the flat parameter bucket (torch.optim.Adam arithmetic)"
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.model.parameters():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self) -> None:
+        import ctypes as C
+
+        from . import _lib
+        from .model import _param_list
+        lib = _lib.load()
+        model = self.model
+        flat_p = model.flatten_parameters()
+        offsets, live, total = model.bucket_layout()
+        if self.exp_avg is None or self.exp_avg.numel() != total or self.exp_avg.device != flat_p.device:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+        self.t += 1
+        b1, b2 = self.betas
+        step = float(self.t)
+        bias_correction1 = 1 - b1 ** step                    # torch/optim/adam.py (_multi_tensor_adam), python doubles
+        bias_correction2 = 1 - b2 ** step
+        neg_step_size = (self.lr / bias_correction1) * -1
+        bias_correction2_sqrt = bias_correction2 ** 0.5
+        scal = (1 - b1, b2, 1 - b2, bias_correction2_sqrt, self.eps, neg_step_size)
+        stream = torch.cuda.current_stream(flat_p.device).cuda_stream
+
+        def launch(p_ptr, g_ptr, off, n):
+            _lib.check(lib.drin_adam_step(p_ptr, g_ptr, self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off,
+                                          n, *(C.c_float(x) for x in scal), self.arith, stream))
+
+        params = _param_list(model)
+        with_grad = [i for i, p in enumerate(params) if p.grad is not None]
+        gflat = model.grad_bucket()
+        live_set = [i for i, o in enumerate(offsets) if o < live]
+        if gflat is not None and with_grad == live_set:
+            launch(flat_p.data_ptr(), gflat.data_ptr(), 0, live)          # the whole live prefix, slot padding included (zeros)
+            self.one_launch_steps += 1
+            return
+        for i in with_grad:                                               # irregular step: one launch per tensor
+            p, g = params[i], params[i].grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.to(torch.float32).contiguous()
+            launch(p.data_ptr(), g.data_ptr(), offsets[i], p.numel())
+
+
+def make_adam(model, lr: float, library: Optional[bool] = None, capturable: bool = False, fused: bool = False):
+    """The optimiser of `train.py:55-56`.  `library` (default: when `model` is a `drin_amd.model.Model` on a GPU): the
+    one-launch `LibraryAdam`; else `torch.optim.Adam` with its defaults (`fused=True` opts into torch's single-kernel
+    variant, whose rounding differs)."""
+    from .model import Model
+    p0 = next(model.parameters())
+    can = isinstance(model, Model) and p0.is_cuda and not capturable and not fused
+    if library is None:
+        library = can
+    if library and not can:
+        raise ValueError("LibraryAdam steps a drin_amd.model.Model on a GPU (no capturable / fused variants)")
+    if library:
+        return LibraryAdam(model, lr)
+    return torch.optim.Adam(model.parameters(), lr=lr, capturable=capturable, **({"fused": True} if fused else {}))
 
 
 class _GatherScores(torch.autograd.Function):
@@ -101,14 +222,21 @@ class MELRunner:
 
     def __init__(self, cfg: DrinConfig, model: nn.Module, device, global_batch_loss: bool = False,
                  log: Optional[Callable[[str], None]] = None, entity_table=None, device_loss: Optional[bool] = None,
-                 fused_adam: bool = False):
+                 fused_adam: bool = False, library_adam: Optional[bool] = None, output_test_result: Optional[str] = None):
         """`entity_table`: a device-resident `drin_amd.model.EntityTable`; the loaders then yield the 11-item
         table-form batches of `drin_amd.data.IndexedMELData` (candidate indices instead of gathered features).
         `device_loss`: loss + top-k counters through the library's `drin_triplet_topk` (default on a GPU; the
-        gathered global-batch loss keeps the torch classes)."""
+        gathered global-batch loss keeps the torch classes).
+        `library_adam`: the one-launch `LibraryAdam` (default for a `drin_amd.model.Model` on a GPU), else `torch.optim.Adam`.
+        `output_test_result`: a path - the per-sample dump of `train.py:16-17,40-43` (`args.output_test_result`): every
+        test-split sample's score row and answer row, `"{index}:\t{scores}\n{answer}\n"` (rank r > 0 of a data-parallel
+        run appends `.rank{r}` to the name and numbers its own shard's samples)."""
         self.cfg, self.model, self.device = cfg, model, torch.device(device)
         self.entity_table = entity_table
-        self.fused_adam = fused_adam
+        self.fused_adam, self.library_adam = fused_adam, library_adam
+        self.result_file = None
+        if output_test_result:
+            self.result_file = open(output_test_result + (f".rank{_rank()}" if _rank() > 0 else ""), "w")
         self.loss = TripletLoss(cfg.triplet_margin)
         self.metrics = [TopkAccuracy(k, self.device) for k in cfg.metrics_topk]
         if device_loss and global_batch_loss:
@@ -123,7 +251,7 @@ class MELRunner:
     def _to_device(self, batch):
         return [t.to(self.device, non_blocking=True) for t in batch]
 
-    def forward_step(self, batch, split: int):
+    def forward_step(self, batch, split: int, batch_idx: int = 0):
         """`_forward_step` (`train.py:30-44`)."""
         batch = self._to_device(batch)
         y = batch[-1]
@@ -132,7 +260,13 @@ class MELRunner:
             y_hat = self.model(IndexedBatch(batch[:7], self.entity_table, batch[7], batch[8], batch[9]))
         else:
             y_hat = self.model(batch[:-1])
-        if self.global_batch_loss and _world() > 1:
+        if self.result_file is not None and split == 2:                # train.py:40-43
+            for i, sample in enumerate(y_hat.detach().to("cpu").tolist()):
+                self.result_file.write(f"{i + batch_idx * self.cfg.batch_size}:\t{sample}\n{y[i]}\n")
+            self.result_file.flush()
+        # (evaluation shards may differ in length by one mention across ranks - no padding, so that the metrics count every
+        #  mention exactly once - hence no per-step collective there: the gathered loss is a training-step construct)
+        if self.global_batch_loss and _world() > 1 and self.model.training:
             world = _world()
             ys = [torch.empty_like(y) for _ in range(world)]
             dist.all_gather(ys, y.contiguous())
@@ -159,16 +293,16 @@ class MELRunner:
         training = optimizer is not None
         self.model.train(training)
         total, steps = torch.zeros((), dtype=torch.float64, device=self.device), 0   # summed on the device: no per-step read-back
-        for batch in loader:
+        for batch_idx, batch in enumerate(loader):
             if training:
                 optimizer.zero_grad(set_to_none=True)
-                loss = self.forward_step(batch, split)
+                loss = self.forward_step(batch, split, batch_idx)
                 loss.backward()
                 self.bucket.allreduce_mean()
                 optimizer.step()
             else:
                 with torch.no_grad():
-                    loss = self.forward_step(batch, split)
+                    loss = self.forward_step(batch, split, batch_idx)
             total += loss.detach()
             steps += 1
         for m in meters:
@@ -192,7 +326,9 @@ class MELRunner:
             # configure_optimizers (train.py:55-56), per Trainer.  `fused_adam` (opt-in): torch's single-kernel implementation
             # of the same update - 0.27 ms less per step, but its rounding differs from the default's, and Adam's division
             # by sqrt(v) amplifies that: after two epochs the loss is 1.4e-3 off the reference loop instead of 1e-4
-            optimizer = torch.optim.Adam(self.model.parameters(), lr=cfg.learning_rate, **({"fused": True} if self.fused_adam else {}))
+            # LibraryAdam (default for the HIP Model on a GPU): the same update as torch's default, bit for bit, in one launch
+            optimizer = make_adam(self.model, cfg.learning_rate, library=False if self.fused_adam else self.library_adam,
+                                  fused=self.fused_adam)
             for _ in range(interval):
                 sampler = getattr(loaders[0], "sampler", None)
                 if hasattr(sampler, "set_epoch"):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRIN_ABI_VERSION 1
+#define DRIN_ABI_VERSION 2
 #define DRIN_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -285,6 +285,23 @@ DRIN_API int drin_triplet_topk(const float* scores, const uint8_t* answer, int32
                                float margin, const int32_t* topk, int32_t num_topk, float* loss, float* d_scores,
                                int64_t* correct, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- caller-side optimiser step of the training configs ------------------------------------------ *
+ * `torch.optim.Adam(self.parameters(), lr)` of train.py:55-56 (torch defaults: betas (0.9, 0.999), eps 1e-8, no weight
+ * decay, no amsgrad), one step over `n` contiguous fp32 elements in ONE launch - a flat bucket holding every parameter
+ * that receives a gradient, its gradient bucket (what drin_backward wrote / RCCL all-reduced) and the two moment buckets.
+ * The op sequence and the per-op fp32 rounding are those of torch's default multi-tensor implementation, so a training
+ * loop stepped with it tracks the reference's loop bit for bit (csrc/optim_kernels.hip).  Scalars, formed on the HOST in
+ * double precision as torch/optim/adam.py forms them for step t (1-based) and rounded to fp32 here:
+ *   lerp_weight = 1 - beta1;  one_minus_beta2 = 1 - beta2;  bias_correction2_sqrt = (1 - beta2^t)^0.5;
+ *   neg_step_size = -(lr / (1 - beta1^t)).
+ * `arith`: DRIN_ADAM_ARITH_DEFAULT, or a 3-bit mask choosing fma (bit set) or product-then-sum for the lerp (1), the
+ * addcmul (2) and the addcdiv (4) - only the parity test passes anything but the default. */
+#define DRIN_ADAM_ARITH_DEFAULT (-1)
+#define DRIN_ADAM_ARITH_TORCH 7
+DRIN_API int drin_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                            float lerp_weight, float beta2, float one_minus_beta2, float bias_correction2_sqrt, float eps,
+                            float neg_step_size, int32_t arith, void* stream);
+
 /* ---- in-process kernel timing (bench.py's roofline leg) ---------------------------------------- */
 
 /* Kernel classes the launches are attributed to. */
@@ -296,7 +313,8 @@ typedef enum {
   DRIN_KC_STREAM = 4, /* k_entity_stream / k_cached_pairs: the single HBM-bound pass over entity bytes  */
   DRIN_KC_GEMM_X3 = 5,     /* k_gemm_bf16x3: split-bf16 contraction, fp32 operands split on the fly */
   DRIN_KC_GEMM_PLANES = 6, /* k_gemm_x3_planes: split-bf16 contraction on pre-split planes (LDS-DMA) */
-  DRIN_KC_COUNT = 7
+  DRIN_KC_OPTIM = 7,       /* drin_adam_step                                                        */
+  DRIN_KC_COUNT = 8
 } drin_kernel_class;
 
 /* While a profile is open, every launch the library makes - from any thread, e.g. drin_backward on

@@ -92,3 +92,62 @@ def test_grad_bucket_is_identity_without_process_group():
         p.grad = torch.ones_like(p)
     GradBucket(list(m.parameters())).allreduce_mean()
     assert all(torch.equal(p.grad, torch.ones_like(p)) for p in m.parameters())
+
+
+# ---- the EPOCH loop under data parallelism with n % (world * batch) != 0 (ranks must never disagree on the
+# number of steps or on the size of the last batch, or the per-step collectives pair up wrongly / hang) -------------------
+def _epoch_worker(rank, world, port, root, out_dir, global_loss):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        from drin_amd.data import create_datasets
+        model = OracleModel(CFG)
+        model.load_state_dict(synth.make_state_dict(CFG, 8))
+        loaders = create_datasets(CFG, root, rank=rank, world_size=world)
+        runner = MELRunner(CFG, model, "cpu", global_batch_loss=global_loss)
+        opt = torch.optim.Adam(model.parameters(), lr=CFG.learning_rate)
+        steps_tr, steps_va = len(loaders[0]), len(loaders[1])
+        tr = runner.run_epoch(loaders[0], 0, opt)
+        va = runner.run_epoch(loaders[1], 1, None)
+        torch.save({"w": {k: v.detach().clone() for k, v in model.state_dict().items()}, "train": (tr.loss, tr.topk),
+                    "valid": (va.loss, va.topk), "steps": (steps_tr, steps_va),
+                    "valid_total": int(runner.metrics[0].total)}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_loss", [False, True], ids=["per_rank_batch", "global_batch_loss"])
+def test_epoch_with_ragged_shards_runs_in_lockstep(global_loss, tmp_path):
+    from drin_amd.data import write_synthetic_dataset
+    root = str(tmp_path / "data")
+    # 13 train mentions on 2 ranks x batch 4: shards of 7 (one wrapped-around mention) -> 2 steps of sizes (4, 3) on BOTH
+    # ranks; unpadded they would be 7 / 6 mentions = last batches of 3 / 2.  5 valid mentions: 3 + 2, never padded
+    write_synthetic_dataset(CFG.with_(shuffle_train_data=True), root, sizes=(13, 5, 3), seed=11)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    mp.spawn(_epoch_worker, args=(2, _free_port(), root, out, global_loss), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2))
+    assert r0["steps"][0] == r1["steps"][0] == 2                       # same number of training steps
+    for k in r0["w"]:
+        assert torch.equal(r0["w"][k], r1["w"][k]), f"replicas diverged: {k}"   # every step's all-reduce paired up
+    assert r0["train"] == r1["train"] and r0["valid"][1] == r1["valid"][1]
+    assert r0["valid_total"] == r1["valid_total"] == 5                 # evaluation counts every mention exactly once
+
+
+def test_grad_bucket_reduces_a_flat_bucket_in_place_and_packs_anything_else():
+    """Gradients that are views of one flat buffer (what drin_amd.Model's backward hands to autograd) are recognised and
+    all-reduced in place; scattered gradients take the staging copy.  (world = 1 here: only the recognition is checked;
+    the collective itself runs in the two-rank tests above and in bench.py --stub.)"""
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+    flat = torch.arange(64 + 64 + 7, dtype=torch.float32)
+    params[0].grad, params[1].grad = flat[0:15].view(5, 3), flat[64:71]      # 256-byte slots, params[2] has no gradient
+    b = GradBucket(params)
+    live = [p for p in b.params if p.grad is not None]
+    view = b._aliased_bucket(live)
+    assert view is not None and view.data_ptr() == flat.data_ptr() and view.numel() == 71
+    view.mul_(2.0)
+    assert params[1].grad[0].item() == 128.0                                 # the same memory
+    params[1].grad = torch.ones(7)
+    assert b._aliased_bucket([p for p in b.params if p.grad is not None]) is None
+    assert b.nbytes() == 4 * (15 + 7)

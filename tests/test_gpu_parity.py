@@ -23,7 +23,7 @@ def _golden(golden_dir, name):
 
 
 def _model(cfg, sd):
-    m = Model(cfg).to(DEV)
+    m = Model(cfg, precision="f32").to(DEV)
     m.load_state_dict(sd)
     return m.eval()
 
@@ -234,7 +234,7 @@ def test_forward_matches_reference_golden(golden_dir, name):
         if l > 0:
             np.testing.assert_allclose(out[f"edges{l}"].numpy(), g[f"edges{l}"], atol=5e-6)
     # the Module call on the generic path (dead work of the last layer skipped) gives the same scores
-    unfused = Model(cfg, fused=False).to(DEV).eval()
+    unfused = Model(cfg, precision="f32", fused=False).to(DEV).eval()
     unfused.load_state_dict(sd)
     with torch.no_grad():
         s2 = unfused(_to_dev(batch)).cpu()
@@ -370,7 +370,7 @@ def test_fused_path_vs_oracle(maker, B, precision):
 def test_fused_path_follows_weight_updates():
     """The folded weights are cached per weight version: an optimizer step must invalidate them."""
     cfg, sd, batch = build_case("tiny_wd")
-    model = Model(cfg).to(DEV)
+    model = Model(cfg, precision="f32").to(DEV)
     model.load_state_dict(sd)
     dbatch = _to_dev(batch)
     with torch.no_grad():
@@ -504,7 +504,7 @@ def test_backward_matches_reference_golden(golden_dir, name):
     from drin_amd.metrics import TripletLoss
     cfg, sd, batch = build_case(name)
     g = _golden(golden_dir, name)
-    model = Model(cfg).to(DEV)
+    model = Model(cfg, precision="f32").to(DEV)
     model.load_state_dict(sd)
     dbatch = _to_dev(batch)
     scores = model(dbatch[:-1])
@@ -548,7 +548,7 @@ def test_backward_vs_oracle_autograd_reference_batch():
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref_loss = O.triplet_loss(batch[-1], O.forward(p, batch), cfg.triplet_margin)
     ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
-    model = Model(cfg).to(DEV)
+    model = Model(cfg, precision="f32").to(DEV)
     model.load_state_dict(sd)
     dbatch = _to_dev(batch)
     loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
@@ -575,7 +575,7 @@ def test_vector_edges_vs_oracle(maker, B, edge_type):
     ref_scores = O.forward(p, batch, dynamic=edge_type == "dynamic", vector=True)
     ref_loss = O.triplet_loss(batch[-1], ref_scores, cfg.triplet_margin)
     ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
-    model = Model(cfg).to(DEV)
+    model = Model(cfg, precision="f32").to(DEV)
     model.load_state_dict(sd)
     dbatch = _to_dev(batch)
     with torch.no_grad():
@@ -637,7 +637,7 @@ def test_training_loop_on_device_tracks_cpu_oracle_loop(tmp_path):
     for kind in ("hip", "oracle"):
         seed_everything(cfg.seed)
         loaders = create_datasets(cfg, str(tmp_path))
-        model = Model(cfg).to(DEV) if kind == "hip" else OracleModel(cfg)
+        model = Model(cfg, precision="f32").to(DEV) if kind == "hip" else OracleModel(cfg)
         hist[kind] = MELRunner(cfg, model, DEV if kind == "hip" else "cpu").fit(loaders)
     for a, b in zip(hist["hip"].train + hist["hip"].valid + hist["hip"].test,
                     hist["oracle"].train + hist["oracle"].valid + hist["oracle"].test):
@@ -675,7 +675,7 @@ def test_indexed_batch_matches_gathered_batch(token_level):
         assert torch.equal(a, b), precision
         assert (a.cpu() - ref).abs().max().item() <= 1e-5
     # training through the table form: same gradients as through the gathered tensors
-    model = Model(cfg).to(DEV)
+    model = Model(cfg, precision="f32").to(DEV)
     model.load_state_dict(sd)
     s1 = model(ib)
     s1.sum().backward()
@@ -728,7 +728,7 @@ def test_indexed_loader_and_runner(tmp_path):
     hist = {}
     for kind in ("gathered", "indexed", "device"):
         seed_everything(cfg.seed)
-        model = Model(cfg).to(DEV)
+        model = Model(cfg, precision="f32").to(DEV)
         if kind == "gathered":
             hist[kind] = MELRunner(cfg, model, DEV).fit(create_datasets(cfg, str(tmp_path)))
         else:
@@ -760,7 +760,7 @@ def test_unusual_geometries_vs_oracle(kw, B, fused):
     sd = synth.make_state_dict(cfg, 8)
     batch = synth.make_batch(cfg, B, 61, min_tokens=1)
     ref = O.forward(sd, batch)
-    model = Model(cfg, fused=fused).to(DEV).eval()
+    model = Model(cfg, precision="f32", fused=fused).to(DEV).eval()
     model.load_state_dict(sd)
     with torch.no_grad():
         got = model(_to_dev(batch)).cpu()
@@ -864,7 +864,7 @@ def test_random_table_forms(seed):
 
 def test_empty_batch():
     cfg = DrinConfig(**TINY)
-    model = Model(cfg).to(DEV).eval()
+    model = Model(cfg, precision="f32").to(DEV).eval()
     batch = [t[:0] for t in _to_dev(synth.make_batch(cfg, 2, 1))]
     with torch.no_grad():
         out = model(batch)
@@ -882,7 +882,7 @@ def test_inner_feature_dims_take_the_pooled_path():
     batch[9] = torch.randn(3, cfg.num_candidates_model, 3, cfg.resnet_embed_dim, generator=g)
     batch[10] = torch.randn(3, cfg.num_candidates_model, 1, 2, cfg.resnet_embed_dim, generator=g)
     ref = O.forward(sd, batch)
-    model = Model(cfg).to(DEV).eval()
+    model = Model(cfg, precision="f32").to(DEV).eval()
     model.load_state_dict(sd)
     with torch.no_grad():
         got = model(_to_dev(batch)).cpu()
@@ -1067,7 +1067,7 @@ def test_entity_cache_scores_match_oracle_and_uncached(kw):
         assert table._cache_key != key
         assert (moved - moved_plain).abs().max().item() <= 4e-6 and (moved - cached).abs().max().item() > 1e-4
     # training never takes the cache
-    model = Model(cfg).to(DEV)
+    model = Model(cfg, precision="f32").to(DEV)
     model.load_state_dict(sd)
     model(ib).sum().backward()
     assert model.gcn_layers[0].w_h.weight.grad is not None
@@ -1199,7 +1199,7 @@ def test_runner_with_device_loss_matches_torch_loss(tmp_path):
     for fused in (True, False):
         seed_everything(0)
         loaders = create_datasets(cfg, str(tmp_path), num_workers=0)
-        model = Model(cfg).to(DEV)
+        model = Model(cfg, precision="f32").to(DEV)
         runner = MELRunner(cfg, model, DEV, device_loss=fused)
         assert (runner.device_loss is not None) == fused
         hist[fused] = runner.fit(loaders, num_epoch=2, test_epoch_interval=2)

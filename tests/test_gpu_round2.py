@@ -1,0 +1,320 @@
+"""-m gpu, round 2: flat gradient / parameter buckets and the one-launch Adam, data-parallel semantics through the HIP
+`Model`, call splitting above 32 768 mentions, BASELINE config 5 at FULL width (N = 1001, D = 768, R = 2048, a >= 1 M-row
+entity table, fused path and per-entity cache) against the oracle, cache / fold invalidation."""
+import ctypes as C
+
+import pytest
+import torch
+
+from drin_amd import _lib, synth
+from drin_amd.config import DrinConfig, wikimel_config
+from drin_amd.model import EntityTable, IndexedBatch, Model, _param_list
+from drin_amd.train import GradBucket, LibraryAdam, make_adam
+from oracle import drin_oracle as O
+from oracle.cases import TINY
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _to_dev(batch):
+    return [t.to(DEV) for t in batch]
+
+
+# ---- one-launch Adam (train.py:55-56) ---------------------------------------------------------------------------------
+def _adam_call(p, g, m, v, t, lr, arith):
+    lib = _lib.load()
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    bc1, bc2 = 1 - b1 ** float(t), 1 - b2 ** float(t)
+    scal = (1 - b1, b2, 1 - b2, bc2 ** 0.5, eps, (lr / bc1) * -1)
+    _lib.check(lib.drin_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), *(C.c_float(x) for x in scal),
+                                  arith, torch.cuda.current_stream().cuda_stream))
+
+
+def test_library_adam_matches_torch_adam_bitwise():
+    """drin_adam_step == torch.optim.Adam (default multi-tensor implementation) BIT FOR BIT over several steps, on values
+    spanning many magnitudes: the training loop's trajectory is then the reference loop's (Adam amplifies rounding)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    n = 3 * 768 * 768 + 13                                    # ragged tail included
+    p0 = torch.randn(n, device=DEV, generator=g) * torch.logspace(-6, 2, n, device=DEV)
+    grads = [torch.randn(n, device=DEV, generator=g) * torch.logspace(-8, 1, n, device=DEV).flip(0) for _ in range(6)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    mine = {a: (p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)) for a in range(8)}
+    matches = set(range(8))
+    for t, gr in enumerate(grads, 1):
+        ref.grad = gr.clone()
+        opt.step()
+        for a in list(matches):
+            p, m, v = mine[a]
+            _adam_call(p, gr, m, v, t, 1e-3, a)
+            st = opt.state[ref]
+            if not (torch.equal(p, ref.data) and torch.equal(m, st["exp_avg"]) and torch.equal(v, st["exp_avg_sq"])):
+                matches.discard(a)
+    print("arith variants bit-identical to torch.optim.Adam:", sorted(matches))
+    lib = _lib.load()
+    # the library default must be one of them
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ref2 = torch.nn.Parameter(p0.clone())
+    opt2 = torch.optim.Adam([ref2], lr=1e-3)
+    for t, gr in enumerate(grads, 1):
+        ref2.grad = gr.clone()
+        opt2.step()
+        _adam_call(p, gr, m, v, t, 1e-3, _lib.ADAM_ARITH_DEFAULT)
+    assert torch.equal(p, ref2.data), f"default arithmetic differs from torch.optim.Adam; bit-identical variants: {sorted(matches)}"
+    assert lib.drin_adam_step(None, None, None, None, 4, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) == _lib.E_NULL
+
+
+def _train_setup(cfg, B, seed=31, precision="bf16x3", **kw):
+    sd = synth.make_state_dict(cfg, 8)
+    model = Model(cfg, precision=precision, **kw).to(DEV)
+    model.load_state_dict(sd)
+    batch = _to_dev(synth.make_batch(cfg, B, seed))
+    return model, batch, sd
+
+
+def _step_loss(model, batch, cfg):
+    from drin_amd.metrics import TripletLoss
+    return TripletLoss(cfg.triplet_margin)(batch[14], model(batch[:14]))
+
+
+@pytest.mark.parametrize("maker", [lambda: DrinConfig(), lambda: DrinConfig(gcn_edge_type="static", **TINY),
+                                   lambda: DrinConfig(gcn_edge_feature="vector", **TINY),
+                                   lambda: wikimel_config(max_entity_attr_token_len=8)],
+                         ids=["wikidiverse", "static", "vector", "wikimel"])
+def test_gradients_are_views_of_one_flat_bucket(maker):
+    """backward writes into ONE flat bucket: every .grad is a view of it at its slot, dead parameters have none, the values
+    equal those of the per-tensor path, and a second backward before zero_grad accumulates like torch (fresh bucket)."""
+    cfg = maker()
+    model, batch, sd = _train_setup(cfg, 6)
+    plain, _, _ = _train_setup(cfg, 6, grad_bucket=False)
+    _step_loss(model, batch, cfg).backward()
+    _step_loss(plain, batch, cfg).backward()
+    flat = model.grad_bucket()
+    assert flat is not None and flat.data_ptr() == model._grad_flat.data_ptr()
+    offsets, live, total = model.bucket_layout()
+    n_live = 0
+    for o, p, q in zip(offsets, _param_list(model), _param_list(plain)):
+        assert (p.grad is None) == (q.grad is None)
+        if p.grad is None:
+            assert o >= live                                          # dead parameters sit behind the all-reduced prefix
+            continue
+        assert p.grad.data_ptr() == flat.data_ptr() + 4 * o and o + p.numel() <= live
+        # same kernels, same order - except that the weight-gradient atomics of small products may differ in the last bits
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)
+        n_live += p.numel()
+    assert n_live <= live < n_live + 64 * len(offsets)
+    bucket = GradBucket(list(model.parameters()))
+    assert bucket._aliased_bucket([p for p in bucket.params if p.grad is not None]) is not None
+    # accumulate a second backward: the bucket the .grads alias must not be zeroed under them
+    first = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    _step_loss(model, batch, cfg).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(p.grad, 2 * first[k], rtol=1e-4, atol=1e-7), k
+
+
+def test_data_parallel_step_through_the_hip_model_equals_the_full_batch():
+    """SURVEY.md 8e with the HIP Model and its flat bucket (world = 1, the collective injected as "sum of shards / 2"):
+    two half-batches, each with its own per-rank loss, bucket-averaged == the mean of the two half-batch gradients computed
+    tensor by tensor, and the one-launch Adam on the averaged bucket == torch.optim.Adam on those means."""
+    cfg = wikimel_config(max_entity_attr_token_len=8, batch_size=4)
+    model, batch, sd = _train_setup(cfg, 8, precision="f32")
+    halves = [[t[:4] for t in batch], [t[4:] for t in batch]]
+    buckets = []
+    for h in halves:                                                    # what rank r computes
+        model.zero_grad(set_to_none=True)
+        _step_loss(model, h, cfg).backward()
+        buckets.append(model.grad_bucket().clone())
+    ref, _, _ = _train_setup(cfg, 8, precision="f32", grad_bucket=False)
+    mean = {}
+    for h in halves:
+        ref.zero_grad(set_to_none=True)
+        _step_loss(ref, h, cfg).backward()
+        for k, p in ref.named_parameters():
+            if p.grad is not None:
+                mean[k] = mean.get(k, 0) + p.grad / 2
+    # the all-reduce (mean) acts on the bucket in place: emulate it on rank 1's live bucket
+    live = model.grad_bucket()
+    live.copy_((buckets[0] + buckets[1]) / 2)
+    for k, p in model.named_parameters():
+        assert (p.grad is None) == (k not in mean), k
+        if p.grad is not None:
+            assert torch.allclose(p.grad, mean[k], rtol=2e-5, atol=1e-7), k
+    assert {k for k, p in model.named_parameters() if p.grad is None} == {f"gcn_layers.1.w_{x}.{y}" for x in "uv" for y in ("weight", "bias")}
+    opt = make_adam(model, 1e-3)
+    assert isinstance(opt, LibraryAdam)
+    opt.step()
+    assert opt.one_launch_steps == 1
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    for k, p in ref.named_parameters():
+        p.grad = mean.get(k)
+    topt.step()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=2e-6), k            # first Adam step: +-lr, sign of the gradient
+    # the parameters now live in one flat bucket too; state_dict / load_state_dict are unaffected
+    flat = model.flatten_parameters()
+    assert all(p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in model.parameters())
+    model.load_state_dict(sd)
+    assert torch.equal(model.gcn_layers[0].w_h.weight, sd["gcn_layers.0.w_h.weight"].to(DEV))
+    with torch.no_grad():
+        s1 = model.eval()(batch[:14])
+    fresh = Model(cfg, precision="f32").to(DEV).eval()
+    fresh.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(s1, fresh(batch[:14]))
+
+
+def test_library_adam_loop_tracks_torch_adam_loop():
+    """Five optimisation steps of the same model / data with LibraryAdam and with torch.optim.Adam: identical weights
+    (bit for bit when the default arithmetic matches torch's - asserted separately - and the gradients are deterministic)."""
+    cfg = DrinConfig(**TINY)
+    a, batch, _ = _train_setup(cfg, 16, precision="f32")
+    b, _, _ = _train_setup(cfg, 16, precision="f32")
+    oa, ob = make_adam(a, 1e-3), make_adam(b, 1e-3, library=False)
+    assert isinstance(ob, torch.optim.Adam)
+    for _ in range(5):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            _step_loss(m, batch, cfg).backward()
+            o.step()
+    assert oa.one_launch_steps == 5
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert (p - q).abs().max().item() <= 1e-6, k
+
+
+def test_frozen_parameters_take_the_per_tensor_adam_path():
+    cfg = DrinConfig(**TINY)
+    model, batch, _ = _train_setup(cfg, 8)
+    model.vertex_encoder.mention_image_linear.weight.requires_grad_(False)
+    before = model.vertex_encoder.mention_image_linear.weight.clone()
+    w0 = model.gcn_layers[0].w_h.weight.clone()
+    opt = make_adam(model, 1e-2)
+    opt.zero_grad()
+    _step_loss(model, batch, cfg).backward()
+    opt.step()
+    assert opt.one_launch_steps == 0
+    assert torch.equal(model.vertex_encoder.mention_image_linear.weight, before)
+    assert not torch.equal(model.gcn_layers[0].w_h.weight, w0)
+
+
+# ---- calls above 32 768 mentions are split (launch_entity_stream refused B > 65 535) ------------------------
+def test_large_batches_are_split_into_calls():
+    cfg = DrinConfig(num_candidates_data=3, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    B = 70_000                                                       # > 65 535: the grids of the row kernels stop there
+    batch = synth.make_device_batch(cfg, B, 9, DEV)[:14]
+    with torch.no_grad():
+        out = model(batch)
+        assert out.shape == (B, 4) and torch.isfinite(out).all()
+        for rows in (slice(0, 5), slice(32766, 32771), slice(B - 3, B)):    # mention independence: any slice alone
+            assert torch.equal(out[rows], model([t[rows] for t in batch]))
+        ref = O.forward(sd, [t[32760:32776].cpu() for t in batch])
+        assert (out[32760:32776].cpu() - ref).abs().max().item() <= 1e-5
+        # table form splits too
+        tab = synth.make_device_batch(cfg.with_(num_candidates_data=499), 1, 4, DEV)
+        table = EntityTable(tab[7][0], None, tab[9][0], tab[10][0], tab[11][0])
+        cand = torch.randint(0, 500, (B, 4), device=DEV)
+        ib = IndexedBatch(batch[:7], table, cand, batch[12], batch[13])
+        big = model(ib)
+        sub = IndexedBatch([t[40000:40004] for t in batch[:7]], table, cand[40000:40004], batch[12][40000:40004], batch[13][40000:40004])
+        assert torch.equal(big[40000:40004], model(sub))
+
+
+# ---- BASELINE config 5 at full width (only ever tested at D = 64) -------------------------------------------
+@pytest.fixture(scope="module")
+def million_entity_table():
+    cfg = DrinConfig(num_candidates_data=1000)
+    E, D, R = 1_000_003, cfg.bert_embed_dim, cfg.resnet_embed_dim
+    g = torch.Generator(device=DEV).manual_seed(7)
+    table = EntityTable(torch.randn(E, D, device=DEV, generator=g), None, torch.randn(E, R, device=DEV, generator=g),
+                        torch.randn(E, 1, R, device=DEV, generator=g), torch.rand(E, 1, device=DEV, generator=g))
+    yield cfg, table
+    table.invalidate()
+    del table
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("path", ["fused", "cache", "exact_f32"])
+def test_config5_full_width_against_the_oracle(million_entity_table, path):
+    """N = 1001 candidates per mention gathered from a 1 000 003-row table at D = 768 / R = 2048 (63 chunks of 16
+    candidates in k_entity_stream, entity_index up to 2^20, k_cached_pairs over 23.5 KB cache rows): three mentions'
+    slices against the CPU oracle on the gathered rows; the remaining mentions against each other across paths."""
+    cfg, table = million_entity_table
+    sd = synth.make_state_dict(cfg, 7)
+    B, N, E = 37, cfg.num_candidates_model, table.num_entities
+    g = torch.Generator(device=DEV).manual_seed(11)
+    men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 12, DEV)
+    cand = torch.randint(0, E, (B, N), device=DEV, generator=g)
+    cand[0, :3] = torch.tensor([0, E - 1, E - 2], device=DEV)          # first / last rows of the table
+    sims = 20.0 + 5.0 * torch.randn(2, B, N, device=DEV, generator=g)
+    ib = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+    model = Model(cfg, precision="f32" if path == "exact_f32" else "bf16x3").to(DEV).eval()
+    model.load_state_dict(sd)
+    table.enable_cache(path == "cache")
+    with torch.no_grad():
+        got = model(ib)
+        again = model(ib)
+    table.enable_cache(False)
+    assert got.shape == (B, N) and torch.isfinite(got).all() and torch.equal(got, again)
+    rows = [0, 17, B - 1]
+    sub = IndexedBatch([t[rows] for t in men[:7]], table, cand[rows], sims[0][rows], sims[1][rows])
+    ref = O.forward(sd, [t.cpu() for t in sub.gathered()])
+    err = (got[rows].cpu() - ref).abs().max().item()
+    top1 = (got[rows, :-1].argmax(1).cpu() == ref[:, :-1].argmax(1)).float().mean().item()
+    print(f"config 5 full width, {path}: max |score - oracle| = {err:.2e}, top-1 agreement {top1}")
+    assert err <= 2e-5 and top1 == 1.0                                 # bar of the path: 1e-4
+    if path == "cache":
+        plain = Model(cfg).to(DEV).eval()
+        plain.load_state_dict(sd)
+        with torch.no_grad():
+            assert (plain(ib) - got).abs().max().item() <= 1e-5         # every mention: cached == un-cached
+
+
+def test_table_edits_and_data_writes_are_seen_or_can_be_declared():
+    """the cache keyed on the text pointer alone missed edits of the image / object tables; writes through
+    `.data` bypass the version counter and need `invalidate()`."""
+    cfg = DrinConfig(num_candidates_data=20, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    E, B, N = 83, 5, cfg.num_candidates_model
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 71)
+    table = EntityTable(tab[7][0], None, tab[9][0], tab[10][0], tab[11][0]).to(DEV).enable_cache()
+    men = _to_dev(synth.make_batch(cfg, B, 72))
+    cand = torch.randint(0, E, (B, N), generator=torch.Generator().manual_seed(3)).to(DEV)
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+
+    def oracle():
+        return O.forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, [t.cpu() for t in ib.gathered()])
+
+    with torch.no_grad():
+        assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5
+        table.image.mul_(-0.5)                                        # in-place torch op on the IMAGE table: seen
+        assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5
+        table.object_score.data.fill_(0.25)                           # a .data write: invisible ...
+        stale = (model(ib).cpu() - oracle()).abs().max().item()
+        table.invalidate()                                            # ... until declared
+        assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5 < stale
+        model.gcn_layers[0].w_h.weight.data.mul_(1.25)                # the same for the weights
+        stale = (model(ib).cpu() - oracle()).abs().max().item()
+        model.invalidate()
+        assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5 < stale
+        model.load_state_dict(sd)                                     # load_state_dict invalidates by itself
+        assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_second_device_opts_into_large_lds():
+    """the dynamic-LDS opt-in is per device; a process that ran on cuda:0 first must still launch on cuda:1."""
+    cfg = wikimel_config(max_entity_attr_token_len=8)
+    sd = synth.make_state_dict(cfg, 7)
+    outs = []
+    for d in ("cuda:0", "cuda:1"):
+        m = Model(cfg).to(d).eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            outs.append(m([t.to(d) for t in synth.make_batch(cfg, 300, 5)[:14]]).cpu())
+    assert torch.equal(outs[0], outs[1])

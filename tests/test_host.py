@@ -8,7 +8,7 @@ import torch
 
 from drin_amd import synth
 from drin_amd.config import DrinConfig, wikimel_config
-from drin_amd.data import create_datasets, write_synthetic_dataset
+from drin_amd.data import ShardSampler, create_datasets, write_synthetic_dataset
 from drin_amd.metrics import TopkAccuracy, TripletLoss
 from drin_amd.model import Model
 from drin_amd.train import MELRunner, seed_everything
@@ -89,11 +89,20 @@ def test_loader_tuple_contract(tmp_path, cfg):
 
 def test_sharded_loaders_partition_the_split(tmp_path):
     write_synthetic_dataset(TINY_WD, str(tmp_path), sizes=(11, 4, 4), seed=5)
-    seen = []
+    seen, valid = [], []
     for r in range(2):
-        tr = create_datasets(TINY_WD, str(tmp_path), rank=r, world_size=2)[0]
-        seen.append(sorted(list(tr.sampler)))
-    assert sorted(seen[0] + seen[1]) == list(range(11)) and not set(seen[0]) & set(seen[1])
+        loaders = create_datasets(TINY_WD, str(tmp_path), rank=r, world_size=2)
+        seen.append(list(loaders[0].sampler))
+        valid.append(list(loaders[1].sampler))
+        assert len(loaders[0].sampler) == len(seen[-1]) and len(loaders[1].sampler) == len(valid[-1])
+    # train: every mention is drawn, and the shards have ONE length (11 = 6 + 6 with one wrapped-around mention), so that
+    # every rank runs the same number of steps - the per-step gradient all-reduce needs that
+    assert len(seen[0]) == len(seen[1]) == 6 and set(seen[0] + seen[1]) == set(range(11))
+    assert len(seen[0] + seen[1]) - len(set(seen[0] + seen[1])) == 1
+    # evaluation: an exact partition - every mention counts once in the metrics
+    assert sorted(valid[0] + valid[1]) == list(range(4)) and not set(valid[0]) & set(valid[1])
+    odd = [list(ShardSampler(5, r, 2, False, 0)) for r in range(2)]
+    assert sorted(odd[0] + odd[1]) == list(range(5)) and len(odd[0]) == 3 and len(odd[1]) == 2
 
 
 def test_triplet_loss_matches_oracle_and_reference_vectors(golden_dir):

@@ -662,7 +662,7 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
         "library_launches_per_step": sum(v[1] for v in prof.values()) / steps,
         "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items()},
         "roofline": train_roofline(cfg, B, N, prof, steps, precision),
-        "final_loss": float(loss)}
+        "final_loss": float(loss.detach())}
 
 
 # =====================================================================================================================

@@ -19,7 +19,6 @@ ABI_VERSION = 2
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
 FEAT_F32, FEAT_BF16 = 0, 1
-ADAM_ARITH_DEFAULT = -1
 
 fp = C.POINTER(C.c_float)
 ip = C.POINTER(C.c_int64)
@@ -102,7 +101,7 @@ EXPORTS = {
     "drin_triplet_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_int32), C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
-                                 C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+                                 C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "drin_profile_begin": (C.c_int, [C.c_int]),
     "drin_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "drin_kernel_class_name": (C.c_char_p, [C.c_int]),

@@ -245,10 +245,10 @@ int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P,
   // (entity_text_cls: the raw rows of a batch whose token means were pooled ahead of time)
   const float* raw = b->entity_text_cls ? b->entity_text_cls : b->entity_text;
   const int64_t raw_stride = b->entity_text_cls ? (int64_t)c->embed_dim : P.entity_text_raw_stride;
+  // (the two CLIP edges are two loads and two divisions per pair: they ride in the cosine launch)
   DRIN_TRY(launch_cosine_rows(P.span_mean, raw, raw_stride, edges + 0 * M, B, N, c->embed_dim, c->cosine_eps, 1.0f, st,
-                              b->entity_index));
-  DRIN_TRY(launch_scale_div(b->mtei_similarity, edges + 1 * M, M, 1.0f, c->clip_scale, st));
-  DRIN_TRY(launch_scale_div(b->miet_similarity, edges + 2 * M, M, 1.0f, c->clip_scale, st));
+                              b->entity_index, b->mtei_similarity, b->miet_similarity, edges + 1 * M, edges + 2 * M,
+                              c->clip_scale));
   DRIN_TRY(launch_miei(P.mention_object, b->mention_object_score, P.entity_object, b->entity_object_score,
                        edges + 3 * M, B, N, c->mention_objects, c->entity_objects, c->image_dim, c->cosine_eps,
                        c->miei_eps, 1.0f, st, b->entity_index));
@@ -583,10 +583,10 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st, tl, tlf));
     float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
     float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
-    DRIN_TRY(launch_layernorm_gelu(h_m, W.ln_weight, W.ln_bias, ws + L.vm[l + 1], st_m, st_m ? st_m + 2 * (size_t)B : nullptr,
-                                   (int64_t)types * B, D, cfg->layer_norm_eps, st));
-    DRIN_TRY(launch_layernorm_gelu(h_e, W.ln_weight, W.ln_bias, ws + L.ve[l + 1], st_e, st_e ? st_e + 2 * (size_t)M : nullptr,
-                                   (int64_t)types * M, D, cfg->layer_norm_eps, st));
+    // one LayerNorm + GELU launch for the mention and the entity vertices (they share it, model.py:128)
+    DRIN_TRY(launch_layernorm_gelu2(h_m, ws + L.vm[l + 1], st_m, st_m ? st_m + 2 * (size_t)B : nullptr, (int64_t)types * B, h_e,
+                                    ws + L.ve[l + 1], st_e, st_e ? st_e + 2 * (size_t)M : nullptr, (int64_t)types * M,
+                                    W.ln_weight, W.ln_bias, D, cfg->layer_norm_eps, st));
     // dynamic edges, edge_graph of model.py:107: (mt,et) (mt,ei) (mi,et) (mi,ei)
     float* e_next = ws + L.edges[l + 1];
     if (live_edges && vec) {
@@ -742,25 +742,40 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
 
   bool all_enabled = true;
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
-
   float* const tnp = L.tn_part_floats ? ws + L.tn_part : nullptr;  // partial tiles of the split-bf16 dW products
   const size_t tnf = L.tn_part_floats;
   // dX (+)= dY W.  Pair-sized products in split-bf16 precision run on the NT kernel against W^T, transposed into
   // workspace scratch right before use (a D x D transpose is ~3 us; the product it feeds is 2.5x faster than
   // the exact-fp32 MFMA one); everything else takes the exact fp32 NN kernel.
   const bool x3 = prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL;
+  // scalar edges: W_h^T and W_v^T of every layer in ONE batched transpose up front (slots 2 l and 2 l + 1 of L.wt);
+  // vector edges (half-width W_u / W_v, W_m) transpose per product into slot 0
+  const bool pre_t = x3 && !cfg->vector_edges && M >= 1024 && (D % 32) == 0;
+  auto wt_slot = [&](int l, int which) { return ws + L.wt + ((size_t)2 * l + which) * D * D; };
+  if (pre_t) {
+    TransposeBatch tb;
+    for (int l = 0; l < nl; ++l) {
+      tb.src[tb.n] = params->layer[l].w_h, tb.dst[tb.n++] = wt_slot(l, 0);
+      if (cfg->dynamic_edges && l < nl - 1) tb.src[tb.n] = params->layer[l].w_v, tb.dst[tb.n++] = wt_slot(l, 1);
+    }
+    DRIN_TRY(launch_transpose_batch(tb, D, D, st));
+  }
   auto gemm_nn = [&](const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int64_t rows, int n_out,
-                     int k_red, bool accumulate) -> int {
-    // w is [k_red][n_out] contiguous
+                     int k_red, bool accumulate, const float* w_t = nullptr) -> int {
+    // w is [k_red][n_out] contiguous; w_t: its transpose, already in the workspace
     if (x3 && rows >= 1024 && (k_red % 32) == 0 && (n_out % 4) == 0 && (size_t)k_red * n_out <= (size_t)D * D) {
-      float* wt = ws + L.wt;
-      DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));
-      return launch_gemm_nt_bf16x3(dy, lddy, wt, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate,
+      if (w_t == nullptr) {
+        float* wt = ws + L.wt;
+        DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));
+        w_t = wt;
+      }
+      return launch_gemm_nt_bf16x3(dy, lddy, w_t, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate,
                                    false, tnp, tnf);
     }
     return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st,
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
   };
+  ColsumBatch bias_sums;   // the bias gradients of W_u / W_v and of the vertex encoders: one launch
 
   // score = cos(mt_L, et_L) (model.py:207-209)
   int cur = 0;
@@ -779,10 +794,10 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     const float* st_m = ws + L.ln_stat_m[l];
     const float* st_e = ws + L.ln_stat_e[l];
     // (a) LayerNorm + GELU backward; column sums give dgamma, dbeta and db_h
-    DRIN_TRY(launch_layernorm_gelu_bwd(ws + L.h_m[l], st_m, st_m + 2 * (size_t)B, W.ln_weight, W.ln_bias, gm,
-                                       G.ln_weight, G.ln_bias, G.b_h, ws + L.ln_part, (int64_t)types * B, D, st));
-    DRIN_TRY(launch_layernorm_gelu_bwd(ws + L.h_e[l], st_e, st_e + 2 * M, W.ln_weight, W.ln_bias, ge, G.ln_weight,
-                                       G.ln_bias, G.b_h, ws + L.ln_part, (int64_t)types * M, D, st));
+    // (mention and entity rows in one launch)
+    DRIN_TRY(launch_layernorm_gelu_bwd2(ws + L.h_m[l], st_m, st_m + 2 * (size_t)B, gm, (int64_t)types * B, ws + L.h_e[l], st_e,
+                                        st_e + 2 * M, ge, (int64_t)types * M, W.ln_weight, W.ln_bias, G.ln_weight, G.ln_bias,
+                                        G.b_h, ws + L.ln_part, D, st));
     // (b) dW_h += dH^T A
     if (G.w_h) {
       DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st, tnp, tnf));
@@ -790,7 +805,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     }
     // (c) dA = dH W_h
     DRIN_TRY(gemm_nn(gm, D, W.w_h, dA_m, D, (int64_t)types * B, D, D, false));
-    DRIN_TRY(gemm_nn(ge, D, W.w_h, dA_e, D, (int64_t)types * M, D, D, false));
+    DRIN_TRY(gemm_nn(ge, D, W.w_h, dA_e, D, (int64_t)types * M, D, D, false, pre_t ? wt_slot(l, 0) : nullptr));
     const float* dA_mt = dA_m;
     const float* dA_mi = types == 2 ? dA_m + BD : nullptr;
     const float* dA_et = dA_e;
@@ -818,13 +833,11 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       de_extra = g_e[cur];
     } else if (edge_update) {
       // (d) e'_k = sigmoid(mean_d(fu fv) + e_k)  (model.py:148-153,133)
-      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)M, st));
       const float* fu = ws + L.fu[l];
       const float* fv = ws + L.fv[l];
       const float inv_d = 1.0f / (float)D;
-      // dfv_t = (dpre_tt fu_t + dpre_it fu_i) / D ; dfv_i = (dpre_ti fu_t + dpre_ii fu_i) / D
-      DRIN_TRY(launch_entity_combine(dpre, fu, dpre + 2 * M, fu + BD, dfv, B, N, D, inv_d, st));
-      DRIN_TRY(launch_entity_combine(dpre + M, fu, dpre + 3 * M, fu + BD, dfv + MD, B, N, D, inv_d, st));
+      // dpre = g e' (1 - e');  dfv_t = (dpre_tt fu_t + dpre_it fu_i) / D ; dfv_i = (dpre_ti fu_t + dpre_ii fu_i) / D: one pass
+      DRIN_TRY(launch_edge_update_bwd(g_e[cur], ws + L.edges[l + 1], fu, dpre, dfv, B, N, D, inv_d, st));
       // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
       if (B <= 65535) {
         DRIN_TRY(launch_mention_reduce2(dpre, fv, fv + MD, nullptr, nullptr, dfu, dfu + BD, B, N, D, inv_d, st));
@@ -833,9 +846,9 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
         DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
       }
       if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, prec, st, tnp, tnf));
-      DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, D, st));
+      DRIN_TRY(bias_sums.add(dfv, G.b_v, 2 * (int64_t)M, D));
       if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st, tnp, tnf));
-      DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, D, st));
+      DRIN_TRY(bias_sums.add(dfu, G.b_u, 2 * (int64_t)B, D));
       de_extra = dpre;
     } else if (!cfg->dynamic_edges && have_edge) {
       de_extra = g_e[cur];  // static edges pass through (model.py:136)
@@ -853,7 +866,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     } else {
       // (e) entity side of the aggregation backward + edge gradients
       // (the edge update's dfv W_v goes first and the row kernel adds onto it)
-      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, D, false));
+      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, D, false, pre_t ? wt_slot(l, 1) : nullptr));
       DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
                                       g_e[nxt], B, N, D, cfg->edge_enabled, edge_update, st));
       // (f) mention side
@@ -868,6 +881,12 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     have_image = true;
     have_edge = true;
     cur = nxt;
+    // dfv / dfu are overwritten by the next layer down: their column sums go now - except layer 0's, which share the
+    // launch of the vertex encoders' bias gradients below
+    if (l > 0 && bias_sums.n > 0) {
+      DRIN_TRY(launch_colsum_batch(bias_sums, st));
+      bias_sums = ColsumBatch();
+    }
   }
 
   // VertexEncoder (model.py:26-46): four Linears over the pooled inputs
@@ -876,26 +895,26 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   const float* g_et = g_ve[cur];
   const float* g_ei = g_ve[cur] + MD;
   if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st, tnp, tnf));
-  DRIN_TRY(launch_colsum(g_mt, grads->b_mention_text, B, D, st));
+  DRIN_TRY(bias_sums.add(g_mt, grads->b_mention_text, B, D));
   if (grads->w_entity_text) {
     if (eidx)
       DRIN_TRY(launch_gemm_tn_bf16x3(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, st, tnp, tnf, eidx));
     else
       DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st, tnp, tnf));
   }
-  DRIN_TRY(launch_colsum(g_et, grads->b_entity_text, (int64_t)M, D, st));
+  DRIN_TRY(bias_sums.add(g_et, grads->b_entity_text, (int64_t)M, D));
   if (have_image) {
     if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st, tnp, tnf));
-    DRIN_TRY(launch_colsum(g_mi, grads->b_mention_image, B, D, st));
+    DRIN_TRY(bias_sums.add(g_mi, grads->b_mention_image, B, D));
     if (grads->w_entity_image) {
       if (eidx)
         DRIN_TRY(launch_gemm_tn_bf16x3(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, st, tnp, tnf, eidx));
       else
         DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st, tnp, tnf));
     }
-    DRIN_TRY(launch_colsum(g_ei, grads->b_entity_image, (int64_t)M, D, st));
+    DRIN_TRY(bias_sums.add(g_ei, grads->b_entity_image, (int64_t)M, D));
   }
-  return DRIN_OK;
+  return launch_colsum_batch(bias_sums, st);
 }
 
 }  // extern "C"

@@ -131,12 +131,23 @@ int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx,
 // V = float4 columns per lane (3 for D = 768).  The next row's h / g are requested before the current row's
 // erf / exp chain starts: the kernel is half memory (3 rows of traffic per row), half VALU, and four resident waves
 // per SIMD did not overlap the two on their own (2 x 51 712 rows: 257 us without the prefetch).
+// one row segment of the LayerNorm backward: pre-LayerNorm values, saved statistics, gradient (in / out)
+struct LnBwdSeg {
+  const float* h;
+  const float* mean;
+  const float* rstd;
+  float* g;
+  int64_t rows;
+};
+
 template <int V>
-__global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restrict__ h, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd,
+__global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const LnBwdSeg sa, const LnBwdSeg sb,
                                                             const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* g,
-                                                            float* __restrict__ partial, int64_t rows, int D4) {
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ partial, int D4) {
+  // rows of segment a, then rows of segment b (the mention vertices and the entity vertices of a layer share W_h and the
+  // LayerNorm, model.py:128: one launch and one set of column sums for both)
+  const int64_t rows = sa.rows + sb.rows;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 gm[V], bt[V];
   float4 a_dg[V], a_db[V], a_dh[V];
@@ -154,23 +165,25 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const float* __restr
   float4 hv[V], gv[V];
   float mu = 0.f, rs = 0.f;
   auto fetch = [&](int64_t r, float4* ph, float4* pg, float& m, float& s) {
-    const float* hr = h + r * (int64_t)D4 * 4;
-    const float* gr = g + r * (int64_t)D4 * 4;
+    const bool first = r < sa.rows;
+    const int64_t lr = first ? r : r - sa.rows;
+    const float* hr = (first ? sa.h : sb.h) + lr * (int64_t)D4 * 4;
+    const float* gr = (first ? sa.g : sb.g) + lr * (int64_t)D4 * 4;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int c4 = lane + 64 * j;
       ph[j] = c4 < D4 ? ld4(hr + c4 * 4) : zero;
       pg[j] = c4 < D4 ? ld4(gr + c4 * 4) : zero;
     }
-    m = mean[r];
-    s = rstd[r];
+    m = (first ? sa.mean : sb.mean)[lr];
+    s = (first ? sa.rstd : sb.rstd)[lr];
   };
   if (row < rows) fetch(row, hv, gv, mu, rs);
   for (; row < rows; row += stride) {
     float4 nh[V], ng[V];
     float nmu = 0.f, nrs = 0.f;
     if (row + stride < rows) fetch(row + stride, nh, ng, nmu, nrs);
-    float* gr = g + row * (int64_t)D4 * 4;
+    float* gr = (row < sa.rows ? sa.g + row * (int64_t)D4 * 4 : sb.g + (row - sa.rows) * (int64_t)D4 * 4);
     float4 xh[V], dxh[V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -271,22 +284,30 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
   }
 }
 
-int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
-                              int64_t rows, int D, hipStream_t st) {
-  if (rows <= 0) return DRIN_OK;
+// (h2 .. rows2: an optional second row segment sharing gamma / beta and the column sums.  Folding the two k_sum_partials
+//  launches into this kernel with arrival tickets - last block of a group adds the group, last group adds the groups - was
+//  measured and dropped: every block's device-scope release is an L2 write-back on this 8-XCD part; the B = 64 training step
+//  went from 1.61 to 1.81 ms with it, same box)
+int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* rstd, float* g, int64_t rows, const float* h2,
+                               const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
+                               const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
+                               hipStream_t st) {
+  const int64_t total = rows + (h2 != nullptr ? rows2 : 0);
+  if (total <= 0) return DRIN_OK;
   if (D % 4 || D > 256 * MAXV) {
     set_error("layernorm_gelu_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
     return DRIN_E_SHAPE;
   }
   // 161 VGPRs at V = 3: three workgroups per CU are resident, so 768 (of the 1024 the partial buffer holds) run as one round
   const int64_t cap = 768;
-  const int64_t blocks = cdiv(rows, 4) < cap ? cdiv(rows, 4) : cap;
+  const int64_t blocks = cdiv(total, 4) < cap ? cdiv(total, 4) : cap;
   KernelTimer timer(DRIN_KC_GCN, st);
   const int v = (int)cdiv(D / 4, 64);
   auto kern = v <= 1 ? k_layernorm_gelu_bwd<1> : v == 2 ? k_layernorm_gelu_bwd<2> : v == 3 ? k_layernorm_gelu_bwd<3>
                                                                                          : k_layernorm_gelu_bwd<4>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, h, mean, rstd, gamma, beta, g, partial, rows, D / 4);
+  const LnBwdSeg sa{h, mean, rstd, g, rows};
+  const LnBwdSeg sb{h2, mean2, rstd2, g2, h2 != nullptr ? rows2 : 0};
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, sa, sb, gamma, beta, partial, D / 4);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
   // partial: [kLnBwdMaxBlocks][3][D] block rows, then [kLnBwdMaxBlocks / 64][3][D] for the first reduction level
   float* level1 = partial + (int64_t)kLnBwdMaxBlocks * 3 * D;
@@ -298,6 +319,13 @@ int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rs
                      dbeta, dbias);
   DRIN_CHECK_LAUNCH("k_sum_partials");
   return DRIN_OK;
+}
+
+int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
+                              int64_t rows, int D, hipStream_t st) {
+  return launch_layernorm_gelu_bwd2(h, mean, rstd, g, rows, nullptr, nullptr, nullptr, nullptr, 0, gamma, beta, dgamma, dbeta,
+                                    dbias, partial, D, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,6 +356,66 @@ __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, flo
     atomicAdd(out + c4 * 4 + 2, t.z);
     atomicAdd(out + c4 * 4 + 3, t.w);
   }
+}
+
+// up to 8 column sums in one launch (blockIdx.z = which): the bias gradients of one backward pass
+__global__ void __launch_bounds__(256) k_colsum_batch(const ColsumBatch b) {
+  __shared__ float4 comb[4][64];
+  const int seg = blockIdx.z;
+  const float* __restrict__ x = b.x[seg];
+  float* __restrict__ out = b.out[seg];
+  const int64_t rows = b.rows[seg];
+  const int C4 = b.c4[seg];
+  const int by = b.by[seg];
+  if ((int)blockIdx.y >= by || (int)blockIdx.x * 64 >= C4) return;   // uniform per block
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c4 = blockIdx.x * 64 + lane;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < C4) {
+    const int64_t step = (int64_t)by * 4;
+    const float* col = x + (int64_t)c4 * 4;
+    int64_t row = (int64_t)blockIdx.y * 4 + wave;
+    for (; row + 3 * step < rows; row += 4 * step) {  // four independent loads in flight per wave
+      const float4 v0 = ld4(col + row * (int64_t)C4 * 4), v1 = ld4(col + (row + step) * (int64_t)C4 * 4);
+      const float4 v2 = ld4(col + (row + 2 * step) * (int64_t)C4 * 4), v3 = ld4(col + (row + 3 * step) * (int64_t)C4 * 4);
+      acc = acc + ((v0 + v1) + (v2 + v3));
+    }
+    for (; row < rows; row += step) acc = acc + ld4(col + row * (int64_t)C4 * 4);
+  }
+  comb[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c4 < C4) {
+    const float4 t = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
+    atomicAdd(out + c4 * 4 + 0, t.x);
+    atomicAdd(out + c4 * 4 + 1, t.y);
+    atomicAdd(out + c4 * 4 + 2, t.z);
+    atomicAdd(out + c4 * 4 + 3, t.w);
+  }
+}
+
+int ColsumBatch::add(const float* src, float* dst, int64_t nrows, int C) {
+  if (nrows <= 0 || !dst) return DRIN_OK;
+  if (C % 4 || n >= 8) {
+    set_error("colsum: C=%d must be a multiple of 4 (and at most 8 sums per batch)", C);
+    return DRIN_E_SHAPE;
+  }
+  const int64_t want = cdiv(nrows, 4 * 16) < 256 ? cdiv(nrows, 4 * 16) : 256;
+  x[n] = src, out[n] = dst, rows[n] = nrows, c4[n] = C / 4, by[n] = (int)(want < 1 ? 1 : want);
+  ++n;
+  return DRIN_OK;
+}
+
+int launch_colsum_batch(const ColsumBatch& b, hipStream_t st) {
+  if (b.n == 0) return DRIN_OK;
+  int gx = 1, gy = 1;
+  for (int i = 0; i < b.n; ++i) {
+    gx = gx > (int)cdiv(b.c4[i], 64) ? gx : (int)cdiv(b.c4[i], 64);
+    gy = gy > b.by[i] ? gy : b.by[i];
+  }
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_colsum_batch, dim3((unsigned)gx, (unsigned)gy, (unsigned)b.n), dim3(256), 0, st, b);
+  DRIN_CHECK_LAUNCH("k_colsum_batch");
+  return DRIN_OK;
 }
 
 int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st) {
@@ -518,6 +606,46 @@ __global__ void __launch_bounds__(256) k_entity_combine(const float* __restrict_
     if (r2 != nullptr) s = fma4(a2, ld4(r2 + c4 * 4), s);
     st4(o + c4 * 4, s * scale);
   }
+}
+
+// The scalar-edge update's backward in one pass over the pairs (model.py:148-153,133), one wave per pair:
+//   dpre_k[p] = g_k[p] e'_k[p] (1 - e'_k[p])                       k = tt, ti, it, ii      (written: the mention side reads it)
+//   dfv_t[p]  = (dpre_tt fu_t[b] + dpre_it fu_i[b]) / D            dfv_i[p] = (dpre_ti fu_t[b] + dpre_ii fu_i[b]) / D
+// g, e_new, dpre = [4][pairs]; fu = [2][B][D]; dfv = [2][pairs][D].
+__global__ void __launch_bounds__(256) k_edge_update_bwd(const float* __restrict__ g, const float* __restrict__ e_new,
+                                                         const float* __restrict__ fu, float* __restrict__ dpre,
+                                                         float* __restrict__ dfv, int64_t pairs, int B, int N, int D4,
+                                                         float scale) {
+  int64_t p, b;
+  if (!wave_pair(pairs, N, p, b)) return;
+  const int lane = threadIdx.x & 63;
+  float d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float e = e_new[k * pairs + p];
+    d[k] = g[k * pairs + p] * e * (1.0f - e);
+  }
+  if (lane < 4) dpre[(int64_t)lane * pairs + p] = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
+  const float* ft = fu + b * (int64_t)D4 * 4;
+  const float* fi = fu + ((int64_t)B + b) * (int64_t)D4 * 4;
+  float* ot = dfv + p * (int64_t)D4 * 4;
+  float* oi = dfv + (pairs + p) * (int64_t)D4 * 4;
+  for (int c4 = lane; c4 < D4; c4 += 64) {
+    const float4 t = ld4(ft + c4 * 4), i = ld4(fi + c4 * 4);
+    // (same association as k_entity_combine: (w1 m1) then fma(w2, m2, .), scaled last)
+    st4(ot + c4 * 4, fma4(d[2], i, t * d[0]) * scale);
+    st4(oi + c4 * 4, fma4(d[3], i, t * d[1]) * scale);
+  }
+}
+
+int launch_edge_update_bwd(const float* g, const float* e_new, const float* fu, float* dpre, float* dfv, int B, int N, int D,
+                           float scale, hipStream_t st) {
+  const int64_t pairs = (int64_t)B * N;
+  if (pairs <= 0 || D <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_edge_update_bwd, pair_grid(B, N), dim3(256), 0, st, g, e_new, fu, dpre, dfv, pairs, B, N, D / 4, scale);
+  DRIN_CHECK_LAUNCH("k_edge_update_bwd");
+  return DRIN_OK;
 }
 
 int launch_entity_combine(const float* w1, const float* m1, const float* w2, const float* m2, float* out, int B, int N,

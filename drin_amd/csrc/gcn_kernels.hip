@@ -217,12 +217,19 @@ int launch_entity_aggregate(const float* e1, const float* m1, const float* e2, c
 // One wave per row, the row held in registers (up to 4 float4 per lane: D <= 1024); y may alias h.
 constexpr int LN_MAXV = 4;
 
+// (a second row segment h2 / y2 / ... of rows2 rows may follow the first: the mention and the entity vertices of a layer
+//  share the LayerNorm, model.py:128 - one launch for both)
 __global__ void __launch_bounds__(256) k_layernorm_gelu(const float* h, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* y,
                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                        int64_t rows, int D4, float eps) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+                                                        int64_t rows, int D4, float eps, const float* h2, float* y2,
+                                                        float* __restrict__ mean2, float* __restrict__ rstd2, int64_t rows2) {
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows + rows2) return;
+  if (row >= rows) {
+    row -= rows;
+    h = h2, y = y2, mean_out = mean2, rstd_out = rstd2;
+  }
   const int lane = threadIdx.x & 63;
   const float* hr = h + row * (int64_t)D4 * 4;
   float4 x[LN_MAXV];
@@ -275,7 +282,22 @@ int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta,
   }
   KernelTimer timer(DRIN_KC_GCN, st);
   hipLaunchKernelGGL(k_layernorm_gelu, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, h, gamma, beta, y, mean, rstd,
-                     rows, D / 4, eps);
+                     rows, D / 4, eps, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0);
+  DRIN_CHECK_LAUNCH("k_layernorm_gelu");
+  return DRIN_OK;
+}
+
+int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, int64_t rows, const float* h2, float* y2,
+                           float* mean2, float* rstd2, int64_t rows2, const float* gamma, const float* beta, int D, float eps,
+                           hipStream_t st) {
+  if (rows + rows2 <= 0) return DRIN_OK;
+  if (D % 4 || D > 256 * LN_MAXV) {
+    set_error("layernorm_gelu: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
+    return DRIN_E_SHAPE;
+  }
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_layernorm_gelu, dim3((unsigned)cdiv(rows + rows2, 4)), dim3(256), 0, st, h, gamma, beta, y, mean, rstd,
+                     rows, D / 4, eps, h2, y2, mean2, rstd2, rows2);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu");
   return DRIN_OK;
 }

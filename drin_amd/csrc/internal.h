@@ -74,8 +74,10 @@ int launch_entity_token_mean(const float* feat, const int64_t* mask, float* out,
 int launch_entity_token_mean_bf16(const void* feat, const int64_t* mask, float* out, int64_t pairs, int T, int D,
                                   hipStream_t st);
 // out[b*N + n] = scale * cos(x[b, :], y[(b*N + n) * y_stride : +D])
+// (sim1 / sim2 -> out1 / out2: optional [B*N] arrays divided by `div` in the same pass: the CLIP edges of model.py:203)
 int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
-                       float scale, hipStream_t st, const int64_t* y_index = nullptr);
+                       float scale, hipStream_t st, const int64_t* y_index = nullptr, const float* sim1 = nullptr,
+                       const float* sim2 = nullptr, float* out1 = nullptr, float* out2 = nullptr, float div = 1.0f);
 // model.py:84-92: weighted object-pair similarity
 int launch_miei(const float* mobj, const float* mscore, const float* eobj, const float* escore, float* out, int B,
                 int N, int Km, int Ke, int R, float cos_eps, float miei_eps, float scale, hipStream_t st,
@@ -140,6 +142,10 @@ int launch_layer_aggregate(const float* e, int64_t edge_stride, const float* vm,
 // model.py:128: y = gelu(layer_norm(h)) row-wise; optionally keeps mean / rstd for backward
 int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                           int64_t rows, int D, float eps, hipStream_t st);
+// two row segments (rows of h, then rows2 of h2) through the same LayerNorm in one launch
+int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, int64_t rows, const float* h2, float* y2,
+                           float* mean2, float* rstd2, int64_t rows2, const float* gamma, const float* beta, int D, float eps,
+                           hipStream_t st);
 // model.py:148-153 + :133: out[b,n] = sigmoid(mean_d(fu[b,:] fv[b,n,:]) + e[b,n])
 int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
                         hipStream_t st);
@@ -153,8 +159,27 @@ int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx,
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
                               int64_t rows, int D, hipStream_t st);
+// the same over two row segments that share gamma / beta and the column sums (mention + entity vertices of one layer)
+int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* rstd, float* g, int64_t rows, const float* h2,
+                               const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
+                               const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
+                               hipStream_t st);
 // out[c] += sum_rows x[row, c]
 int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st);
+// up to 8 such column sums in ONE launch
+struct ColsumBatch {
+  const float* x[8];
+  float* out[8];
+  int64_t rows[8];
+  int c4[8];
+  int by[8];
+  int n = 0;
+  int add(const float* src, float* dst, int64_t nrows, int C);   // no-op for dst == NULL or nrows <= 0
+};
+int launch_colsum_batch(const ColsumBatch& b, hipStream_t st);
+// sigmoid backward of the scalar edge update + both entity-side gradients dfv_t, dfv_i in one pass (see the kernel)
+int launch_edge_update_bwd(const float* g, const float* e_new, const float* fu, float* dpre, float* dfv, int B, int N, int D,
+                           float scale, hipStream_t st);
 // dpre = g * e' * (1 - e')
 int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st);
 // out[b,:] = scale (sum_n w1 v1 + sum_n w2 v2) + u      (v2, u optional)

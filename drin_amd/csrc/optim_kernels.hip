@@ -12,30 +12,31 @@
 //     denom        = denom + eps                                    _foreach_add_
 //     param        = param + (-lr / bias_correction1) (exp_avg / denom)   _foreach_addcdiv_  a + s (t1 / t2)
 // The scalars are formed on the host in double precision exactly as torch/optim/adam.py does and rounded to fp32 at the
-// call, as the foreach kernels' `scalar.to<opmath_t>()` does.  `arith` selects, per fused-looking expression (a + s x),
-// whether it is evaluated as one fma or as a rounded product followed by a rounded sum - whatever the compiler made of
-// torch's functors; tests/test_gpu_parity.py::test_library_adam_matches_torch_adam_bitwise pins the default against
-// torch.optim.Adam on the GPU.
+// call, as the foreach kernels' `scalar.to<opmath_t>()` does.  Which roundings torch's kernels make on this GPU was
+// measured (tools/adam_diag.py against float64 emulations rounded once): every `a + s x` above is ONE fma, sqrt and both
+// divisions are correctly rounded.  tests/test_gpu_round2.py::test_library_adam_matches_torch_adam_bitwise pins it.
+// (HIP's __fsqrt_rn / __fdiv_rn are NOT the rounded operations unless OCML_BASIC_ROUNDED_OPERATIONS is defined -
+// __fsqrt_rn is the native approximation - so the kernel uses sqrtf and '/', which hipcc compiles correctly rounded by
+// default, with contraction switched off so that exactly the three fmas written below are fused.)
 #include "internal.h"
 
 namespace drin {
 
-template <int ARITH>
 __device__ __forceinline__ void adam_one(float& p, const float g, float& m, float& v, const float w1, const float beta2,
                                          const float w2, const float bc2_sqrt, const float eps, const float neg_step) {
-  const float diff = __fsub_rn(g, m);
-  m = (ARITH & 1) ? __fmaf_rn(w1, diff, m) : __fadd_rn(m, __fmul_rn(w1, diff));
-  v = __fmul_rn(v, beta2);
-  const float gg = __fmul_rn(g, g);
-  v = (ARITH & 2) ? __fmaf_rn(w2, gg, v) : __fadd_rn(v, __fmul_rn(w2, gg));
-  float d = __fsqrt_rn(v);
-  d = __fdiv_rn(d, bc2_sqrt);
-  d = __fadd_rn(d, eps);
-  const float q = __fdiv_rn(m, d);
-  p = (ARITH & 4) ? __fmaf_rn(neg_step, q, p) : __fadd_rn(p, __fmul_rn(neg_step, q));
+#pragma clang fp contract(off)
+  const float diff = g - m;
+  m = __builtin_fmaf(w1, diff, m);
+  v = v * beta2;
+  const float gg = g * g;
+  v = __builtin_fmaf(w2, gg, v);
+  float d = sqrtf(v);
+  d = d / bc2_sqrt;
+  d = d + eps;
+  const float q = m / d;
+  p = __builtin_fmaf(neg_step, q, p);
 }
 
-template <int ARITH>
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ param, const float* __restrict__ grad,
                                               float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, const int64_t n,
                                               const float w1, const float beta2, const float w2, const float bc2_sqrt,
@@ -47,10 +48,10 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ param, const f
     const float4 g = reinterpret_cast<const float4*>(grad)[i];
     float4 m = reinterpret_cast<float4*>(exp_avg)[i];
     float4 v = reinterpret_cast<float4*>(exp_avg_sq)[i];
-    adam_one<ARITH>(p.x, g.x, m.x, v.x, w1, beta2, w2, bc2_sqrt, eps, neg_step);
-    adam_one<ARITH>(p.y, g.y, m.y, v.y, w1, beta2, w2, bc2_sqrt, eps, neg_step);
-    adam_one<ARITH>(p.z, g.z, m.z, v.z, w1, beta2, w2, bc2_sqrt, eps, neg_step);
-    adam_one<ARITH>(p.w, g.w, m.w, v.w, w1, beta2, w2, bc2_sqrt, eps, neg_step);
+    adam_one(p.x, g.x, m.x, v.x, w1, beta2, w2, bc2_sqrt, eps, neg_step);
+    adam_one(p.y, g.y, m.y, v.y, w1, beta2, w2, bc2_sqrt, eps, neg_step);
+    adam_one(p.z, g.z, m.z, v.z, w1, beta2, w2, bc2_sqrt, eps, neg_step);
+    adam_one(p.w, g.w, m.w, v.w, w1, beta2, w2, bc2_sqrt, eps, neg_step);
     reinterpret_cast<float4*>(param)[i] = p;
     reinterpret_cast<float4*>(exp_avg)[i] = m;
     reinterpret_cast<float4*>(exp_avg_sq)[i] = v;
@@ -60,21 +61,20 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ param, const f
   if (blockIdx.x == 0 && tail + threadIdx.x < n) {
     const int64_t i = tail + threadIdx.x;
     float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
-    adam_one<ARITH>(p, grad[i], m, v, w1, beta2, w2, bc2_sqrt, eps, neg_step);
+    adam_one(p, grad[i], m, v, w1, beta2, w2, bc2_sqrt, eps, neg_step);
     param[i] = p;
     exp_avg[i] = m;
     exp_avg_sq[i] = v;
   }
 }
 
-template <int ARITH>
 static int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float w1, float beta2, float w2, float bc2s,
                        float eps, float neg_step, hipStream_t st) {
   const int64_t n4 = n >> 2;
   int64_t blocks = cdiv(n4 > 0 ? n4 : 1, 256);
   if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride beyond
   KernelTimer timer(DRIN_KC_OPTIM, st);
-  hipLaunchKernelGGL(k_adam<ARITH>, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, w1, beta2, w2, bc2s, eps, neg_step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, w1, beta2, w2, bc2s, eps, neg_step);
   DRIN_CHECK_LAUNCH("k_adam");
   return DRIN_OK;
 }
@@ -85,7 +85,7 @@ using namespace drin;
 
 extern "C" int drin_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lerp_weight,
                               float beta2, float one_minus_beta2, float bias_correction2_sqrt, float eps, float neg_step_size,
-                              int32_t arith, void* stream) {
+                              void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq) {
     set_error("drin_adam_step: NULL operand");
     return DRIN_E_NULL;
@@ -104,23 +104,6 @@ extern "C" int drin_adam_step(float* param, const float* grad, float* exp_avg, f
     set_error("drin_adam_step: 1 - beta1 = %g outside (-0.5, 0.5) is not built", (double)lerp_weight);
     return DRIN_E_UNSUPPORTED;
   }
-  hipStream_t st = (hipStream_t)stream;
-  if (arith == DRIN_ADAM_ARITH_DEFAULT) arith = DRIN_ADAM_ARITH_TORCH;
-  switch (arith) {
-#define DRIN_ADAM_CASE(A) \
-  case A:                 \
-    return launch_adam<A>(param, grad, exp_avg, exp_avg_sq, n, lerp_weight, beta2, one_minus_beta2, bias_correction2_sqrt, eps, neg_step_size, st);
-    DRIN_ADAM_CASE(0)
-    DRIN_ADAM_CASE(1)
-    DRIN_ADAM_CASE(2)
-    DRIN_ADAM_CASE(3)
-    DRIN_ADAM_CASE(4)
-    DRIN_ADAM_CASE(5)
-    DRIN_ADAM_CASE(6)
-    DRIN_ADAM_CASE(7)
-#undef DRIN_ADAM_CASE
-    default:
-      set_error("drin_adam_step: arith=%d outside [-1, 7]", arith);
-      return DRIN_E_SHAPE;
-  }
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, n, lerp_weight, beta2, one_minus_beta2, bias_correction2_sqrt, eps,
+                     neg_step_size, (hipStream_t)stream);
 }

@@ -177,10 +177,15 @@ int launch_entity_token_mean_bf16(const void* feat, const int64_t* mask, float* 
 // y = entity pooler vector or token 0 of the token block) and for the final score (model.py:207-209).
 __global__ void __launch_bounds__(256) k_cosine_rows(const float* __restrict__ x, const float* __restrict__ y,
                                                      int64_t y_stride, float* __restrict__ out, int64_t pairs, int N,
-                                                     int D4, float eps, float scale, const int64_t* __restrict__ y_index) {
+                                                     int D4, float eps, float scale, const int64_t* __restrict__ y_index,
+                                                     const float* __restrict__ sim1, const float* __restrict__ sim2,
+                                                     float* __restrict__ out1, float* __restrict__ out2, float div) {
   int64_t p, b;
   if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
+  // the two CLIP edges of model.py:203 ride along (ti = mtei / 100, it = miet / 100: true divisions)
+  if (sim1 != nullptr && lane == 1) out1[p] = sim1[p] / div;
+  if (sim2 != nullptr && lane == 2) out2[p] = sim2[p] / div;
   const float* xr = x + b * (int64_t)D4 * 4;
   const float* yr = y + (y_index != nullptr ? y_index[p] : p) * y_stride;  // y_index: y is a table, pair p reads row y_index[p]
   float xy = 0.f, xx = 0.f, yy = 0.f;
@@ -197,7 +202,8 @@ __global__ void __launch_bounds__(256) k_cosine_rows(const float* __restrict__ x
 }
 
 int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* out, int B, int N, int D, float eps,
-                       float scale, hipStream_t st, const int64_t* y_index) {
+                       float scale, hipStream_t st, const int64_t* y_index, const float* sim1, const float* sim2,
+                       float* out1, float* out2, float div) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   if (D % 4 != 0 || y_stride % 4 != 0) {
@@ -206,7 +212,7 @@ int launch_cosine_rows(const float* x, const float* y, int64_t y_stride, float* 
   }
   KernelTimer timer(DRIN_KC_EDGE, st);
   hipLaunchKernelGGL(k_cosine_rows, pair_grid(B, N), dim3(256), 0, st, x, y, y_stride, out, pairs, N,
-                     D / 4, eps, scale, y_index);
+                     D / 4, eps, scale, y_index, sim1, sim2, out1, out2, div);
   DRIN_CHECK_LAUNCH("k_cosine_rows");
   return DRIN_OK;
 }

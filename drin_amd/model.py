@@ -377,6 +377,7 @@ class _Prepared:
     def __init__(self):
         self.key = None
         self.buf: Optional[torch.Tensor] = None
+        self.generation = 0          # bumped by every rebuild: what caches derived from the folds are keyed on
 
     def invalidate(self) -> None:
         self.key = None
@@ -390,6 +391,7 @@ class _Prepared:
             stream = torch.cuda.current_stream(call.device).cuda_stream
             _lib.check(lib.drin_prepare(C.byref(call.cfg), C.byref(pc), self.buf.data_ptr(), n, stream))
             self.key = key
+            self.generation += 1
         return self.buf
 
 
@@ -604,7 +606,7 @@ class Model(nn.Module):
                     if t.cache_enabled:                                # per-entity precompute cache
                         return self._forward_cached(call, t, params)
                     if planes:
-                        return self._apply(call, self._prepared, False, *params)
+                        return self._score(call, self._prepared, False, *params)
             if not inference and t.text.dim() == 3:
                 # training on a token-level table: every entity's tokens pooled once; the step then reads the pooled /
                 # token-0 / image / object tables through the candidate index inside the kernels, or gathers those rows
@@ -612,7 +614,7 @@ class Model(nn.Module):
                 if call is not None:
                     if call.B == 0:
                         return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-                    return self._apply(call, None, True, *params)
+                    return self._score(call, None, True, *params)
                 batch, cls = batch.gathered_pooled(self.cfg)
             else:
                 batch = batch.gathered()
@@ -638,16 +640,16 @@ class Model(nn.Module):
             call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec, entity_text_cls=cls)
             if call.B == 0:
                 return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-            return self._apply(call, None, training, *params)
+            return self._score(call, None, training, *params)
         call = _Call(self.cfg, batch, prec, keep_bf16=in_place)
         if ((call.cfg.feature_dtype != _lib.FEAT_F32 or prec == _lib.PREC_BF16)
                 and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK):
             call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec)
         if call.B == 0:
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-        return self._apply(call, self._prepared, training, *params)
+        return self._score(call, self._prepared, training, *params)
 
-    def _apply(self, call: _Call, prepared, training: bool, *params):
+    def _score(self, call: _Call, prepared, training: bool, *params):
         call.owner = self
         return _DrinScore.apply(call, prepared, training, *params)
 
@@ -680,7 +682,7 @@ class Model(nn.Module):
         pc = _lib.DrinParamsC()
         _fill_params(pc, det, call.per_layer)
         pbuf = self._prepared.get(call, params, pc)
-        cache = table._get_cache(call, self._prepared.key, pc, pbuf)
+        cache = table._get_cache(call, (id(self._prepared), self._prepared.generation), pc, pbuf)
         n = lib.drin_cached_workspace_bytes(C.byref(call.cfg))
         ws = torch.empty(max(n, 16), dtype=torch.uint8, device=call.device)
         scores = torch.empty(call.B, call.N, dtype=torch.float32, device=call.device)

@@ -107,10 +107,8 @@ class LibraryAdam:
     with it follows the reference's loop bit for bit (`tests/test_gpu_parity.py::test_library_adam_matches_torch_adam_bitwise`).
     Like torch's Adam it skips parameters whose `.grad` is None and creates its zero moments at the first step."""
 
-    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, arith: Optional[int] = None):
-        from . import _lib
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         self.model, self.lr, self.betas, self.eps = model, float(lr), (float(betas[0]), float(betas[1])), float(eps)
-        self.arith = _lib.ADAM_ARITH_DEFAULT if arith is None else arith
         self.t = 0
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
@@ -152,9 +150,13 @@ class LibraryAdam:
 
         def launch(p_ptr, g_ptr, off, n):
             _lib.check(lib.drin_adam_step(p_ptr, g_ptr, self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off,
-                                          n, *(C.c_float(x) for x in scal), self.arith, stream))
+                                          n, *(C.c_float(x) for x in scal), stream))
 
         params = _param_list(model)
+        # the kernel writes the parameters behind PyTorch's back: bump their version counters (no launch), so that everything
+        # keyed on them - the folded weights of the fused inference path, the per-entity cache, autograd's saved-tensor
+        # checks - sees the update exactly as it sees torch.optim.Adam's
+        torch.autograd.graph.increment_version(params)
         with_grad = [i for i, p in enumerate(params) if p.grad is not None]
         gflat = model.grad_bucket()
         live_set = [i for i, o in enumerate(offsets) if o < live]

@@ -294,13 +294,11 @@ DRIN_API int drin_triplet_topk(const float* scores, const uint8_t* answer, int32
  * double precision as torch/optim/adam.py forms them for step t (1-based) and rounded to fp32 here:
  *   lerp_weight = 1 - beta1;  one_minus_beta2 = 1 - beta2;  bias_correction2_sqrt = (1 - beta2^t)^0.5;
  *   neg_step_size = -(lr / (1 - beta1^t)).
- * `arith`: DRIN_ADAM_ARITH_DEFAULT, or a 3-bit mask choosing fma (bit set) or product-then-sum for the lerp (1), the
- * addcmul (2) and the addcdiv (4) - only the parity test passes anything but the default. */
-#define DRIN_ADAM_ARITH_DEFAULT (-1)
-#define DRIN_ADAM_ARITH_TORCH 7
+ * Every `a + s x` of that sequence is one fma, sqrt and the divisions are correctly rounded - what torch's kernels do on
+ * this GPU (tools/adam_diag.py). */
 DRIN_API int drin_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                             float lerp_weight, float beta2, float one_minus_beta2, float bias_correction2_sqrt, float eps,
-                            float neg_step_size, int32_t arith, void* stream);
+                            float neg_step_size, void* stream);
 
 /* ---- in-process kernel timing (bench.py's roofline leg) ---------------------------------------- */
 

@@ -22,13 +22,13 @@ def _to_dev(batch):
 
 
 # ---- one-launch Adam (train.py:55-56) ---------------------------------------------------------------------------------
-def _adam_call(p, g, m, v, t, lr, arith):
+def _adam_call(p, g, m, v, t, lr):
     lib = _lib.load()
     b1, b2, eps = 0.9, 0.999, 1e-8
     bc1, bc2 = 1 - b1 ** float(t), 1 - b2 ** float(t)
     scal = (1 - b1, b2, 1 - b2, bc2 ** 0.5, eps, (lr / bc1) * -1)
     _lib.check(lib.drin_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), *(C.c_float(x) for x in scal),
-                                  arith, torch.cuda.current_stream().cuda_stream))
+                                  torch.cuda.current_stream().cuda_stream))
 
 
 def test_library_adam_matches_torch_adam_bitwise():
@@ -40,29 +40,15 @@ def test_library_adam_matches_torch_adam_bitwise():
     grads = [torch.randn(n, device=DEV, generator=g) * torch.logspace(-8, 1, n, device=DEV).flip(0) for _ in range(6)]
     ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([ref], lr=1e-3)
-    mine = {a: (p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)) for a in range(8)}
-    matches = set(range(8))
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     for t, gr in enumerate(grads, 1):
         ref.grad = gr.clone()
         opt.step()
-        for a in list(matches):
-            p, m, v = mine[a]
-            _adam_call(p, gr, m, v, t, 1e-3, a)
-            st = opt.state[ref]
-            if not (torch.equal(p, ref.data) and torch.equal(m, st["exp_avg"]) and torch.equal(v, st["exp_avg_sq"])):
-                matches.discard(a)
-    print("arith variants bit-identical to torch.optim.Adam:", sorted(matches))
-    lib = _lib.load()
-    # the library default must be one of them
-    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    ref2 = torch.nn.Parameter(p0.clone())
-    opt2 = torch.optim.Adam([ref2], lr=1e-3)
-    for t, gr in enumerate(grads, 1):
-        ref2.grad = gr.clone()
-        opt2.step()
-        _adam_call(p, gr, m, v, t, 1e-3, _lib.ADAM_ARITH_DEFAULT)
-    assert torch.equal(p, ref2.data), f"default arithmetic differs from torch.optim.Adam; bit-identical variants: {sorted(matches)}"
-    assert lib.drin_adam_step(None, None, None, None, 4, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, -1, None) == _lib.E_NULL
+        _adam_call(p, gr, m, v, t, 1e-3)
+        st = opt.state[ref]
+        for name, mine, theirs in (("exp_avg", m, st["exp_avg"]), ("exp_avg_sq", v, st["exp_avg_sq"]), ("param", p, ref.data)):
+            assert torch.equal(mine, theirs), f"step {t}: {name} differs in {int((mine != theirs).sum())} of {n} elements"
+    assert _lib.load().drin_adam_step(None, None, None, None, 4, 0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, None) == _lib.E_NULL
 
 
 def _train_setup(cfg, B, seed=31, precision="bf16x3", **kw):
@@ -144,14 +130,17 @@ def test_data_parallel_step_through_the_hip_model_equals_the_full_batch():
     assert {k for k, p in model.named_parameters() if p.grad is None} == {f"gcn_layers.1.w_{x}.{y}" for x in "uv" for y in ("weight", "bias")}
     opt = make_adam(model, 1e-3)
     assert isinstance(opt, LibraryAdam)
-    opt.step()
-    assert opt.one_launch_steps == 1
+    # torch.optim.Adam on the SAME averaged gradients (a near-zero gradient entry moves by +-lr on the sign of its last bit,
+    # so the two models' own gradients - equal to 2e-5 - would not do): bit-identical parameters
     topt = torch.optim.Adam(ref.parameters(), lr=1e-3)
-    for k, p in ref.named_parameters():
-        p.grad = mean.get(k)
+    for (k, p), (_, q) in zip(ref.named_parameters(), model.named_parameters()):
+        p.grad = None if q.grad is None else q.grad.clone()
     topt.step()
+    version = model.gcn_layers[0].w_h.weight._version
+    opt.step()
+    assert opt.one_launch_steps == 1 and model.gcn_layers[0].w_h.weight._version > version
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        assert torch.allclose(p, q, rtol=0, atol=2e-6), k            # first Adam step: +-lr, sign of the gradient
+        assert torch.equal(p, q), k
     # the parameters now live in one flat bucket too; state_dict / load_state_dict are unaffected
     flat = model.flatten_parameters()
     assert all(p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in model.parameters())
@@ -210,7 +199,8 @@ def test_large_batches_are_split_into_calls():
         out = model(batch)
         assert out.shape == (B, 4) and torch.isfinite(out).all()
         for rows in (slice(0, 5), slice(32766, 32771), slice(B - 3, B)):    # mention independence: any slice alone
-            assert torch.equal(out[rows], model([t[rows] for t in batch]))
+            # (a handful of mentions takes other tile shapes / K-splits than 32 768: equal to fp32 re-association)
+            assert (out[rows] - model([t[rows] for t in batch])).abs().max().item() <= 5e-6
         ref = O.forward(sd, [t[32760:32776].cpu() for t in batch])
         assert (out[32760:32776].cpu() - ref).abs().max().item() <= 1e-5
         # table form splits too
@@ -220,7 +210,9 @@ def test_large_batches_are_split_into_calls():
         ib = IndexedBatch(batch[:7], table, cand, batch[12], batch[13])
         big = model(ib)
         sub = IndexedBatch([t[40000:40004] for t in batch[:7]], table, cand[40000:40004], batch[12][40000:40004], batch[13][40000:40004])
-        assert torch.equal(big[40000:40004], model(sub))
+        assert (big[40000:40004] - model(sub)).abs().max().item() <= 5e-6
+        ref = O.forward(sd, [t.cpu() for t in sub.gathered()])
+        assert (big[40000:40004].cpu() - ref).abs().max().item() <= 1e-5
 
 
 # ---- BASELINE config 5 at full width (only ever tested at D = 64) -------------------------------------------
@@ -294,7 +286,7 @@ def test_table_edits_and_data_writes_are_seen_or_can_be_declared():
         assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5
         table.image.mul_(-0.5)                                        # in-place torch op on the IMAGE table: seen
         assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5
-        table.object_score.data.fill_(0.25)                           # a .data write: invisible ...
+        table.object.data.neg_()                                      # a .data write: invisible ...
         stale = (model(ib).cpu() - oracle()).abs().max().item()
         table.invalidate()                                            # ... until declared
         assert (model(ib).cpu() - oracle()).abs().max().item() <= 1e-5 < stale

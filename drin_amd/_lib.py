@@ -19,6 +19,7 @@ ABI_VERSION = 2
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
 FEAT_F32, FEAT_BF16 = 0, 1
+ACTIVATIONS = {"gelu": 1, "sigmoid": 2, "relu": 3, "tanh": 4, "silu": 5}   # drin_activation
 
 fp = C.POINTER(C.c_float)
 ip = C.POINTER(C.c_int64)
@@ -33,6 +34,7 @@ class DrinConfigC(C.Structure):
         ("dynamic_edges", C.c_int32), ("edge_enabled", C.c_float * 4), ("layer_norm_eps", C.c_float),
         ("cosine_eps", C.c_float), ("miei_eps", C.c_float), ("clip_scale", C.c_float), ("precision", C.c_int32),
         ("num_entities", C.c_int32), ("vector_edges", C.c_int32), ("feature_dtype", C.c_int32),
+        ("vertex_activation", C.c_int32), ("edge_activation", C.c_int32),
     ]
 
 

@@ -69,8 +69,12 @@ class DrinConfig:
             raise ValueError(f"unknown gcn_edge_feature {self.gcn_edge_feature!r} (reference spelling: 'scaler' | 'vector')")
         if self.gcn_edge_feature == "vector" and self.gcn_embed_dim % 8:
             raise ValueError("vector edges split gcn_embed_dim in two halves of 16-byte rows: it must be a multiple of 8")
-        if self.gcn_vertex_activation != "gelu" or self.gcn_edge_activation != "sigmoid":
-            raise NotImplementedError("only gelu vertex / sigmoid edge activations (args.py:35-36) are built")
+        # the reference takes getattr(torch.nn.functional, name) (model.py:117-118): any name.  Built: see include/drin_hip.h
+        if self.gcn_vertex_activation not in ("gelu", "relu", "tanh", "silu", "sigmoid"):
+            raise NotImplementedError(f"gcn_vertex_activation {self.gcn_vertex_activation!r}: built are gelu, relu, tanh, silu, sigmoid")
+        if self.gcn_edge_activation not in ("sigmoid", "tanh", "relu"):
+            raise NotImplementedError(f"gcn_edge_activation {self.gcn_edge_activation!r}: built are sigmoid, tanh, relu "
+                                      "(the backward takes the derivative from the stored edge value)")
         if self.gcn_embed_dim != self.bert_embed_dim:
             raise ValueError("gcn_embed_dim must equal bert_embed_dim (args.py:38-39 force the output dims)")
         if len(self.gcn_edge_enabled) != 4:

@@ -71,6 +71,9 @@ static void profile_free(Profile& p) {
   p.open.store(false);
 }
 
+int vertex_act(const drin_config* c) { return c->vertex_activation == DRIN_ACT_DEFAULT ? DRIN_ACT_GELU : c->vertex_activation; }
+int edge_act(const drin_config* c) { return c->edge_activation == DRIN_ACT_DEFAULT ? DRIN_ACT_SIGMOID : c->edge_activation; }
+
 int validate_config(const drin_config* c) {
   if (!c) {
     set_error("config is NULL");
@@ -105,6 +108,16 @@ int validate_config(const drin_config* c) {
   }
   if (c->feature_dtype != DRIN_FEAT_F32 && c->feature_dtype != DRIN_FEAT_BF16) {
     set_error("config: feature_dtype %d is not DRIN_FEAT_F32 / DRIN_FEAT_BF16", c->feature_dtype);
+    return DRIN_E_UNSUPPORTED;
+  }
+  if (c->vertex_activation < DRIN_ACT_DEFAULT || c->vertex_activation > DRIN_ACT_SILU) {
+    set_error("config: vertex_activation %d is not a drin_activation", c->vertex_activation);
+    return DRIN_E_UNSUPPORTED;
+  }
+  if (c->edge_activation != DRIN_ACT_DEFAULT && c->edge_activation != DRIN_ACT_SIGMOID && c->edge_activation != DRIN_ACT_RELU &&
+      c->edge_activation != DRIN_ACT_TANH) {
+    set_error("config: edge_activation %d - built are sigmoid, tanh and relu (the backward takes the derivative from the stored "
+              "edge value, which gelu / silu do not offer)", c->edge_activation);
     return DRIN_E_UNSUPPORTED;
   }
   if (c->precision != DRIN_PREC_F32 && c->precision != DRIN_PREC_BF16X3 && c->precision != DRIN_PREC_BF16X3_ALL &&
@@ -486,6 +499,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   const int64_t M = (int64_t)B * N;
   const int nl = cfg->num_layers;
   const int prec = cfg->precision;
+  const int act_v = vertex_act(cfg), act_e = edge_act(cfg);
   if (B == 0) return DRIN_OK;
   // dead work of the last layer (its edge update and its image-vertex updates never reach the score,
   // SURVEY.md 3.2) is only computed when a trace asks to see it
@@ -586,7 +600,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     // one LayerNorm + GELU launch for the mention and the entity vertices (they share it, model.py:128)
     DRIN_TRY(launch_layernorm_gelu2(h_m, ws + L.vm[l + 1], st_m, st_m ? st_m + 2 * (size_t)B : nullptr, (int64_t)types * B, h_e,
                                     ws + L.ve[l + 1], st_e, st_e ? st_e + 2 * (size_t)M : nullptr, (int64_t)types * M,
-                                    W.ln_weight, W.ln_bias, D, cfg->layer_norm_eps, st));
+                                    W.ln_weight, W.ln_bias, D, cfg->layer_norm_eps, st, act_v));
     // dynamic edges, edge_graph of model.py:107: (mt,et) (mt,ei) (mi,et) (mi,ei)
     float* e_next = ws + L.edges[l + 1];
     if (live_edges && vec) {
@@ -599,13 +613,13 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, H, 2 * M, H, D, false, prec, st));
       DRIN_TRY(launch_edge_pre_vec(fu, fv, e, pre, B, N, D, st));
       DRIN_TRY(launch_gemm_nt(pre, D, W.w_m, D, W.b_m, e_next, D, 4 * M, D, D, false, prec, st));
-      DRIN_TRY(launch_sigmoid_inplace(e_next, 4 * M * D, st));
+      DRIN_TRY(launch_sigmoid_inplace(e_next, 4 * M * D, st, act_e));
     } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
       DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, msk, mskf));
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf));
-      DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st));
+      DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st, act_e));
     } else if (!cfg->dynamic_edges) {
       hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);
       if (err != hipSuccess) return hip_fail(err, "hipMemcpyAsync(static edges)");
@@ -712,6 +726,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   const size_t M = (size_t)B * N, BD = (size_t)B * D, MD = M * D;
   const int nl = cfg->num_layers;
   const int prec = cfg->precision;
+  const int act_v = vertex_act(cfg), act_e = edge_act(cfg);
   if (B == 0) return DRIN_OK;
   Pooled P;
   resolve_pooled(cfg, batch, L, ws, &P);
@@ -797,7 +812,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     // (mention and entity rows in one launch)
     DRIN_TRY(launch_layernorm_gelu_bwd2(ws + L.h_m[l], st_m, st_m + 2 * (size_t)B, gm, (int64_t)types * B, ws + L.h_e[l], st_e,
                                         st_e + 2 * M, ge, (int64_t)types * M, W.ln_weight, W.ln_bias, G.ln_weight, G.ln_bias,
-                                        G.b_h, ws + L.ln_part, D, st));
+                                        G.b_h, ws + L.ln_part, D, st, act_v));
     // (b) dW_h += dH^T A
     if (G.w_h) {
       DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st, tnp, tnf));
@@ -821,7 +836,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     if (edge_update && vec) {
       // (d, vector edges) e' = sigmoid(W_m(cat(W_u(u), W_v(v)) + e) + b_m)  (model.py:150-152,133)
       const int H = D / 2;
-      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st));         // dz
+      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st, act_e));  // dz
       if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st));
       DRIN_TRY(gemm_nn(dpre, D, W.w_m, g_e[cur], D, 4 * (int64_t)M, D, D, false));  // d(cat + e)
@@ -837,7 +852,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       const float* fv = ws + L.fv[l];
       const float inv_d = 1.0f / (float)D;
       // dpre = g e' (1 - e');  dfv_t = (dpre_tt fu_t + dpre_it fu_i) / D ; dfv_i = (dpre_ti fu_t + dpre_ii fu_i) / D: one pass
-      DRIN_TRY(launch_edge_update_bwd(g_e[cur], ws + L.edges[l + 1], fu, dpre, dfv, B, N, D, inv_d, st));
+      DRIN_TRY(launch_edge_update_bwd(g_e[cur], ws + L.edges[l + 1], fu, dpre, dfv, B, N, D, inv_d, st, act_e));
       // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
       if (B <= 65535) {
         DRIN_TRY(launch_mention_reduce2(dpre, fv, fv + MD, nullptr, nullptr, dfu, dfu + BD, B, N, D, inv_d, st));

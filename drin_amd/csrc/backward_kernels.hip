@@ -144,7 +144,7 @@ template <int V>
 __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const LnBwdSeg sa, const LnBwdSeg sb,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            float* __restrict__ partial, int D4) {
+                                                            float* __restrict__ partial, int D4, int act) {
   // rows of segment a, then rows of segment b (the mention vertices and the entity vertices of a layer share W_h and the
   // LayerNorm, model.py:128: one launch and one set of column sums for both)
   const int64_t rows = sa.rows + sb.rows;
@@ -192,10 +192,10 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const LnBwdSeg sa, c
       if (c4 < D4) {
         xh[j] = make_float4((hv[j].x - mu) * rs, (hv[j].y - mu) * rs, (hv[j].z - mu) * rs, (hv[j].w - mu) * rs);
         float4 dz;
-        dz.x = gv[j].x * gelu_erf_grad(xh[j].x * gm[j].x + bt[j].x);
-        dz.y = gv[j].y * gelu_erf_grad(xh[j].y * gm[j].y + bt[j].y);
-        dz.z = gv[j].z * gelu_erf_grad(xh[j].z * gm[j].z + bt[j].z);
-        dz.w = gv[j].w * gelu_erf_grad(xh[j].w * gm[j].w + bt[j].w);
+        dz.x = gv[j].x * act_grad(act, xh[j].x * gm[j].x + bt[j].x);
+        dz.y = gv[j].y * act_grad(act, xh[j].y * gm[j].y + bt[j].y);
+        dz.z = gv[j].z * act_grad(act, xh[j].z * gm[j].z + bt[j].z);
+        dz.w = gv[j].w * act_grad(act, xh[j].w * gm[j].w + bt[j].w);
         a_dg[j] = make_float4(fmaf(dz.x, xh[j].x, a_dg[j].x), fmaf(dz.y, xh[j].y, a_dg[j].y),
                               fmaf(dz.z, xh[j].z, a_dg[j].z), fmaf(dz.w, xh[j].w, a_dg[j].w));
         a_db[j] = a_db[j] + dz;
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
 int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* rstd, float* g, int64_t rows, const float* h2,
                                const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
                                const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
-                               hipStream_t st) {
+                               hipStream_t st, int act) {
   const int64_t total = rows + (h2 != nullptr ? rows2 : 0);
   if (total <= 0) return DRIN_OK;
   if (D % 4 || D > 256 * MAXV) {
@@ -307,7 +307,7 @@ int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* r
                                                                                          : k_layernorm_gelu_bwd<4>;
   const LnBwdSeg sa{h, mean, rstd, g, rows};
   const LnBwdSeg sb{h2, mean2, rstd2, g2, h2 != nullptr ? rows2 : 0};
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, sa, sb, gamma, beta, partial, D / 4);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, sa, sb, gamma, beta, partial, D / 4, act);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
   // partial: [kLnBwdMaxBlocks][3][D] block rows, then [kLnBwdMaxBlocks / 64][3][D] for the first reduction level
   float* level1 = partial + (int64_t)kLnBwdMaxBlocks * 3 * D;
@@ -323,9 +323,9 @@ int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* r
 
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
-                              int64_t rows, int D, hipStream_t st) {
+                              int64_t rows, int D, hipStream_t st, int act) {
   return launch_layernorm_gelu_bwd2(h, mean, rstd, g, rows, nullptr, nullptr, nullptr, nullptr, 0, gamma, beta, dgamma, dbeta,
-                                    dbias, partial, D, st);
+                                    dbias, partial, D, st, act);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,18 +435,17 @@ int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 // dpre[k][p] = g[k][p] * e'[k][p] * (1 - e'[k][p])     (sigmoid of model.py:133)
 __global__ void __launch_bounds__(256) k_sigmoid_bwd(const float* __restrict__ g, const float* __restrict__ e_new,
-                                                     float* __restrict__ dpre, int64_t n) {
+                                                     float* __restrict__ dpre, int64_t n, int act) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const float s = e_new[i];
-    dpre[i] = g[i] * s * (1.0f - s);
+    dpre[i] = g[i] * act_grad_from_output(act, e_new[i]);
   }
 }
 
-int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st) {
+int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st, int act) {
   if (n <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_sigmoid_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, g, e_new, dpre, n);
+  hipLaunchKernelGGL(k_sigmoid_bwd, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, g, e_new, dpre, n, act);
   DRIN_CHECK_LAUNCH("k_sigmoid_bwd");
   return DRIN_OK;
 }
@@ -609,13 +608,13 @@ __global__ void __launch_bounds__(256) k_entity_combine(const float* __restrict_
 }
 
 // The scalar-edge update's backward in one pass over the pairs (model.py:148-153,133), one wave per pair:
-//   dpre_k[p] = g_k[p] e'_k[p] (1 - e'_k[p])                       k = tt, ti, it, ii      (written: the mention side reads it)
+//   dpre_k[p] = g_k[p] act'(e'_k[p])      [sigmoid: e' (1 - e')]       k = tt, ti, it, ii      (written: the mention side reads it)
 //   dfv_t[p]  = (dpre_tt fu_t[b] + dpre_it fu_i[b]) / D            dfv_i[p] = (dpre_ti fu_t[b] + dpre_ii fu_i[b]) / D
 // g, e_new, dpre = [4][pairs]; fu = [2][B][D]; dfv = [2][pairs][D].
 __global__ void __launch_bounds__(256) k_edge_update_bwd(const float* __restrict__ g, const float* __restrict__ e_new,
                                                          const float* __restrict__ fu, float* __restrict__ dpre,
                                                          float* __restrict__ dfv, int64_t pairs, int B, int N, int D4,
-                                                         float scale) {
+                                                         float scale, int act) {
   int64_t p, b;
   if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
@@ -623,7 +622,7 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float e = e_new[k * pairs + p];
-    d[k] = g[k * pairs + p] * e * (1.0f - e);
+    d[k] = g[k * pairs + p] * act_grad_from_output(act, e);
   }
   if (lane < 4) dpre[(int64_t)lane * pairs + p] = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
   const float* ft = fu + b * (int64_t)D4 * 4;
@@ -639,11 +638,11 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd(const float* __restrict
 }
 
 int launch_edge_update_bwd(const float* g, const float* e_new, const float* fu, float* dpre, float* dfv, int B, int N, int D,
-                           float scale, hipStream_t st) {
+                           float scale, hipStream_t st, int act) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0 || D <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_edge_update_bwd, pair_grid(B, N), dim3(256), 0, st, g, e_new, fu, dpre, dfv, pairs, B, N, D / 4, scale);
+  hipLaunchKernelGGL(k_edge_update_bwd, pair_grid(B, N), dim3(256), 0, st, g, e_new, fu, dpre, dfv, pairs, B, N, D / 4, scale, act);
   DRIN_CHECK_LAUNCH("k_edge_update_bwd");
   return DRIN_OK;
 }

@@ -103,6 +103,36 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// gcn_vertex_activation / gcn_edge_activation by id (drin_activation, already resolved: never DRIN_ACT_DEFAULT).
+// The id is uniform over a launch, so the switch is a scalar branch.
+__device__ __forceinline__ float act_apply(int id, float x) {
+  switch (id) {
+    case 2: return sigmoidf(x);
+    case 3: return x < 0.f ? 0.f : x;            // F.relu; a NaN stays a NaN
+    case 4: return tanhf(x);
+    case 5: return x / (1.0f + expf(-x));        // F.silu = x sigmoid(x)
+    default: return gelu_erf(x);
+  }
+}
+// derivative at the pre-activation z (LayerNorm backward recomputes z)
+__device__ __forceinline__ float act_grad(int id, float z) {
+  switch (id) {
+    case 2: { const float s = sigmoidf(z); return s * (1.0f - s); }
+    case 3: return z > 0.f ? 1.0f : 0.f;
+    case 4: { const float t = tanhf(z); return 1.0f - t * t; }
+    case 5: { const float s = sigmoidf(z); return s * fmaf(z, 1.0f - s, 1.0f); }
+    default: return gelu_erf_grad(z);
+  }
+}
+// derivative from the OUTPUT y = act(z) (the edge update keeps e', not its pre-activation): sigmoid, tanh, relu only
+__device__ __forceinline__ float act_grad_from_output(int id, float y) {
+  switch (id) {
+    case 3: return y > 0.f ? 1.0f : 0.f;
+    case 4: return 1.0f - y * y;
+    default: return y * (1.0f - y);
+  }
+}
+
 // nn.CosineSimilarity as torch>=2 evaluates it: each norm clamped at eps separately.
 __device__ __forceinline__ float cosine_from_sums(float xy, float xx, float yy, float eps) {
   return xy / (fmaxf(sqrtf(xx), eps) * fmaxf(sqrtf(yy), eps));

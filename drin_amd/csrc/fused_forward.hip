@@ -94,6 +94,10 @@ int fused_supported(const drin_config* c) {
     set_error("fused path: built for num_layers == 2 (got %d); use drin_forward", c->num_layers);
     return DRIN_E_UNSUPPORTED;
   }
+  if (vertex_act(c) != DRIN_ACT_GELU || edge_act(c) != DRIN_ACT_SIGMOID) {
+    set_error("fused path: built for the reference's default activations (gelu / sigmoid, args.py:35-36); use drin_forward");
+    return DRIN_E_UNSUPPORTED;
+  }
   if (c->vector_edges) {
     set_error("fused path: vector edge features (model.py:112-116) run on the layer-by-layer path; use drin_forward");
     return DRIN_E_UNSUPPORTED;

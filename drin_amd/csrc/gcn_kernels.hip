@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu(const float* h, const fl
                                                         const float* __restrict__ beta, float* y,
                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                         int64_t rows, int D4, float eps, const float* h2, float* y2,
-                                                        float* __restrict__ mean2, float* __restrict__ rstd2, int64_t rows2) {
+                                                        float* __restrict__ mean2, float* __restrict__ rstd2, int64_t rows2,
+                                                        int act) {
   int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows + rows2) return;
   if (row >= rows) {
@@ -260,10 +261,10 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu(const float* h, const fl
     if (c4 < D4) {
       const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
       float4 r;
-      r.x = gelu_erf((x[j].x - mu) * rstd * g.x + bt.x);
-      r.y = gelu_erf((x[j].y - mu) * rstd * g.y + bt.y);
-      r.z = gelu_erf((x[j].z - mu) * rstd * g.z + bt.z);
-      r.w = gelu_erf((x[j].w - mu) * rstd * g.w + bt.w);
+      r.x = act_apply(act, (x[j].x - mu) * rstd * g.x + bt.x);
+      r.y = act_apply(act, (x[j].y - mu) * rstd * g.y + bt.y);
+      r.z = act_apply(act, (x[j].z - mu) * rstd * g.z + bt.z);
+      r.w = act_apply(act, (x[j].w - mu) * rstd * g.w + bt.w);
       st4(yr + c4 * 4, r);
     }
   }
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu(const float* h, const fl
 }
 
 int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                          int64_t rows, int D, float eps, hipStream_t st) {
+                          int64_t rows, int D, float eps, hipStream_t st, int act) {
   if (rows <= 0) return DRIN_OK;
   if (D % 4 || D > 256 * LN_MAXV) {
     set_error("layernorm_gelu: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
@@ -282,14 +283,14 @@ int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta,
   }
   KernelTimer timer(DRIN_KC_GCN, st);
   hipLaunchKernelGGL(k_layernorm_gelu, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, h, gamma, beta, y, mean, rstd,
-                     rows, D / 4, eps, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0);
+                     rows, D / 4, eps, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0, act);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu");
   return DRIN_OK;
 }
 
 int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, int64_t rows, const float* h2, float* y2,
                            float* mean2, float* rstd2, int64_t rows2, const float* gamma, const float* beta, int D, float eps,
-                           hipStream_t st) {
+                           hipStream_t st, int act) {
   if (rows + rows2 <= 0) return DRIN_OK;
   if (D % 4 || D > 256 * LN_MAXV) {
     set_error("layernorm_gelu: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXV);
@@ -297,7 +298,7 @@ int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, i
   }
   KernelTimer timer(DRIN_KC_GCN, st);
   hipLaunchKernelGGL(k_layernorm_gelu, dim3((unsigned)cdiv(rows + rows2, 4)), dim3(256), 0, st, h, gamma, beta, y, mean, rstd,
-                     rows, D / 4, eps, h2, y2, mean2, rstd2, rows2);
+                     rows, D / 4, eps, h2, y2, mean2, rstd2, rows2, act);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu");
   return DRIN_OK;
 }
@@ -310,7 +311,7 @@ int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, i
 // order is fixed, so the results do not depend on the launch geometry.
 __global__ void __launch_bounds__(256) k_edge_update4(const float* __restrict__ fu, const float* __restrict__ fv,
                                                       const float* __restrict__ e, float* __restrict__ out,
-                                                      int64_t pairs, int B, int N, int D4) {
+                                                      int64_t pairs, int B, int N, int D4, int act) {
   int64_t p, b;
   if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
@@ -333,15 +334,15 @@ __global__ void __launch_bounds__(256) k_edge_update4(const float* __restrict__ 
   s_ii = wave_sum(s_ii);
   if (lane == 0) {
     const float d = (float)(D4 * 4);
-    out[p] = sigmoidf(s_tt / d + e[p]);
-    out[pairs + p] = sigmoidf(s_ti / d + e[pairs + p]);
-    out[2 * pairs + p] = sigmoidf(s_it / d + e[2 * pairs + p]);
-    out[3 * pairs + p] = sigmoidf(s_ii / d + e[3 * pairs + p]);
+    out[p] = act_apply(act, s_tt / d + e[p]);
+    out[pairs + p] = act_apply(act, s_ti / d + e[pairs + p]);
+    out[2 * pairs + p] = act_apply(act, s_it / d + e[2 * pairs + p]);
+    out[3 * pairs + p] = act_apply(act, s_ii / d + e[3 * pairs + p]);
   }
 }
 
 int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
-                        hipStream_t st) {
+                        hipStream_t st, int act) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   if (D % 4) {
@@ -349,7 +350,7 @@ int launch_edge_update4(const float* fu, const float* fv, const float* e, float*
     return DRIN_E_SHAPE;
   }
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_edge_update4, pair_grid(B, N), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4);
+  hipLaunchKernelGGL(k_edge_update4, pair_grid(B, N), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4, act);
   DRIN_CHECK_LAUNCH("k_edge_update4");
   return DRIN_OK;
 }

@@ -140,15 +140,16 @@ int launch_entity_aggregate(const float* e1, const float* m1, const float* e2, c
 int launch_layer_aggregate(const float* e, int64_t edge_stride, const float* vm, const float* ve, float* agg_m,
                            float* agg_e, int B, int N, int D, bool live_image, hipStream_t st);
 // model.py:128: y = gelu(layer_norm(h)) row-wise; optionally keeps mean / rstd for backward
+// (act: drin_activation of the vertices, resolved - DRIN_ACT_GELU by default; the name keeps the reference's default)
 int launch_layernorm_gelu(const float* h, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                          int64_t rows, int D, float eps, hipStream_t st);
+                          int64_t rows, int D, float eps, hipStream_t st, int act = DRIN_ACT_GELU);
 // two row segments (rows of h, then rows2 of h2) through the same LayerNorm in one launch
 int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, int64_t rows, const float* h2, float* y2,
                            float* mean2, float* rstd2, int64_t rows2, const float* gamma, const float* beta, int D, float eps,
-                           hipStream_t st);
+                           hipStream_t st, int act = DRIN_ACT_GELU);
 // model.py:148-153 + :133: out[b,n] = sigmoid(mean_d(fu[b,:] fv[b,n,:]) + e[b,n])
 int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
-                        hipStream_t st);
+                        hipStream_t st, int act = DRIN_ACT_SIGMOID);
 
 // ---- backward row kernels (backward_kernels.hip) ------------------------------------------------
 // d cos(x[b], y[p]) : dx [B, D], dy [B*N, D]; scratch3 holds 3 * B*N floats
@@ -158,12 +159,12 @@ int launch_cosine_bwd(const float* x, const float* y, const float* g, float* dx,
 // partial: (1024 + 16) * 3 * D floats of scratch for the per-block column sums
 int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
-                              int64_t rows, int D, hipStream_t st);
+                              int64_t rows, int D, hipStream_t st, int act = DRIN_ACT_GELU);
 // the same over two row segments that share gamma / beta and the column sums (mention + entity vertices of one layer)
 int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* rstd, float* g, int64_t rows, const float* h2,
                                const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
                                const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
-                               hipStream_t st);
+                               hipStream_t st, int act = DRIN_ACT_GELU);
 // out[c] += sum_rows x[row, c]
 int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st);
 // up to 8 such column sums in ONE launch
@@ -179,9 +180,9 @@ struct ColsumBatch {
 int launch_colsum_batch(const ColsumBatch& b, hipStream_t st);
 // sigmoid backward of the scalar edge update + both entity-side gradients dfv_t, dfv_i in one pass (see the kernel)
 int launch_edge_update_bwd(const float* g, const float* e_new, const float* fu, float* dpre, float* dfv, int B, int N, int D,
-                           float scale, hipStream_t st);
+                           float scale, hipStream_t st, int act = DRIN_ACT_SIGMOID);
 // dpre = g * e' * (1 - e')
-int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st);
+int launch_sigmoid_bwd(const float* g, const float* e_new, float* dpre, int64_t n, hipStream_t st, int act = DRIN_ACT_SIGMOID);
 // out[b,:] = scale (sum_n w1 v1 + sum_n w2 v2) + u      (v2, u optional)
 int launch_mention_reduce(const float* w1, const float* v1, const float* w2, const float* v2, const float* u,
                           float* out, int B, int N, int D, float scale, hipStream_t st);
@@ -205,7 +206,7 @@ int launch_entity_aggregate_vec(const float* e1, const float* m1, const float* e
                                 float* out, int B, int N, int D, hipStream_t st);
 int launch_edge_pre_vec(const float* fu, const float* fv, const float* e, float* pre, int B, int N, int D,
                         hipStream_t st);
-int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st);
+int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st, int act = DRIN_ACT_SIGMOID);
 int launch_edge_pre_vec_bwd(const float* dpre, float* dfu, float* dfv, int B, int N, int D, hipStream_t st);
 int launch_entity_side_bwd_vec(const float* dA_mt, const float* dA_mi, const float* dA_et, const float* dA_ei,
                                const float* mt, const float* mi, const float* et, const float* ei, const float* e,

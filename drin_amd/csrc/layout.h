@@ -127,6 +127,8 @@ struct Layout {
 };
 
 int validate_config(const drin_config* c);
+int vertex_act(const drin_config* c);   // drin_activation with DRIN_ACT_DEFAULT resolved (gelu)
+int edge_act(const drin_config* c);     // (sigmoid)
 void resolve_pooled(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out);
 int run_pooling(const drin_config* c, const drin_batch* b, const Layout& L, float* ws, Pooled* out, hipStream_t st);
 int run_static_edges(const drin_config* c, const drin_batch* b, const Pooled& P, float* edges, hipStream_t st);

@@ -354,6 +354,8 @@ class _Call:
         c.num_entities = etf.shape[0] if table else 0
         c.vector_edges = 1 if cfg.gcn_edge_feature == "vector" else 0
         c.feature_dtype = _lib.FEAT_BF16 if bf16 else _lib.FEAT_F32
+        c.vertex_activation = _lib.ACTIVATIONS[cfg.gcn_vertex_activation]
+        c.edge_activation = _lib.ACTIVATIONS[cfg.gcn_edge_activation]
         self.per_layer = 10 if c.vector_edges else 8
         self.cfg = c
         b = _lib.DrinBatchC()

@@ -87,7 +87,22 @@ typedef struct {
                                fp32 (a bf16 value is exact in fp32, so the result equals the reference forward on
                                the same features widened to fp32).  drin_forward_prepared only; the other paths
                                return DRIN_E_UNSUPPORTED (widen the features on the caller side). */
+  int32_t vertex_activation; /* drin_activation: gcn_vertex_activation (args.py:35; model.py:117,128), default gelu    */
+  int32_t edge_activation;   /* drin_activation: gcn_edge_activation   (args.py:36; model.py:118,133), default sigmoid */
 } drin_config;
+
+/* The reference resolves `getattr(torch.nn.functional, name)` (model.py:117-118) - any function name.  Built here: the
+ * five below for the vertices; sigmoid, tanh and relu for the edges (their backward needs the derivative from the stored
+ * OUTPUT; gelu / silu do not offer it).  Anything but the defaults runs on the layer-by-layer path (drin_forward /
+ * drin_backward); the folded inference entry points return DRIN_E_UNSUPPORTED for it. */
+typedef enum {
+  DRIN_ACT_DEFAULT = 0, /* gelu for vertex_activation, sigmoid for edge_activation (a zero-initialised config is the reference's) */
+  DRIN_ACT_GELU = 1,    /* exact-erf gelu (F.gelu default)                                              */
+  DRIN_ACT_SIGMOID = 2,
+  DRIN_ACT_RELU = 3,
+  DRIN_ACT_TANH = 4,
+  DRIN_ACT_SILU = 5
+} drin_activation;
 
 typedef enum {
   DRIN_FEAT_F32 = 0,

@@ -21,6 +21,13 @@ CASES = {
     "tiny_wd_vector": (DrinConfig(gcn_edge_feature="vector", **TINY), 3, 12, 8, True, True),
     "tiny_wm_vector_static": (DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6,
                                          gcn_edge_feature="vector", gcn_edge_type="static", **TINY), 2, 13, 8, True, True),
+    # activations by name (args.py:35-36; model.py:117-118 takes getattr(torch.nn.functional, name))
+    "tiny_wd_relu_tanh": (DrinConfig(gcn_vertex_activation="relu", gcn_edge_activation="tanh", **TINY), 3, 14, 8, True, True),
+    "tiny_wm_silu_relu": (DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6,
+                                     gcn_vertex_activation="silu", gcn_edge_activation="relu", **TINY), 3, 15, 8, True, True),
+    "tiny_wd_tanh_vector": (DrinConfig(gcn_vertex_activation="tanh", gcn_edge_activation="tanh", gcn_edge_feature="vector", **TINY),
+                            3, 16, 8, True, True),
+    "tiny_wd_sigmoid_vertex": (DrinConfig(gcn_vertex_activation="sigmoid", num_gcn_layers=3, **TINY), 2, 17, 8, True, True),
     "tiny_wm_n37": (DrinConfig(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=9, **TINY), 4, 9, 8, True, False),
 }
 

@@ -66,6 +66,8 @@ def _patch(cfg: DrinConfig) -> None:
         gcn_edge_type=cfg.gcn_edge_type,
         gcn_edge_feature=cfg.gcn_edge_feature,
         gcn_edge_enabled=list(cfg.gcn_edge_enabled),
+        gcn_vertex_activation=cfg.gcn_vertex_activation,
+        gcn_edge_activation=cfg.gcn_edge_activation,
         use_device="cpu",
     )
     for mod in (ref_args, ref_model, ref_ghmfc):

@@ -13,4 +13,5 @@ class OracleModel(Model):
         p = dict(self.named_parameters())
         cfg: DrinConfig = self.cfg
         return O.forward(p, batch, num_layers=cfg.num_gcn_layers, edge_enabled=cfg.gcn_edge_enabled,
-                         dynamic=cfg.gcn_edge_type == "dynamic", vector=cfg.gcn_edge_feature == "vector")
+                         dynamic=cfg.gcn_edge_type == "dynamic", vector=cfg.gcn_edge_feature == "vector",
+                         vertex_activation=cfg.gcn_vertex_activation, edge_activation=cfg.gcn_edge_activation)

@@ -781,7 +781,11 @@ def _random_geometry(seed):
               num_gcn_layers=pick([1, 2, 2, 2, 3]), gcn_edge_type=pick(["dynamic", "dynamic", "static"]),
               gcn_edge_feature=pick(["scaler", "scaler", "scaler", "vector"]),
               gcn_edge_enabled=tuple(float(x) for x in pick([(1, 1, 1, 1), (1, 1, 1, 1), (1, 0, 1, 1), (0, 1, 1, 0), (1, 1, 0, 1)])))
-    return DrinConfig(**kw), int(g.integers(1, 10))
+    B = int(g.integers(1, 10))
+    # activations by name (args.py:35-36): drawn last, so that the geometries of the earlier seeds stay what they were
+    kw["gcn_vertex_activation"] = pick(["gelu", "gelu", "gelu", "relu", "tanh", "silu", "sigmoid"])
+    kw["gcn_edge_activation"] = pick(["sigmoid", "sigmoid", "sigmoid", "tanh", "relu"])
+    return DrinConfig(**kw), B
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -793,8 +797,7 @@ def test_random_geometries_all_paths_vs_oracle(seed):
     cfg, B = _random_geometry(seed)
     sd = synth.make_state_dict(cfg, 100 + seed)
     batch = synth.make_batch(cfg, B, 200 + seed, min_tokens=3)
-    kw = dict(dynamic=cfg.gcn_edge_type == "dynamic", edge_enabled=cfg.gcn_edge_enabled, num_layers=cfg.num_gcn_layers,
-              vector=cfg.gcn_edge_feature == "vector")
+    kw = O.config_kwargs(cfg)
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = O.forward(p, batch, **kw)
     ref_loss = O.triplet_loss(batch[-1], ref, cfg.triplet_margin)

@@ -23,8 +23,7 @@ def test_forward_matches_reference(golden_dir, name):
     cfg, sd, batch = build_case(name)
     g = _load(golden_dir, name)
     trace = {}
-    scores = O.forward(sd, batch, num_layers=cfg.num_gcn_layers, edge_enabled=cfg.gcn_edge_enabled,
-                       dynamic=cfg.gcn_edge_type == "dynamic", trace=trace, vector=cfg.gcn_edge_feature == "vector")
+    scores = O.forward(sd, batch, trace=trace, **O.config_kwargs(cfg))
     assert scores.shape == (batch[0].shape[0], cfg.num_candidates_model)
     np.testing.assert_allclose(scores.numpy(), g["scores"], atol=ATOL, rtol=0)
     vec = cfg.gcn_edge_feature == "vector"
@@ -50,8 +49,7 @@ def test_backward_matches_reference(golden_dir, name):
     cfg, sd, batch = build_case(name)
     g = _load(golden_dir, name)
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    kw = dict(num_layers=cfg.num_gcn_layers, edge_enabled=cfg.gcn_edge_enabled, dynamic=cfg.gcn_edge_type == "dynamic",
-              vector=cfg.gcn_edge_feature == "vector")
+    kw = O.config_kwargs(cfg)
     scores = O.forward(p, batch, **kw)
     rng = np.random.Generator(np.random.Philox(key=[int(g["functional_weights_seed"]), 99]))
     w = torch.from_numpy(rng.standard_normal(size=tuple(scores.shape), dtype=np.float32))

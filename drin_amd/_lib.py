@@ -12,7 +12,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrin_hip.so")
+# DRIN_LIB_PATH: another build of the same library (the sanitizer build of `python -m drin_amd.build --asan-host`)
+LIB_PATH = os.environ.get("DRIN_LIB_PATH") or os.path.join(_HERE, "libdrin_hip.so")
 MAX_LAYERS = 8
 ABI_VERSION = 2
 

@@ -1,6 +1,10 @@
 """Builds libdrin_hip.so (gfx950) in-tree with hipcc.  No GPU is needed: hipcc cross-compiles.
 
     python -m drin_amd.build [--force] [--debug]
+    python -m drin_amd.build --asan-host      # libdrin_hip_asan.so: the HOST side (argument validation, workspace layout, launch
+                                              # sequencing) under AddressSanitizer + UBSan, device code uninstrumented
+                                              # (-fno-gpu-sanitize; GPU sanitizer runs are not available on this pool).
+                                              # Load it with DRIN_LIB_PATH=... and LD_PRELOAD=<asan runtime> (tests/test_cabi.py).
 
 The shared library is written next to this file so that it travels with the source tree
 (it is git-ignored, not gpurun-ignored).  Objects are rebuilt only when a source or header
@@ -34,12 +38,31 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str:
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+ASAN_LIB = os.path.join(HERE, "libdrin_hip_asan.so")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-g"]
+
+
+def asan_runtime() -> str:
+    """Path of clang's shared ASan runtime (what LD_PRELOAD needs when python loads the instrumented library)."""
+    out = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(out) or not os.path.exists(out):
+        import glob
+        hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+        if not hits:
+            raise RuntimeError("clang's libclang_rt.asan-x86_64.so not found")
+        out = hits[-1]
+    return out
+
+
+def build(force: bool = False, debug: bool = False, verbose: bool = True, asan_host: bool = False) -> str:
+    obj_dir = os.path.join(CSRC, "build_asan" if asan_host else "build")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden",
-             f"-I{INCLUDE}", f"-I{CSRC}"]
+    flags = [f"--offload-arch={ARCH}", "-O1" if asan_host else "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+             "-fvisibility=hidden", f"-I{INCLUDE}", f"-I{CSRC}"]
     flags += os.environ.get("DRIN_EXTRA_FLAGS", "").split()
+    if asan_host:
+        flags += SAN_FLAGS
     if debug:
         flags += ["-g", "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     hdr_t = _newest_header()
@@ -47,7 +70,7 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
             jobs.append([hipcc, "-c", s, "-o", o] + flags)
@@ -63,10 +86,11 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True) -> str
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
-    return LIB
+    lib = ASAN_LIB if asan_host else LIB
+    if jobs or not os.path.exists(lib):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + (SAN_FLAGS[:2] + ["-shared-libsan"] if asan_host else []) + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, debug="--debug" in sys.argv))
+    print(build(force="--force" in sys.argv, debug="--debug" in sys.argv, asan_host="--asan-host" in sys.argv))

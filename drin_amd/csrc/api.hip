@@ -1,6 +1,8 @@
 // C ABI of libdrin_hip.so (include/drin_hip.h): argument validation, workspace layout and the launch
 // sequence of Model.forward (drin/model.py:164-209).  Host code only; kernels live in the sibling files.
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -25,6 +27,35 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return DRIN_E_HIP;
+}
+
+// ---- roctx ranges (opt-in: DRIN_ROCTX) ----------------------------------------------------------
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (!getenv("DRIN_ROCTX")) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static const Roctx& roctx() {
+  static const Roctx r;  // thread-safe one-time initialisation
+  return r;
+}
+RoctxRange::RoctxRange(const char* name) : pushed(false) {
+  const Roctx& r = roctx();
+  if (r.push) {
+    r.push(name);
+    pushed = true;
+  }
+}
+RoctxRange::~RoctxRange() {
+  if (pushed) roctx().pop();
 }
 
 // ---- process-wide kernel profile ---------------------------------------------------------------
@@ -474,6 +505,7 @@ int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, 
 
 int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                  size_t workspace_bytes, float* scores, int keep_for_backward, const drin_trace* trace, void* stream) {
+  RoctxRange range("drin_forward");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
   DRIN_TRY(validate_params(cfg, params));
@@ -700,6 +732,7 @@ const char* drin_kernel_class_name(int kernel_class) {
 
 int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                   size_t workspace_bytes, const float* grad_scores, const drin_param_grads* grads, void* stream) {
+  RoctxRange range("drin_backward");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
   DRIN_TRY(validate_params(cfg, params));

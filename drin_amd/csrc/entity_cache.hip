@@ -461,6 +461,7 @@ DRIN_API size_t drin_cached_workspace_bytes(const drin_config* cfg) {
 DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* tables, const drin_params* params,
                                      const void* prepared, void* cache, size_t cache_bytes, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  RoctxRange range("drin_build_entity_cache");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(cache_supported(cfg));
   if (!tables || !params || !prepared || !cache || !workspace) {
@@ -534,6 +535,7 @@ DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* t
 
 DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
                                  const void* cache, void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  RoctxRange range("drin_forward_cached");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(cache_supported(cfg));
   if (!b || !params || !prepared || !cache || !workspace || !scores) {

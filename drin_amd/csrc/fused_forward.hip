@@ -159,6 +159,7 @@ size_t drin_fused_workspace_bytes(const drin_config* cfg) {
 
 int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepared, size_t prepared_bytes,
                  void* stream) {
+  RoctxRange range("drin_prepare");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(fused_supported(cfg));
   if (!params || !prepared) {
@@ -226,6 +227,7 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
 
 int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
                           void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  RoctxRange range("drin_forward_prepared");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(fused_supported(cfg));
   if (!b || !params || !prepared || !workspace || !scores) {

@@ -51,6 +51,15 @@ inline int ensure_dynamic_lds(DynLdsOptIn& s, const void* kernel, int bytes, con
   return DRIN_OK;
 }
 
+// roctx range over one entry point (rocprofv3 --marker-trace shows the calls of the path as named ranges above their
+// kernels).  Inert unless DRIN_ROCTX is set in the environment when the first entry point runs; the roctx library is
+// dlopen'ed then (librocprofiler-sdk-roctx.so, else libroctx64.so) - the library has no link-time dependency on it.
+struct RoctxRange {
+  explicit RoctxRange(const char* name);
+  ~RoctxRange();
+  bool pushed;
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // grid of the one-wave-per-pair kernels (device_utils.h: wave_pair)

@@ -132,3 +132,49 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
             assert int(got[f"{cname}.{field}"]) == getattr(cls, field).offset, f"{cname}.{field}"
     # and the header declares no field the mirror lacks (sizes equal + every mirrored field at its offset + no padding holes)
     assert C.sizeof(_lib.DrinBatchC) == 8 * len(_lib.DrinBatchC._fields_)
+
+
+def test_activation_ids_are_validated_on_host():
+    lib = _lib.load()
+    c = _lib.DrinConfigC()
+    lib.drin_default_config(C.byref(c))
+    c.batch = 4
+    assert (c.vertex_activation, c.edge_activation) == (0, 0)             # DRIN_ACT_DEFAULT: gelu / sigmoid
+    assert lib.drin_fused_supported(C.byref(c)) == _lib.OK
+    c.vertex_activation = _lib.ACTIVATIONS["relu"]
+    assert lib.drin_workspace_bytes(C.byref(c), 1) > 0
+    assert lib.drin_fused_supported(C.byref(c)) == _lib.E_UNSUPPORTED     # the folded path is built for gelu / sigmoid
+    c.edge_activation = _lib.ACTIVATIONS["silu"]                          # no derivative-from-output: not built for edges
+    assert lib.drin_workspace_bytes(C.byref(c), 1) == 0 and b"edge_activation" in lib.drin_last_error()
+    c.edge_activation, c.vertex_activation = 0, 17
+    assert lib.drin_workspace_bytes(C.byref(c), 1) == 0
+
+
+def test_adam_entry_point_validates_on_host():
+    lib = _lib.load()
+    one = C.c_void_p(16)
+    args = (0.1, 0.999, 0.001, 1.0, 1e-8, -1e-3, None)
+    assert lib.drin_adam_step(None, one, one, one, 8, *args) == _lib.E_NULL
+    assert lib.drin_adam_step(one, one, one, one, -1, *args) == _lib.E_SHAPE
+    assert lib.drin_adam_step(one, one, one, one, 0, *args) == _lib.OK    # nothing to do, nothing launched
+    assert lib.drin_adam_step(C.c_void_p(20), one, one, one, 8, *args) == _lib.E_ALIGN
+    assert lib.drin_adam_step(one, one, one, one, 8, 0.75, 0.999, 0.001, 1.0, 1e-8, -1e-3, None) == _lib.E_UNSUPPORTED
+
+
+@pytest.mark.skipif(os.environ.get("DRIN_LIB_PATH") is not None, reason="already running against another build of the library")
+def test_host_side_under_address_and_ub_sanitizers(tmp_path):
+    """an ASan / UBSan build of the HOST side of the C-ABI library (argument validation, workspace
+    layouts, error strings; device code uninstrumented, no GPU needed): every host-only test of this module passes against
+    it with the sanitizers armed (`python -m drin_amd.build --asan-host`)."""
+    import shutil
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    from drin_amd import build as B
+    lib = B.build(asan_host=True, verbose=False)
+    env = dict(os.environ, DRIN_LIB_PATH=lib, LD_PRELOAD=B.asan_runtime(),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "not sanitizers and not plain_c_abi_example"], capture_output=True, text=True, env=env, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

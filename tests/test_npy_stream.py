@@ -38,20 +38,21 @@ def test_writer_is_byte_identical_to_reference(tmp_path, golden_dir, name):
 
 
 def test_writer_errors_follow_reference(tmp_path):
+    """The same conditions raise the same exception TYPE as the reference's writer (utils.py:168-202); the wording is ours."""
     w = NpyWriter(str(tmp_path / "a.npy"))
-    with pytest.raises(RuntimeError, match="invalid type"):
+    with pytest.raises(RuntimeError, match="integer or floating"):
         w.append([1, 2, 3])                                   # utils.py:168-173: ndarray only
-    with pytest.raises(RuntimeError, match="invalid type"):
+    with pytest.raises(RuntimeError, match="integer or floating"):
         w.append(np.array(["a"]))
     w.append(np.zeros((2, 3), np.float32))
     assert w.shape == (2, 3)
-    with pytest.raises(RuntimeError, match="does not match previous shape"):
+    with pytest.raises(RuntimeError, match="one shape"):
         w.append(np.zeros((3, 2), np.float32))
-    with pytest.raises(RuntimeError, match="does not match previous type"):
+    with pytest.raises(RuntimeError, match="one dtype"):
         w.append(np.zeros((2, 3), np.float64))
-    with pytest.raises(RuntimeError, match="invalid input shape"):
+    with pytest.raises(RuntimeError, match="at most one dimension"):
         w.reshape((-1, -1))
-    with pytest.raises(RuntimeError, match="does not match previous shape"):
+    with pytest.raises(RuntimeError, match="6 elements have been written"):
         w.reshape((4, 5))
     w.close()
     assert np.load(str(tmp_path / "a.npy")).shape == (1, 2, 3)
@@ -67,7 +68,7 @@ def test_writer_context_manager_and_guards(tmp_path):
     # an unclosed file has no header: refused loudly rather than read as garbage
     w = NpyWriter(str(tmp_path / "d.npy"))
     w.append(np.zeros(3))
-    w.output_file.flush()
+    w._fh.flush()
     with pytest.raises(ValueError, match="not an .npy file"):
         read_npy_header(str(tmp_path / "d.npy"))
     w.close()

@@ -15,10 +15,11 @@ Prints ONE JSON line (rank 0): the contract fields of the headline (BASELINE.jso
   roofline     : dominant kernel of the headline, HIP-event timed inside this process on the launch stream
   cpu_baseline : the CPU oracle (oracle/drin_oracle.py) timed on this host's cores on a bounded sample (N = 1)
   parity       : slices of the TIMED batch re-scored by the oracle (N = 1)
-  legs         : the other BASELINE configs under the same clock - f32_exact, train_step (configs 3 / 4; the only leg
-                 that also runs at N > 1: one RCCL all-reduce of the flat gradient bucket per step), wikidiverse (config 2,
-                 fp32- and bf16-stored features), table_cache (config 5: 1 M-entity table, 1000 candidates gathered on the
-                 device, mention chunks streamed)
+  legs         : the other BASELINE configs under the same clock - f32_exact, wikimel_bf16_features (the headline batch with
+                 bf16-stored features), wikidiverse_b4 (configs[0]: the reference's CPU-runnable case), train_step (configs
+                 3 / 4; the only leg that also runs at N > 1: one RCCL all-reduce of the flat gradient bucket per step),
+                 wikidiverse (config 2, fp32- and bf16-stored features), table_cache (config 5: 1 M-entity table, 1000
+                 candidates gathered on the device, mention chunks streamed)
 """
 from __future__ import annotations
 
@@ -506,6 +507,11 @@ def stream_table(ctx, model, cfg, table, g, mentions, chunk, seed0=1000):
     allocator grow by 1 GB per chunk).  Only the current chunk is resident.  Returns (seconds, chunks, last scores, last chunk)."""
     n_chunks = (mentions + chunk - 1) // chunk
     with torch.no_grad():
+        # untimed: two chunks' worth of blocks into the caching allocator (the loop holds the previous chunk while it draws the
+        # next one); a first hipMalloc of 3.4 GB costs a few hundred ms and would otherwise sit in the first timed steps
+        warm = [make_table_chunk(cfg, table, min(chunk, mentions), seed0 - 1 - i, ctx.dev, g) for i in range(2)]
+        model(warm[0])
+        del warm
         ctx.barrier()
         t0 = time.perf_counter()
         out = ib = None
@@ -723,7 +729,7 @@ def parse_args(argv=None):
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--legs", default="auto",
-                    help="secondary legs of the default run, comma separated: f32_exact,train_step,wikidiverse,table_cache | all | none "
+                    help="secondary legs of the default run, comma separated: f32_exact,wikimel_bf16_features,wikidiverse_b4,train_step,wikidiverse,table_cache | all | none "
                          "(auto: all for the default headline at N = 1, train_step at N > 1, none when a non-default workload / mode / batch is asked for)")
     ap.add_argument("--stub", action="store_true", help="CPU + gloo stand-in step (no GPU, no library): exercises the launcher and the timing plumbing only")
     args = ap.parse_args(argv)
@@ -733,7 +739,7 @@ def parse_args(argv=None):
 
 
 def wanted_legs(args, world):
-    names = ("f32_exact", "train_step", "wikidiverse", "table_cache")
+    names = ("f32_exact", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "wikidiverse", "table_cache")
     default_headline = (args.workload == "wikimel" and args.mode == "score" and not args.batch and not args.generic
                         and args.precision == "bf16x3" and args.features == "f32" and not args.graph)
     if args.legs == "auto":
@@ -846,9 +852,41 @@ def main(argv=None):
             return compact(ln, keep=("value", "unit", "ms_per_step", "steps", "dtype", "path", "roofline", "kernel_ms_per_step",
                                      "parity", "max_abs_diff_vs_headline_scores"))
         extra["f32_exact"] = leg_guard("f32_exact", f32_leg)
+    if "wikimel_bf16_features" in legs and world == 1:
+        def bf16_leg():
+            # BASELINE configs 2-3 say "bf16": the headline batch with its six feature tensors stored as bf16 (read in place by
+            # the fused path; arithmetic unchanged, so the scores equal the oracle's on the same stored values)
+            b16 = [t.to(torch.bfloat16) if i in FEAT_SLOTS else t for i, t in enumerate(batch)]
+            st = min(args.steps, 10)
+            e, pr, o, pf = run_score(ctx, model, b16, st, 2)
+            ln = score_line(ctx, cfg, args, B, b16, e, pr, pf, st, 2, args.precision, "bf16", args.workload, False, fused)
+            ln["parity"] = parity_of_timed_batch(cfg, sd, b16, o, n_slices=4, width=8, fp32_batch=batch)
+            return compact(ln)
+        extra["wikimel_bf16_features"] = leg_guard("wikimel_bf16_features", bf16_leg)
     del batch, out, model
     if torch.cuda.is_available():
         torch.cuda.empty_cache()
+
+    if "wikidiverse_b4" in legs and world == 1:
+        def b4_leg():
+            # BASELINE configs[0]: the reference's own CPU-runnable case (WikiDiverse, batch 4) - one scoring call on the GPU
+            # next to the CPU oracle on the same batch
+            from oracle import drin_oracle as O
+            wd = DrinConfig()
+            wsd = synth.make_state_dict(wd, 7)
+            m = make_model(wd, wsd, dev, "bf16x3")
+            host = synth.make_batch(wd, 4, 1)
+            b = [t.to(dev) for t in host[:14]]
+            e, pr, o, pf = run_score(ctx, m, b, 200, 20)
+            torch.set_num_threads(host_threads()["threads_used"])
+            with torch.no_grad():
+                it, el = _time_oracle(lambda: O.forward(wsd, host), 2.0, 2000)
+                ref = O.forward(wsd, host)
+            return {"workload": "BASELINE configs[0]: wikidiverse-shaped, batch 4, 11 candidates - one scoring call",
+                    "ms_per_call": e / 200 * 1e3, "value": 44 * 200 / e, "unit": "pairs/s",
+                    "cpu_oracle_ms_per_call": el / it * 1e3, "cpu_threads": torch.get_num_threads(),
+                    "parity": {"max_abs_score_err": float((o.cpu() - ref).abs().max()), "mentions": 4}}
+        extra["wikidiverse_b4"] = leg_guard("wikidiverse_b4", b4_leg)
 
     if "train_step" in legs:
         extra["train_step"] = leg_guard("train_step", lambda: bench_train(ctx, cfg, sd, 64, 20, 30))

@@ -88,15 +88,19 @@ class Ctx:
         if self.world != args.gpus:
             raise SystemExit(f"bench.py: WORLD_SIZE={self.world} but --gpus {args.gpus}: start N ranks with "
                              f"`python bench.py --gpus N` (self-launching) or torch.distributed.run --nproc-per-node N ... --gpus N")
+        # rehearsal knobs for a ONE-GPU box (tools/dp_rehearsal.sh): all ranks on device 0 and gloo instead of RCCL (which
+        # refuses two ranks on one device) - everything but the collective library itself is then the N > 1 code path
+        share = os.environ.get("DRIN_BENCH_SHARE_GPU") == "1"
+        backend = os.environ.get("DRIN_BENCH_BACKEND", "nccl")
         if self.stub:
             self.dev = torch.device("cpu")
         else:
-            self.dev = torch.device("cuda", self.local_rank)
+            self.dev = torch.device("cuda", 0 if share else self.local_rank)
             torch.cuda.set_device(self.dev)
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.stub:
+            if self.stub or backend == "gloo":
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)

@@ -797,7 +797,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   // the exact-fp32 MFMA one); everything else takes the exact fp32 NN kernel.
   const bool x3 = prec == DRIN_PREC_BF16X3 || prec == DRIN_PREC_BF16X3_ALL;
   // scalar edges: W_h^T and W_v^T of every layer in ONE batched transpose up front (slots 2 l and 2 l + 1 of L.wt);
-  // vector edges (half-width W_u / W_v, W_m) transpose per product into slot 0
+  // anything else (W_u at 512+ mentions; the half-width W_u / W_v and W_m of vector edges) is transposed per product into the last slot
   const bool pre_t = x3 && !cfg->vector_edges && M >= 1024 && (D % 32) == 0;
   auto wt_slot = [&](int l, int which) { return ws + L.wt + ((size_t)2 * l + which) * D * D; };
   if (pre_t) {
@@ -813,7 +813,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     // w is [k_red][n_out] contiguous; w_t: its transpose, already in the workspace
     if (x3 && rows >= 1024 && (k_red % 32) == 0 && (n_out % 4) == 0 && (size_t)k_red * n_out <= (size_t)D * D) {
       if (w_t == nullptr) {
-        float* wt = ws + L.wt;
+        float* wt = ws + L.wt + (size_t)2 * nl * D * D;   // the scratch slot: never one of the pre-transposed weights
         DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));
         w_t = wt;
       }

@@ -43,7 +43,7 @@ struct Layout {
   size_t splitk = 0, splitk_floats = 0;     // split-K partials of the mention-sized exact-fp32 products (small batches only)
   size_t tn_part = 0, tn_part_floats = 0;   // [slices][N][K] partial tiles of the split-bf16 weight-gradient products
   size_t ln_part = 0;                       // [1024 + 16][3][D] per-block column sums of the LayerNorm backward and their first reduction level
-  size_t wt = 0;                            // [2 layers][D][D] transposed W_h / W_v of every layer (split-bf16 dX = dY W), one batched transpose per backward
+  size_t wt = 0;                            // [2 layers + 1][D][D] transposed W_h / W_v of every layer (split-bf16 dX = dY W, one batched transpose per backward) + one slot for products transposed on the fly
   size_t bwd_scratch = 0;                   // backward temporaries (training only)
   size_t bwd_scratch_floats = 0;
 
@@ -88,7 +88,7 @@ struct Layout {
         fv[l] = take(2 * M * D);
       }
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
-      wt = take((size_t)2 * (nl > 0 ? nl : 1) * D * D);
+      wt = take(((size_t)2 * nl + 1) * D * D);   // slots 2 l, 2 l + 1: W_h^T, W_v^T of layer l; slot 2 nl: the product in flight
       ln_part = take((1024 + 16) * 3 * D);
       {  // one workgroup per CU: 256 / tiles slices of the largest product (D x D: 9 tiles at 768; D x R: 24)
         const size_t t_dd = ((D + 255) / 256) * ((D + 255) / 256), t_dr = ((D + 255) / 256) * ((R + 255) / 256);

@@ -143,6 +143,7 @@ class LibraryAdam:
         step = float(self.t)
         bias_correction1 = 1 - b1 ** step                    # torch/optim/adam.py (_multi_tensor_adam), python doubles
         bias_correction2 = 1 - b2 ** step
+        self.lr = float(self.param_groups[0]["lr"])          # honour a scheduler writing the group's lr, like torch's optimisers
         neg_step_size = (self.lr / bias_correction1) * -1
         bias_correction2_sqrt = bias_correction2 ** 0.5
         scal = (1 - b1, b2, 1 - b2, bias_correction2_sqrt, self.eps, neg_step_size)

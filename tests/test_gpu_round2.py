@@ -313,3 +313,28 @@ def test_second_device_opts_into_large_lds():
         with torch.no_grad():
             outs.append(m([t.to(d) for t in synth.make_batch(cfg, 300, 5)[:14]]).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_three_layer_backward_at_512_mentions_keeps_its_transposed_weights():
+    """Regression (round 2): the split-bf16 dX = dY W products run against weights transposed ONCE per backward; a product that
+    is transposed on the fly (W_u at >= 512 mentions: 2 B >= 1024 rows) must not overwrite one of them.  Three dynamic layers,
+    600 mentions, TINY widths raised to the split-bf16 kernel's range; every gradient against autograd through the oracle."""
+    from drin_amd.metrics import TripletLoss
+    cfg = DrinConfig(num_gcn_layers=3, num_candidates_data=2, bert_embed_dim=128, gcn_embed_dim=128, resnet_embed_dim=128,
+                     max_mention_sentence_len=8, resnet_num_region=2)
+    sd = synth.make_state_dict(cfg, 9)
+    batch = synth.make_batch(cfg, 600, 45)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss = O.triplet_loss(batch[-1], O.forward(p, batch, **O.config_kwargs(cfg)), cfg.triplet_margin)
+    ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)
+    model = Model(cfg, precision="bf16x3").to(DEV)
+    model.load_state_dict(sd)
+    dbatch = _to_dev(batch)
+    loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5
+    for (k, q), r in zip(model.named_parameters(), ref):
+        assert (q.grad is None) == (r is None), k
+        if r is not None:
+            rel = (q.grad.cpu() - r).norm().item() / (r.norm().item() + 1e-12)
+            assert rel <= 5e-4, (k, rel)

@@ -562,20 +562,41 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
   // into the same scratch
   float* const msk = sk ? sk : tl;
   const size_t mskf = sk ? skf : tlf;
+  // split-bf16 precision: every weight an NT product runs against is split into bf16 (hi, lo) planes ONCE per call (one
+  // batched launch) and then streamed by LDS-DMA, instead of being split by every workgroup in every K-block (the register
+  // stager of the 64 x 128 tile spent as many VALU cycles on it as the tile has MFMA cycles)
+  auto wp = [&](size_t off) -> const float* { return L.weight_planes ? ws + off : nullptr; };
+  if (L.weight_planes) {
+    SplitBatch sb;
+    DRIN_TRY(sb.add(params->w_mention_text, ws + L.wp_enc[0], (int64_t)D * D));
+    DRIN_TRY(sb.add(params->w_mention_image, ws + L.wp_enc[1], (int64_t)D * R));
+    DRIN_TRY(sb.add(params->w_entity_text, ws + L.wp_enc[2], (int64_t)D * D));
+    DRIN_TRY(sb.add(params->w_entity_image, ws + L.wp_enc[3], (int64_t)D * R));
+    for (int l = 0; l < nl; ++l) {
+      DRIN_TRY(sb.add(params->layer[l].w_h, ws + L.wp_h[l], (int64_t)D * D));
+      if (cfg->dynamic_edges && (l < nl - 1 || full)) {
+        DRIN_TRY(sb.add(params->layer[l].w_u, ws + L.wp_u[l], (int64_t)D * D));
+        DRIN_TRY(sb.add(params->layer[l].w_v, ws + L.wp_v[l], (int64_t)D * D));
+      }
+    }
+    DRIN_TRY(launch_split_planes_batch(sb, st));
+  }
   DRIN_TRY(launch_gemm_nt(P.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false,
-                          prec, st, msk, mskf));
+                          prec, st, msk, mskf, wp(L.wp_enc[0])));
   DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
-                          D, B, D, R, false, prec, st, msk, mskf));
+                          D, B, D, R, false, prec, st, msk, mskf, wp(L.wp_enc[1])));
   if (eidx) {  // rows of the entity tables, addressed through the candidate index by the GEMM's stager
+    const __bf16* pt = reinterpret_cast<const __bf16*>(wp(L.wp_enc[2]));
+    const __bf16* pi = reinterpret_cast<const __bf16*>(wp(L.wp_enc[3]));
     DRIN_TRY(launch_gemm_nt_bf16x3(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, st,
-                                   nullptr, nullptr, false, false, tl, tlf, eidx));
+                                   pt, pt ? pt + (size_t)D * D : nullptr, false, false, tl, tlf, eidx));
     DRIN_TRY(launch_gemm_nt_bf16x3(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D,
-                                   D, M, D, R, st, nullptr, nullptr, false, false, tl, tlf, eidx));
+                                   D, M, D, R, st, pi, pi ? pi + (size_t)D * R : nullptr, false, false, tl, tlf, eidx));
   } else {
     DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
-                            prec, st, tl, tlf));
+                            prec, st, tl, tlf, wp(L.wp_enc[2])));
     DRIN_TRY(launch_gemm_nt(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D, D,
-                            M, D, R, false, prec, st, tl, tlf));
+                            M, D, R, false, prec, st, tl, tlf, wp(L.wp_enc[3])));
   }
   DRIN_TRY(tap(trace, 0, L, ws, B, M, D, st, EW));
 
@@ -625,8 +646,8 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     // shared W_h + LayerNorm + GELU for all vertex types of the layer (model.py:128)
     float* h_m = ws + L.h_m[l];
     float* h_e = ws + L.h_e[l];
-    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, msk, mskf));
-    DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st, tl, tlf));
+    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, msk, mskf, wp(L.wp_h[l])));
+    DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st, tl, tlf, wp(L.wp_h[l])));
     float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
     float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
     // one LayerNorm + GELU launch for the mention and the entity vertices (they share it, model.py:128)
@@ -649,8 +670,8 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
-      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, msk, mskf));
-      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf));
+      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, msk, mskf, wp(L.wp_u[l])));
+      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf, wp(L.wp_v[l])));
       DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st, act_e));
     } else if (!cfg->dynamic_edges) {
       hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -800,18 +821,23 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   // anything else (W_u at 512+ mentions; the half-width W_u / W_v and W_m of vector edges) is transposed per product into the last slot
   const bool pre_t = x3 && !cfg->vector_edges && M >= 1024 && (D % 32) == 0;
   auto wt_slot = [&](int l, int which) { return ws + L.wt + ((size_t)2 * l + which) * D * D; };
-  if (pre_t) {
-    TransposeBatch tb;
+  if (pre_t) {  // ... and split into bf16 (hi, lo) planes in the same pass: the NT kernel streams them by LDS-DMA
+    SplitBatch tb;
     for (int l = 0; l < nl; ++l) {
-      tb.src[tb.n] = params->layer[l].w_h, tb.dst[tb.n++] = wt_slot(l, 0);
-      if (cfg->dynamic_edges && l < nl - 1) tb.src[tb.n] = params->layer[l].w_v, tb.dst[tb.n++] = wt_slot(l, 1);
+      DRIN_TRY(tb.add(params->layer[l].w_h, wt_slot(l, 0), (int64_t)D * D));
+      if (cfg->dynamic_edges && l < nl - 1) DRIN_TRY(tb.add(params->layer[l].w_v, wt_slot(l, 1), (int64_t)D * D));
     }
-    DRIN_TRY(launch_transpose_batch(tb, D, D, st));
+    DRIN_TRY(launch_transpose_split_batch(tb, D, D, st));
   }
   auto gemm_nn = [&](const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int64_t rows, int n_out,
                      int k_red, bool accumulate, const float* w_t = nullptr) -> int {
-    // w is [k_red][n_out] contiguous; w_t: its transpose, already in the workspace
+    // w is [k_red][n_out] contiguous; w_t: bf16 (hi, lo) planes of its transpose, already in the workspace
     if (x3 && rows >= 1024 && (k_red % 32) == 0 && (n_out % 4) == 0 && (size_t)k_red * n_out <= (size_t)D * D) {
+      if (w_t != nullptr) {
+        const __bf16* hi = reinterpret_cast<const __bf16*>(w_t);
+        return launch_gemm_nt_bf16x3(dy, lddy, nullptr, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, hi, hi + (size_t)k_red * n_out,
+                                     accumulate, false, tnp, tnf);
+      }
       if (w_t == nullptr) {
         float* wt = ws + L.wt + (size_t)2 * nl * D * D;   // the scratch slot: never one of the pre-transposed weights
         DRIN_TRY(launch_transpose(w, wt, k_red, n_out, st));

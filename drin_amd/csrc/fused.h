@@ -122,12 +122,6 @@ int launch_reduce_stream_partials(const float* part, float* s_text, float* s_img
 int launch_mention_input1(const float* T, const float* T2, const float* sig, const float* b_et, const float* b_ei,
                           const float* v0, float* out, int B, int D, int N, hipStream_t st);
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);
-struct TransposeBatch {
-  const float* src[16];
-  float* dst[16];
-  int n = 0;
-};
-int launch_transpose_batch(const TransposeBatch& b, int rows, int cols, hipStream_t st);
 int launch_pair_layer1(const PairArgs& a, hipStream_t st);
 int launch_mention_input2(const float* part, const float* mt1, float* out, int B, int D, int N, int chunks,
                           hipStream_t st);

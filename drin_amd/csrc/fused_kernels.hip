@@ -384,30 +384,6 @@ __global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ in,
     if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
-// the same for up to 16 equally shaped matrices in one launch (blockIdx.z = which): the weights drin_backward's split-bf16
-// dX = dY W products run against, transposed once per call
-__global__ void __launch_bounds__(256) k_transpose_batch(const TransposeBatch b, int rows, int cols) {
-  __shared__ float tile[32][33];
-  const float* __restrict__ in = b.src[blockIdx.z];
-  float* __restrict__ out = b.dst[blockIdx.z];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  for (int i = ty; i < 32; i += 8)
-    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8)
-    if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
-}
-
-int launch_transpose_batch(const TransposeBatch& b, int rows, int cols, hipStream_t st) {
-  if (b.n <= 0 || rows <= 0 || cols <= 0) return DRIN_OK;
-  KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_transpose_batch, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32), (unsigned)b.n), dim3(256), 0, st, b,
-                     rows, cols);
-  DRIN_CHECK_LAUNCH("k_transpose_batch");
-  return DRIN_OK;
-}
-
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
   if (rows <= 0 || cols <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);

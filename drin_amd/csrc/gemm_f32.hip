@@ -288,11 +288,16 @@ static bool small_splitk_fits(int64_t M, int N, int K, int64_t ldy, const float*
 
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                    int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st, float* splitk,
-                   size_t splitk_floats) {
+                   size_t splitk_floats, const float* w_planes) {
   // split-bf16 contraction for the pair-sized GEMMs; the mention-sized ones (a few hundred rows) stay on
   // the exact fp32 kernel: they are latency-bound, not rate-bound
-  if (!accumulate && ((precision == DRIN_PREC_BF16X3 && M >= 256) || precision == DRIN_PREC_BF16X3_ALL))
-    return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, M, N, K, st, nullptr, nullptr, false, false, splitk, splitk_floats);
+  if (!accumulate && ((precision == DRIN_PREC_BF16X3 && M >= 256) || precision == DRIN_PREC_BF16X3_ALL)) {
+    // (pre-split weight planes: contiguous [N][K] weights only, K a multiple of 32 - what the LDS-DMA path reads)
+    const bool planes = w_planes != nullptr && ldw == K && (K % 32) == 0;
+    const __bf16* hi = reinterpret_cast<const __bf16*>(w_planes);
+    return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, M, N, K, st, planes ? (const void*)hi : nullptr,
+                                 planes ? (const void*)(hi + (int64_t)N * K) : nullptr, false, false, splitk, splitk_floats);
+  }
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) precision = DRIN_PREC_F32;
   DRIN_TRY(check_precision(precision, "gemm_nt"));
   if (K % 4) {

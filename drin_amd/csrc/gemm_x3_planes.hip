@@ -300,6 +300,48 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
   *reinterpret_cast<bf16x4*>(lo + i * 4) = l;
 }
 
+// the same for up to 32 tensors in one launch (blockIdx.y = which): the weights a training step's split-bf16 NT products run
+// against, split ONCE per forward / backward instead of once per workgroup per K-block by the register stager
+__global__ void __launch_bounds__(256) k_split_planes_batch(const SplitBatch b) {
+  const int w = blockIdx.y;
+  const int64_t n4 = b.n4[w];
+  const float* __restrict__ x = b.src[w];
+  __bf16* __restrict__ hi = reinterpret_cast<__bf16*>(b.planes[w]);
+  __bf16* __restrict__ lo = hi + n4 * 4;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = ld4(x + i * 4);
+    bf16x4 h, l;
+    h[0] = (__bf16)v.x, h[1] = (__bf16)v.y, h[2] = (__bf16)v.z, h[3] = (__bf16)v.w;
+    l[0] = (__bf16)(v.x - (float)h[0]), l[1] = (__bf16)(v.y - (float)h[1]);
+    l[2] = (__bf16)(v.z - (float)h[2]), l[3] = (__bf16)(v.w - (float)h[3]);
+    *reinterpret_cast<bf16x4*>(hi + i * 4) = h;
+    *reinterpret_cast<bf16x4*>(lo + i * 4) = l;
+  }
+}
+
+// planes[w] = (hi, lo) of src[w]^T for equally shaped [rows][cols] matrices: the transposed weights of the backward dX = dY W
+// products, transposed AND split once per call
+__global__ void __launch_bounds__(256) k_transpose_split_batch(const SplitBatch b, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const float* __restrict__ in = b.src[blockIdx.z];
+  __bf16* __restrict__ hi = reinterpret_cast<__bf16*>(b.planes[blockIdx.z]);
+  __bf16* __restrict__ lo = hi + (int64_t)rows * cols;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) {
+      const float v = tile[tx][i];
+      const __bf16 h = (__bf16)v;
+      const int64_t o = (int64_t)(c0 + i) * rows + r0 + tx;
+      hi[o] = h;
+      lo[o] = (__bf16)(v - (float)h);
+    }
+}
+
 }  // namespace x3p
 
 #ifdef DRIN_STAMPS
@@ -318,6 +360,38 @@ int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream
   hipLaunchKernelGGL(x3p::k_split_planes, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, x, (__bf16*)hi,
                      (__bf16*)lo, n / 4);
   DRIN_CHECK_LAUNCH("k_split_planes");
+  return DRIN_OK;
+}
+
+int SplitBatch::add(const float* w, float* planes_out, int64_t numel) {
+  if (!w || numel <= 0) return DRIN_OK;
+  if (n >= 32 || (numel % 4) || !aligned16(w) || !aligned16(planes_out)) {
+    set_error("split_planes: at most 32 tensors per batch, element counts multiples of 4, 16-byte aligned");
+    return DRIN_E_SHAPE;
+  }
+  src[n] = w, planes[n] = planes_out, n4[n] = numel / 4;
+  ++n;
+  return DRIN_OK;
+}
+
+int launch_split_planes_batch(const SplitBatch& b, hipStream_t st) {
+  if (b.n == 0) return DRIN_OK;
+  int64_t most = 0;
+  for (int i = 0; i < b.n; ++i) most = most > b.n4[i] ? most : b.n4[i];
+  int64_t gx = cdiv(most, 256);
+  if (gx > 2048) gx = 2048;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(x3p::k_split_planes_batch, dim3((unsigned)gx, (unsigned)b.n), dim3(256), 0, st, b);
+  DRIN_CHECK_LAUNCH("k_split_planes_batch");
+  return DRIN_OK;
+}
+
+int launch_transpose_split_batch(const SplitBatch& b, int rows, int cols, hipStream_t st) {
+  if (b.n == 0 || rows <= 0 || cols <= 0) return DRIN_OK;
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(x3p::k_transpose_split_batch, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32), (unsigned)b.n), dim3(256),
+                     0, st, b, rows, cols);
+  DRIN_CHECK_LAUNCH("k_transpose_split_batch");
   return DRIN_OK;
 }
 

@@ -98,9 +98,10 @@ int launch_scale_div(const float* in, float* out, int64_t n, float mul, float di
 // y[m, n] (+)= sum_k x[m, k] * w[n, k] + bias[n];  x row stride ldx, w row stride ldw, y row stride ldy
 // (splitk: optional scratch; mention-sized exact-fp32 products with K >= 512 then split K over workgroups into it
 //  and reduce in order - deterministic - instead of walking K serially in 24 tiles)
+// (w_planes: optional bf16 hi / lo planes of w - launch_split_planes_batch - taken when the product runs split-bf16)
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                    int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st, float* splitk = nullptr,
-                   size_t splitk_floats = 0);
+                   size_t splitk_floats = 0, const float* w_planes = nullptr);
 // same contraction, operands split into bf16 hi + lo, three bf16 MFMAs, fp32 accumulate (gemm_bf16x3.hip)
 // (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
@@ -131,6 +132,17 @@ int launch_splitk_reduce(const float* partial, int splits, int64_t part_stride, 
                          int64_t M, int N, bool accumulate, hipStream_t st);
 // fp32 -> bf16 hi / lo planes (n % 4 == 0)
 int launch_split_planes(const float* x, void* hi, void* lo, int64_t n, hipStream_t st);
+// up to 32 tensors split in ONE launch; planes_out holds numel bf16 of hi followed by numel bf16 of lo (= numel floats).
+// launch_transpose_split_batch: the same for the TRANSPOSES of equally shaped [rows][cols] matrices.
+struct SplitBatch {
+  const float* src[32];
+  float* planes[32];
+  int64_t n4[32];
+  int n = 0;
+  int add(const float* w, float* planes_out, int64_t numel);   // no-op for w == NULL
+};
+int launch_split_planes_batch(const SplitBatch& b, hipStream_t st);
+int launch_transpose_split_batch(const SplitBatch& b, int rows, int cols, hipStream_t st);
 // y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
                    int K, bool accumulate, int precision, hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);

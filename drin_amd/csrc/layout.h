@@ -43,7 +43,12 @@ struct Layout {
   size_t splitk = 0, splitk_floats = 0;     // split-K partials of the mention-sized exact-fp32 products (small batches only)
   size_t tn_part = 0, tn_part_floats = 0;   // [slices][N][K] partial tiles of the split-bf16 weight-gradient products
   size_t ln_part = 0;                       // [1024 + 16][3][D] per-block column sums of the LayerNorm backward and their first reduction level
-  size_t wt = 0;                            // [2 layers + 1][D][D] transposed W_h / W_v of every layer (split-bf16 dX = dY W, one batched transpose per backward) + one slot for products transposed on the fly
+  size_t wt = 0;                            // [2 layers + 1][D][D]: bf16 (hi, lo) planes of W_h^T / W_v^T of every layer (split-bf16 dX = dY W, one batched transpose + split per backward) + one fp32 slot for products transposed on the fly
+  // bf16 (hi, lo) planes of the weights the split-bf16 NT products run against (one batched split per forward call):
+  // vertex encoders (mention text, mention image, entity text, entity image), per layer W_h, W_u, W_v.  numel floats each.
+  size_t wp_enc[4] = {};
+  size_t wp_h[DRIN_MAX_LAYERS] = {}, wp_u[DRIN_MAX_LAYERS] = {}, wp_v[DRIN_MAX_LAYERS] = {};
+  bool weight_planes = false;
   size_t bwd_scratch = 0;                   // backward temporaries (training only)
   size_t bwd_scratch_floats = 0;
 
@@ -69,6 +74,13 @@ struct Layout {
     xet_pool = take(c.entity_tokens > 0 ? M * D : 0);
     splitk_floats = 2 * B <= 512 ? 8 * 2 * B * D : 0;
     splitk = take(splitk_floats);
+    // split-bf16 precision with scalar edges and at least a tile row of pairs: the weights as planes
+    weight_planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL) && !c.vector_edges && M >= 256 &&
+                    (D % 32) == 0 && (R % 32) == 0;
+    if (weight_planes) {
+      wp_enc[0] = take(D * D), wp_enc[1] = take(D * R), wp_enc[2] = take(D * D), wp_enc[3] = take(D * R);
+      for (int l = 0; l < nl; ++l) wp_h[l] = take(D * D), wp_u[l] = take(D * D), wp_v[l] = take(D * D);
+    }
     if (train) {
       for (int l = 0; l <= nl; ++l) {
         edges[l] = take(4 * M * EW);

@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0): the contract fields of the headline (BASELINE.jso
   legs         : the other BASELINE configs under the same clock - f32_exact, wikimel_bf16_features (the headline batch with
                  bf16-stored features), wikidiverse_b4 (configs[0]: the reference's CPU-runnable case), train_step (configs
                  3 / 4; the only leg that also runs at N > 1: one RCCL all-reduce of the flat gradient bucket per step),
+                 train_b512 (the step at a rate-bound batch, gathered and table form),
                  wikidiverse (config 2, fp32- and bf16-stored features), table_cache (config 5: 1 M-entity table, 1000
                  candidates gathered on the device, mention chunks streamed)
 """
@@ -733,7 +734,7 @@ def parse_args(argv=None):
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--legs", default="auto",
-                    help="secondary legs of the default run, comma separated: f32_exact,wikimel_bf16_features,wikidiverse_b4,train_step,wikidiverse,table_cache | all | none "
+                    help="secondary legs of the default run, comma separated: f32_exact,wikimel_bf16_features,wikidiverse_b4,train_step,train_b512,wikidiverse,table_cache | all | none "
                          "(auto: all for the default headline at N = 1, train_step at N > 1, none when a non-default workload / mode / batch is asked for)")
     ap.add_argument("--stub", action="store_true", help="CPU + gloo stand-in step (no GPU, no library): exercises the launcher and the timing plumbing only")
     args = ap.parse_args(argv)
@@ -743,7 +744,7 @@ def parse_args(argv=None):
 
 
 def wanted_legs(args, world):
-    names = ("f32_exact", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "wikidiverse", "table_cache")
+    names = ("f32_exact", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "train_b512", "wikidiverse", "table_cache")
     default_headline = (args.workload == "wikimel" and args.mode == "score" and not args.batch and not args.generic
                         and args.precision == "bf16x3" and args.features == "f32" and not args.graph)
     if args.legs == "auto":
@@ -894,6 +895,11 @@ def main(argv=None):
 
     if "train_step" in legs:
         extra["train_step"] = leg_guard("train_step", lambda: bench_train(ctx, cfg, sd, 64, 20, 30))
+
+    if "train_b512" in legs and world == 1:
+        # the same step at a rate-bound batch, and with the candidates indexed into a device-resident entity table
+        extra["train_b512"] = leg_guard("train_b512", lambda: bench_train(ctx, cfg, sd, 512, 10, 20))
+        extra["train_b512_table"] = leg_guard("train_b512_table", lambda: bench_train(ctx, cfg, sd, 512, 10, 20, train_form="table"))
 
     if "wikidiverse" in legs and world == 1:
         def wd_leg():

@@ -101,10 +101,12 @@ class Ctx:
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import datetime
+            limit = datetime.timedelta(seconds=300)          # a collective that never completes fails the run instead of hanging it
             if self.stub or backend == "gloo":
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=limit)
             else:
-                dist.init_process_group("nccl", device_id=self.dev)
+                dist.init_process_group("nccl", device_id=self.dev, timeout=limit)
 
     def sync(self):
         if not self.stub:

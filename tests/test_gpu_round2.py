@@ -338,3 +338,28 @@ def test_three_layer_backward_at_512_mentions_keeps_its_transposed_weights():
         if r is not None:
             rel = (q.grad.cpu() - r).norm().item() / (r.norm().item() + 1e-12)
             assert rel <= 5e-4, (k, rel)
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 code path of bench.py with the HIP Model on the GPU: two ranks launched by bench.py itself, both on device 0,
+    talking over gloo (RCCL refuses two ranks on one device; everything else - launcher, barrier / max-over-ranks bracket on
+    device tensors, flat gradient bucket all-reduced in place, one-launch Adam - is what an N-GPU run executes)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DRIN_BENCH_SHARE_GPU="1", DRIN_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--mode", "train", "--batch", "16", "--steps", "3",
+                        "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["config"]["global_batch"] == 32
+    assert line["allreduce_ms"] > 0 and line["allreduce_bytes"] == 26775552 and 0 < line["final_loss"] < 1
+    assert "library Adam" in line["optimizer"]
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "2", "--warmup", "1",
+                        "--legs", "none", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["pairs_per_step"] == 2 * 64 * 101 and line["value"] > 0

@@ -2,7 +2,7 @@
 # k_cached_pairs gather rate against the table size (TLB reach / Infinity Cache)
 set -e
 for E in 10000 100000 1000000 4000000; do
-  timeout -k 10 300 python bench.py --workload table --batch ${B:-256} --entities $E --entity-cache --no-cpu-baseline > gpurun_out/ce_$E.json 2> gpurun_out/ce_$E.err
+  timeout -k 10 300 python bench.py --workload table --batch ${B:-256} --entities $E --entity-cache --no-cpu-baseline --legs none > gpurun_out/ce_$E.json 2> gpurun_out/ce_$E.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/ce_$E.json").read().strip().splitlines()[-1])

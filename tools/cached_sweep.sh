@@ -4,7 +4,7 @@ set -e
 for W in 2 3 4; do
   touch drin_amd/csrc/entity_cache.hip
   DRIN_EXTRA_FLAGS="-DDRIN_CACHED_PAIRS_WG_PER_CU=$W" python -m drin_amd.build > gpurun_out/cs_build_$W.log 2>&1
-  timeout -k 10 300 python bench.py --workload table --batch ${B:-256} --entity-cache --no-cpu-baseline > gpurun_out/cs_$W.json 2> gpurun_out/cs_$W.err
+  timeout -k 10 300 python bench.py --workload table --batch ${B:-256} --entity-cache --no-cpu-baseline --legs none > gpurun_out/cs_$W.json 2> gpurun_out/cs_$W.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/cs_$W.json").read().strip().splitlines()[-1])

@@ -5,7 +5,7 @@ for V in nt default nt default; do
   touch drin_amd/csrc/fused_kernels.hip
   if [ $V = default ]; then F="-DDRIN_NO_NT_LOADS"; else F=""; fi
   DRIN_EXTRA_FLAGS="$F" python -m drin_amd.build > gpurun_out/nt_build.log 2>&1
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 10 ${EXTRA} > gpurun_out/nt_$V.json 2> gpurun_out/nt_$V.err
+  timeout -k 10 300 python bench.py --no-cpu-baseline --legs none --steps 10 ${EXTRA} > gpurun_out/nt_$V.json 2> gpurun_out/nt_$V.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/nt_$V.json").read().strip().splitlines()[-1])

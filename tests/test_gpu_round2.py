@@ -363,3 +363,47 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["pairs_per_step"] == 2 * 64 * 101 and line["value"] > 0
+
+
+# ---- size-independent properties at BASELINE's full sizes (WikiMEL-shaped, 512 mentions x 101 candidates) --------------
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layerwise"])
+def test_full_size_disabled_edges_cut_their_inputs_off(fused):
+    """gcn_edge_enabled = (1, 0, 1, 0) (model.py:122) multiplies the ti and ii edges by zero: the scores must not depend on
+    the CLIP text-image similarities nor on any object feature / score - replacing them with other finite values leaves
+    every score bit-identical on either path; the enabled edges' inputs do matter."""
+    cfg = wikimel_config(gcn_edge_enabled=(1, 0, 1, 0), max_entity_attr_token_len=16)
+    sd = synth.make_state_dict(cfg, 7)
+    model = Model(cfg, fused=fused).to(DEV).eval()
+    model.load_state_dict(sd)
+    B = 512
+    batch = synth.make_device_batch(cfg, B, 21, DEV)[:14]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    other = list(batch)
+    other[13] = 20.0 + 5.0 * torch.randn(batch[13].shape, device=DEV, generator=g)            # mtei similarity -> ti edge
+    for i in (5, 10):                                                                          # mention / entity object features
+        other[i] = torch.randn(batch[i].shape, device=DEV, generator=g)
+    for i in (6, 11):                                                                          # their scores
+        other[i] = torch.rand(batch[i].shape, device=DEV, generator=g)
+    with torch.no_grad():
+        a, b = model(batch), model(other)
+        assert torch.equal(a, b)
+        moved = list(batch)
+        moved[12] = batch[12] + 1.0                                                            # miet similarity -> the ENABLED it edge
+        assert (model(moved) - a).abs().max().item() > 1e-5
+        ref = O.forward(sd, [t[:2].cpu() for t in batch], edge_enabled=cfg.gcn_edge_enabled)
+        assert (a[:2].cpu() - ref).abs().max().item() <= 1e-5
+
+
+def test_full_size_cosine_edges_ignore_positive_rescaling():
+    """The two cosine edges (model.py:71-92) are invariant to a positive rescaling of the rows they compare: scaling every
+    entity OBJECT row by a power of two (exact in fp32) leaves the ii edge, hence every score, bit-identical."""
+    cfg = wikimel_config(max_entity_attr_token_len=16)
+    sd = synth.make_state_dict(cfg, 7)
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    batch = synth.make_device_batch(cfg, 512, 22, DEV)[:14]
+    scaled = list(batch)
+    scaled[10] = batch[10] * 4.0
+    scaled[5] = batch[5] * 0.25
+    with torch.no_grad():
+        assert torch.equal(model(batch), model(scaled))

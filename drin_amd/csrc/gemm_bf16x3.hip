@@ -237,11 +237,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
       if (!ONE_PASS) al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
 #pragma unroll
       for (int j = 0; j < G::NI; ++j) {
+        // the WEIGHT fragment is the first operand: a lane's four accumulator registers of a 16 x 16 tile are then four
+        // consecutive output COLUMNS of one row (row lane & 15, columns 4 (lane >> 4) + v) - the epilogue stores 16 bytes
+        // per lane instead of four scattered dwords (as in gemm_x3_planes.hip, where it took the epilogue from 37 k to 24 k cycles)
         if (!ONE_PASS) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -276,29 +279,32 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 #pragma unroll
     for (int i = 0; i < G::MI; ++i)
 #pragma unroll
-      for (int j = 0; j < G::NI; ++j) {
-        const int col = wn * (BN / WN) + j * 16 + r;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) part[(wm * (BM / WM) + i * 16 + c * 4 + v) * BN + col] = acc[i][j][v];
-      }
+      for (int j = 0; j < G::NI; ++j)
+        st4(part + (wm * (BM / WM) + i * 16 + r) * BN + wn * (BN / WN) + j * 16 + c * 4,
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
     return;
   }
+  const bool vec_ok = (ldc % 4) == 0 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
 #pragma unroll
-  for (int i = 0; i < G::MI; ++i)
+  for (int i = 0; i < G::MI; ++i) {
+    const int64_t row = m0 + wm * (BM / WM) + i * 16 + r;  // C/D of a 16 x 16 tile: row lane & 15, columns 4 (lane >> 4) + v
+    if (row >= M) continue;
 #pragma unroll
     for (int j = 0; j < G::NI; ++j) {
-      const int col = n0 + wn * (BN / WN) + j * 16 + r;  // C/D of a 16 x 16 tile: column lane & 15, row 4 (lane >> 4) + v
-      if (col >= N) continue;
-      const float bv = bias != nullptr ? bias[col] : 0.f;
+      const int col = n0 + wn * (BN / WN) + j * 16 + c * 4;
+      float* dst = C + row * ldc + col;
+      if (vec_ok && col + 3 < N) {
+        float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (bias != nullptr) o = o + ld4(bias + col);
+        if (accumulate) o = o + ld4(dst);
+        st4(dst, o);
+      } else {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int64_t row = m0 + wm * (BM / WM) + i * 16 + c * 4 + v;
-        if (row < M) {
-          float* dst = C + row * ldc + col;
-          *dst = acc[i][j][v] + bv + (accumulate ? *dst : 0.f);
-        }
+        for (int v = 0; v < 4; ++v)
+          if (col + v < N) dst[v] = acc[i][j][v] + (bias != nullptr ? bias[col + v] : 0.f) + (accumulate ? dst[v] : 0.f);
       }
     }
+  }
 }
 
 // C[tile] += sum of its ksplit - 1 partial tiles, in order.  Grid (BM rows, tail tiles), BN threads.

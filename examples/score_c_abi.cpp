@@ -9,9 +9,12 @@
 // When the 12th geometry word is 1, the answer tensor [B, N-1] uint8 follows the parameters.
 // scores.bin: B*N fp32 from drin_forward (layer by layer) followed by B*N fp32 from drin_prepare + drin_forward_prepared;
 // with an answer tensor then also one training step's device work (train.py:30-37): the TripletLoss value (1 fp32), the
-// top-1 hit count (1 fp32) and the gradient of every parameter tensor in drin_params order (fp32; dead ones all zero).
+// top-1 hit count (1 fp32), the gradient of every parameter tensor in drin_params order (fp32; dead ones all zero) and,
+// after the Adam step of train.py:55-56 through drin_adam_step, every parameter tensor again (those without a gradient
+// unchanged) - a whole training step with no torch and no Python.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -224,6 +227,40 @@ int main(int argc, char** argv) {
       HIP_OK(hipMemcpy(out.data() + at, gp[i], sizes[i] * 4, hipMemcpyDeviceToHost));
     }
     printf("training step: loss %.7f, top-1 hits %lld of %lld\n", h_loss, (long long)h_correct, (long long)B);
+    // (4) the optimiser step of train.py:55-56 (torch.optim.Adam, lr 1e-3, torch defaults), first step: drin_adam_step per
+    //     tensor that received a gradient, zero moments in one arena laid out like the gradients.  The scalars are formed
+    //     in double on the host exactly as torch/optim/adam.py forms them (include/drin_hip.h).
+    {
+      float* moments = nullptr;
+      HIP_OK(hipMalloc((void**)&moments, 2 * total * 4));
+      HIP_OK(hipMemsetAsync(moments, 0, 2 * total * 4, st));
+      const float* pw[8 + 8 * DRIN_MAX_LAYERS] = {p.w_mention_text,  p.b_mention_text,  p.w_entity_text,  p.b_entity_text,
+                                                  p.w_mention_image, p.b_mention_image, p.w_entity_image, p.b_entity_image};
+      for (int l = 0; l < cfg.num_layers; ++l) {
+        const drin_layer_params& q = p.layer[l];
+        const float* row[8] = {q.w_h, q.b_h, q.w_u, q.b_u, q.w_v, q.b_v, q.ln_weight, q.ln_bias};
+        for (int j = 0; j < 8; ++j) pw[8 + 8 * l + j] = row[j];
+      }
+      const double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, eps = 1e-8, step = 1.0;
+      const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+      size_t off = 0;
+      for (size_t i = 0; i < sizes.size(); ++i) {
+        const int l = i < 8 ? -1 : (int)(i - 8) / 8, j = i < 8 ? -1 : (int)(i - 8) % 8;
+        const bool dead = l >= 0 && j >= 2 && j <= 5 && !(cfg.dynamic_edges && l + 1 < cfg.num_layers);   // no gradient: torch's Adam skips it
+        if (!dead)
+          DRIN_OK_(drin_adam_step(const_cast<float*>(pw[i]), gp[i], moments + off, moments + total + off, (int64_t)sizes[i],
+                                  (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
+                                  (float)((lr / bc1) * -1.0), st));
+        off += (sizes[i] + 63) & ~(size_t)63;
+      }
+      HIP_OK(hipStreamSynchronize(st));
+      for (size_t i = 0; i < sizes.size(); ++i) {
+        const size_t at = out.size();
+        out.resize(at + sizes[i]);
+        HIP_OK(hipMemcpy(out.data() + at, pw[i], sizes[i] * 4, hipMemcpyDeviceToHost));
+      }
+      (void)hipFree(moments);
+    }
     for (void* d : {tws, lws, (void*)scores_t, (void*)loss, (void*)d_scores, (void*)correct, (void*)arena}) (void)hipFree(d);
   }
   FILE* o = fopen(argv[2], "wb");

@@ -471,6 +471,22 @@ def test_c_abi_caller_without_torch(tmp_path, name):
                 assert not g_c.any(), name        # dead parameter: the C caller passed no buffer, its arena stayed zero
             else:
                 assert torch.allclose(g_c, g_t.cpu(), rtol=1e-4, atol=1e-7), (prec, name)
+        # (4) the optimiser step through drin_adam_step: the C caller's updated parameters == torch.optim.Adam's first step on
+        #     the C caller's own gradients, bit for bit; parameters without a gradient untouched
+        grads_c, at_g = {}, 2
+        for name, shape in synth.STATE_DICT_SHAPES(D, R, cfg.num_gcn_layers):
+            n = int(np.prod(shape))
+            grads_c[name] = rest[at_g:at_g + n].reshape(shape)
+            at_g += n
+        twin = {k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in sd.items()}
+        for k, q in twin.items():
+            q.grad = None if dict(layerwise.named_parameters())[k].grad is None else grads_c[k].to(DEV)
+        torch.optim.Adam(list(twin.values()), lr=1e-3).step()
+        for name, shape in synth.STATE_DICT_SHAPES(D, R, cfg.num_gcn_layers):
+            n = int(np.prod(shape))
+            p_c = rest[at:at + n].reshape(shape)
+            at += n
+            assert torch.equal(p_c, twin[name].detach().cpu()), (prec, name)
         assert at == rest.numel()
 
 

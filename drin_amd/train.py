@@ -363,7 +363,8 @@ def seed_everything(seed: int) -> None:
 
 
 def main(argv: Optional[Sequence[str]] = None) -> None:
-    """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I] [--on-device]"""
+    """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I] [--on-device]
+    [--precision bf16x3|f32] [--torch-adam] [--output-test-result PATH]; N GPUs: python -m torch.distributed.run --nproc-per-node N -m drin_amd.train ..."""
     import argparse
     import os
 
@@ -379,6 +380,10 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--global-batch-loss", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"], help="contraction arithmetic of the HIP Model")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the one-launch LibraryAdam (same arithmetic)")
+    ap.add_argument("--output-test-result", default=None, metavar="PATH",
+                    help="per-sample dump of the test split (args.output_test_result, train.py:16-17,40-43)")
     ap.add_argument("--on-device", action="store_true",
                     help="every split (and, wikimel, the entity tables) resident on the GPU (create_device_splits, load_entity_table): "
                          "no host gather, no host-to-device copy in the step")
@@ -398,8 +403,9 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
         loaders = create_device_splits(cfg, a.data, dev, a.batch_size, _rank(), _world(), mention_mmap="r")
     else:
         loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())
-    model = Model(cfg).to(dev)
-    runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print, entity_table=table)
+    model = Model(cfg, precision=a.precision).to(dev)
+    runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print, entity_table=table,
+                       library_adam=False if a.torch_adam else None, output_test_result=a.output_test_result)
     runner.fit(loaders, a.epochs, a.interval)
     if world > 1:
         dist.destroy_process_group()

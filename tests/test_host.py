@@ -232,3 +232,26 @@ def test_device_split_yields_the_indexed_loader_batches(tmp_path):
                 assert len(ba) == len(bb) == 15
                 for x, y in zip(ba, bb):
                     assert x.dtype == y.dtype and torch.equal(x, y)
+
+
+def test_shard_sampler_properties():
+    """For any split size, world size and epoch: padded shards have ONE length and together cover every index (a rank never
+    waits in a per-step collective for a rank that has run out of batches); unpadded shards partition the split exactly."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(n=st.integers(0, 300), world=st.integers(1, 9), shuffle=st.booleans(), epoch=st.integers(0, 5))
+    def check(n, world, shuffle, epoch):
+        padded, exact = [], []
+        for r in range(world):
+            a, b = ShardSampler(n, r, world, shuffle, 0, pad=True), ShardSampler(n, r, world, shuffle, 0)
+            a.set_epoch(epoch)
+            b.set_epoch(epoch)
+            padded.append(list(a))
+            exact.append(list(b))
+            assert len(a) == len(padded[-1]) and len(b) == len(exact[-1])
+        assert len({len(p) for p in padded}) == 1
+        assert set(sum(padded, [])) == set(range(n)) and len(sum(padded, [])) - n < world
+        assert sorted(sum(exact, [])) == list(range(n))
+
+    check()

@@ -104,7 +104,7 @@ class LibraryAdam:
     """`torch.optim.Adam(model.parameters(), lr)` of `train.py:55-56` (torch defaults) for a `drin_amd.model.Model`, as ONE
     launch of `drin_adam_step` over the model's flat parameter / gradient / moment buckets instead of torch's nine
     multi-tensor launches.  Same op sequence and per-op fp32 rounding as torch's default implementation, so a loop stepped
-    with it follows the reference's loop bit for bit (`tests/test_gpu_parity.py::test_library_adam_matches_torch_adam_bitwise`).
+    with it follows the reference's loop bit for bit (`tests/test_gpu_round2.py::test_library_adam_matches_torch_adam_bitwise`).
     Like torch's Adam it skips parameters whose `.grad` is None and creates its zero moments at the first step."""
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
@@ -117,6 +117,19 @@ class LibraryAdam:
 
     def describe(self) -> str:
         return "library Adam: one drin_adam_step launch over the flat parameter bucket (torch.optim.Adam arithmetic)"
+
+    def state_dict(self) -> dict:
+        """Step count, hyper-parameters and the two moment buckets (laid out like `Model.bucket_layout`)."""
+        return {"t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                "exp_avg": None if self.exp_avg is None else self.exp_avg.clone(),
+                "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.clone()}
+
+    def load_state_dict(self, state: dict) -> None:
+        self.t, self.lr, self.betas, self.eps = int(state["t"]), float(state["lr"]), tuple(state["betas"]), float(state["eps"])
+        self.param_groups[0]["lr"] = self.lr
+        dev = next(self.model.parameters()).device
+        self.exp_avg = None if state["exp_avg"] is None else state["exp_avg"].to(dev).clone()
+        self.exp_avg_sq = None if state["exp_avg_sq"] is None else state["exp_avg_sq"].to(dev).clone()
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.model.parameters():

@@ -168,6 +168,19 @@ def test_library_adam_loop_tracks_torch_adam_loop():
             _step_loss(m, batch, cfg).backward()
             o.step()
     assert oa.one_launch_steps == 5
+    # the optimiser state travels: a fresh LibraryAdam loaded with it continues the same trajectory
+    c, _, _ = _train_setup(cfg, 16, precision="f32")
+    c.load_state_dict(a.state_dict())
+    oc = make_adam(c, 1e-3)
+    oc.load_state_dict(oa.state_dict())
+    for m, o in ((a, oa), (c, oc)):
+        o.zero_grad(set_to_none=True)
+        _step_loss(m, batch, cfg).backward()
+        o.step()
+    assert oc.t == 6 and all(((p - q).abs() > 1e-6).float().mean().item() <= 1e-3 for p, q in zip(a.parameters(), c.parameters()))
+    ob.zero_grad(set_to_none=True)
+    _step_loss(b, batch, cfg).backward()
+    ob.step()
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         # (identical optimiser arithmetic; the two models' GRADIENTS may differ in the last bit where fp32 atomics add three or
         #  more partial sums in launch order, and Adam turns a last-bit difference of a near-zero entry into +-lr: allow a

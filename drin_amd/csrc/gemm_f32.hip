@@ -281,6 +281,56 @@ static int launch_small_splitk(const float* x, int64_t ldx, const float* w, int6
   return launch_splitk_reduce(scratch, used, part_stride, bias, y, ldy, M, N, accumulate, st);
 }
 
+// y[m, n] (+)= bias[n] + sum_k x[m, k] w[n, k] for ONE mention's rows (M <= 2: its text and image vertex).  A GEMV per row: one
+// wave per output column, the lanes stride over k in float4 steps (the weight row is read once, coalesced, and meets both
+// activation rows), wave reduction, lane 0 stores.  The MFMA tile kernel spends 12 + 4 us on such a product (24 tiles of
+// 64 x 64 walking K in slices, then the slice reduction); this is one launch of ~7 us - the scoring call of a single mention
+// is a chain of nine of them: 0.263 -> 0.210 ms (WikiMEL-shaped), 0.188 -> 0.155 ms (WikiDiverse-shaped).  Exact fp32 (fma
+// chain per lane, fixed reduction order).  Kept to the single-mention case on purpose: from two mentions up the host's
+// launch rate, not these products, bounds the call (measured at 4 mentions: kernel time -30 us, wall time unchanged), and
+// batches of any other size keep ONE summation order for their mention-sized products (a sub-batch scores bit-identically).
+template <int MR>
+__global__ void __launch_bounds__(256) k_gemv_rows(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                   int64_t ldw, const float* __restrict__ bias, float* __restrict__ y,
+                                                   int64_t ldy, int M, int N, int K4, int accumulate) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* wr = w + (int64_t)n * ldw;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  for (int c4 = lane; c4 < K4; c4 += 64) {
+    const float4 wv = ld4(wr + c4 * 4);
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+      if (m < M) acc[m] += dot4(ld4(x + (int64_t)m * ldx + c4 * 4), wv);
+  }
+  const float bv = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    if (m >= M) break;
+    const float s = wave_sum(acc[m]);
+    if (lane == 0) {
+      float* dst = y + (int64_t)m * ldy + n;
+      *dst = s + bv + (accumulate ? *dst : 0.f);
+    }
+  }
+}
+
+static bool gemv_fits(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t M, int K) {
+  return M >= 1 && M <= 2 && (K % 4) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0 && aligned16(x) && aligned16(w);
+}
+
+static int launch_gemv(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
+                       int64_t M, int N, int K, bool accumulate, hipStream_t st) {
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  const dim3 grid((unsigned)cdiv(N, 4));
+  hipLaunchKernelGGL(k_gemv_rows<2>, grid, dim3(256), 0, st, x, ldx, w, ldw, bias, y, ldy, (int)M, N, K / 4, accumulate ? 1 : 0);
+  DRIN_CHECK_LAUNCH("k_gemv_rows");
+  return DRIN_OK;
+}
+
 static bool small_splitk_fits(int64_t M, int N, int K, int64_t ldy, const float* y, float* scratch, size_t scratch_floats) {
   return scratch != nullptr && M <= 512 && K >= 512 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && aligned16(scratch) &&
          scratch_floats >= (size_t)2 * M * N;
@@ -304,6 +354,7 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
     set_error("gemm_nt: K=%d must be a multiple of 4", K);
     return DRIN_E_SHAPE;
   }
+  if (gemv_fits(x, ldx, w, ldw, M, K)) return launch_gemv(x, ldx, w, ldw, bias, y, ldy, M, N, K, accumulate, st);
   if (small_splitk_fits(M, N, K, ldy, y, splitk, splitk_floats))
     return launch_small_splitk<false>(x, ldx, w, ldw, bias, y, ldy, M, N, K, accumulate, splitk, splitk_floats, st, "gemm_nt");
   // mention-sized problems (a few hundred rows): 64 x 64 tiles give 4x the workgroups of 128 x 128 and

@@ -239,7 +239,9 @@ def test_forward_matches_reference_golden(golden_dir, name):
     with torch.no_grad():
         s2 = unfused(_to_dev(batch)).cpu()
         s3 = model(_to_dev(batch)).cpu()       # fused two-layer path where the geometry allows it
-    assert torch.equal(s2, out["scores"])
+    # (equal to fp32 re-association: with the last layer's image vertices skipped a product of one or two rows takes the
+    #  row-vector kernel where the traced call's four rows take the MFMA tile kernel)
+    assert (s2 - out["scores"]).abs().max().item() <= 2e-6
     err3 = np.abs(s3.numpy() - g["scores"]).max()
     print(f"{name}: fused-path max |score - reference| = {err3:.3e}")
     assert err3 <= 2e-5

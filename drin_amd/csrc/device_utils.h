@@ -114,6 +114,8 @@ __device__ __forceinline__ float act_apply(int id, float x) {
     default: return gelu_erf(x);
   }
 }
+// the edge activation on the folded inference kernels: the default stays the plain sigmoid expression it was
+__device__ __forceinline__ float edge_act_apply(int id, float x) { return id == 2 ? sigmoidf(x) : act_apply(id, x); }
 // derivative at the pre-activation z (LayerNorm backward recomputes z)
 __device__ __forceinline__ float act_grad(int id, float z) {
   switch (id) {

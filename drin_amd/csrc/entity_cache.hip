@@ -129,6 +129,7 @@ struct CachedArgs {
   float* c_part;                 // [B][chunks][2 D + 4]: sum e h for the two mention vertices, 4 edge sums
   float* s2_part;                // [B][chunks][2 D]: layer-2 mention aggregates
   int B, N, D4, R4, Km, chunks, ldfu, ldhm, dynamic;
+  int act_v, act_e;              // drin_activation of vertices / edges, resolved (gelu / sigmoid by default)
   float mask[4];
   float cos_eps, miei_eps, clip, ln_eps;
 };
@@ -139,7 +140,7 @@ struct CachedArgs {
 #endif
 // EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048) - the column guards of the row helpers fold away and the
 // loop body becomes straight-line code
-template <int DV, int RV, bool EXACT>
+template <int DV, int RV, bool EXACT, bool GENERIC_ACT = false>
 __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pairs(const CachedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D4 = EXACT ? DV * 64 : a.D4, R4 = EXACT ? RV * 64 : a.R4, D = D4 * 4, R = R4 * 4;
@@ -275,10 +276,10 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     // ---- layer-2 edges (model.py:148-153; static: pass-through, model.py:136) ------------------------------
     float n_tt = e_tt, n_ti = e_ti, n_it = e_it, n_ii = e_ii;
     if (dyn) {
-      n_tt = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvt, l_fu, lane, D4)) * inv_d + e_tt);
-      n_ti = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvi, l_fu, lane, D4)) * inv_d + e_ti);
-      n_it = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvt, l_fu + D, lane, D4)) * inv_d + e_it);
-      n_ii = sigmoidf(wave_sum(dot_row_lds<DV>(r.fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
+      n_tt = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvt, l_fu, lane, D4)) * inv_d + e_tt);
+      n_ti = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvi, l_fu, lane, D4)) * inv_d + e_ti);
+      n_it = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvt, l_fu + D, lane, D4)) * inv_d + e_it);
+      n_ii = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
     }
     n_tt *= a.mask[0];
     n_ti *= a.mask[1];
@@ -301,12 +302,12 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     sg_it += e_it;
     sg_ii += e_ii;
     // ---- layer-1 entity vertices (model.py:128,146) and the layer-2 mention aggregates ----------------------
-    const Row<DV> et1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4), l_gamma,
-                                            l_beta, lane, D4, a.ln_eps);
+    const Row<DV> et1 = ln_gelu_row_lds<DV, GENERIC_ACT>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4),
+                                                         l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
     if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
     if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
-    const Row<DV> ei1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4), l_gamma,
-                                            l_beta, lane, D4, a.ln_eps);
+    const Row<DV> ei1 = ln_gelu_row_lds<DV, GENERIC_ACT>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4),
+                                                         l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
     accumulate2(acc + 2 * D, n_tt, et1, n_ti, ei1);
   };
   {  // a chunk is one group of at most 16 candidates (chunks = ceil(N / 16))
@@ -420,11 +421,11 @@ static int cache_supported(const drin_config* c) {
   return DRIN_OK;
 }
 
-template <int DV, int RV, bool EXACT>
+template <int DV, int RV, bool EXACT, bool GENERIC_ACT = false>
 static int launch_cached_pairs_t(const CachedArgs& a, hipStream_t st) {
   const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;
   const size_t lds = sizeof(float) * (9 * D + R + 32 + 12 * D);
-  auto kern = k_cached_pairs<DV, RV, EXACT>;
+  auto kern = k_cached_pairs<DV, RV, EXACT, GENERIC_ACT>;
   static DynLdsOptIn opt_in;  // one per template instantiation
   if (lds > 48 * 1024)
     DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(cached_pairs)"));
@@ -626,7 +627,13 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   a.miei_eps = cfg->miei_eps;
   a.clip = cfg->clip_scale;
   a.ln_eps = cfg->layer_norm_eps;
-  if (a.D4 <= 64 && a.R4 <= 64)
+  a.act_v = vertex_act(cfg);
+  a.act_e = edge_act(cfg);
+  if (a.act_v != DRIN_ACT_GELU && a.D4 <= 64 && a.R4 <= 64)   // non-default vertex activation: the generic-width instantiations
+    DRIN_TRY((launch_cached_pairs_t<1, 1, false, true>(a, st)));
+  else if (a.act_v != DRIN_ACT_GELU)
+    DRIN_TRY((launch_cached_pairs_t<3, 8, false, true>(a, st)));
+  else if (a.D4 <= 64 && a.R4 <= 64)
     DRIN_TRY((launch_cached_pairs_t<1, 1, false>(a, st)));
   else if (a.D4 == 192 && a.R4 == 512)
     DRIN_TRY((launch_cached_pairs_t<3, 8, true>(a, st)));
@@ -641,12 +648,14 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
                        hmfu, 2 * D, pb + P.cb_t, pb + P.cb_i, L1.b_h, vm1, B, D, L.chunks, 1.0f / (float)N);
     DRIN_CHECK_LAUNCH("k_mention_layer1_cached");
   }
-  DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
+  DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st,
+                                 vertex_act(cfg)));
   DRIN_TRY(launch_gemm_nt(vm1, D, L2.w_h, D, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D, false, prec, st, sk, skf));
   // (4) layer-2 mention-text vertex
   DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
   DRIN_TRY(launch_gemm_nt(ws + L.agg2, D, L2.w_h, D, L2.b_h, ws + L.mt2, D, B, D, D, false, prec, st, sk, skf));
-  DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
+  DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st,
+                                 vertex_act(cfg)));
   // (5) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h2;
   if (planes) {
@@ -670,6 +679,7 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   fa.D4 = D / 4;
   fa.chunks = L.chunks;
   fa.ln_eps = cfg->layer_norm_eps;
+  fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;
   return launch_pair_final(fa, st);
 }

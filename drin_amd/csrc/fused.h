@@ -80,6 +80,7 @@ struct StreamArgs {
   float* s_img;                      //   written directly in the layout k_reduce_stream_partials would produce
   float* sig;
   int B, N, D4, R4, T, Km, Ke, chunks, ldq, ldfu, dynamic, bf16_features;
+  int act_e;                         // drin_activation of the edges, resolved (DRIN_ACT_SIGMOID by default)
   float mask[4];
   float cos_eps, miei_eps, clip;
 };
@@ -99,6 +100,7 @@ struct PairArgs {
   void* et1_lo;
   float* s2_part;        // [B][chunks][2 D]
   int B, N, D4, chunks, ldhm;
+  int act_v;             // drin_activation of the vertices, resolved (DRIN_ACT_GELU by default)
   float ln_eps;
 };
 
@@ -112,6 +114,7 @@ struct FinalArgs {
   const float* mt2;      // [B, D]
   float* scores;         // [M]
   int B, N, D4, chunks;
+  int act_v;             // drin_activation of the vertices, resolved
   float ln_eps, cos_eps;
 };
 

@@ -94,10 +94,6 @@ int fused_supported(const drin_config* c) {
     set_error("fused path: built for num_layers == 2 (got %d); use drin_forward", c->num_layers);
     return DRIN_E_UNSUPPORTED;
   }
-  if (vertex_act(c) != DRIN_ACT_GELU || edge_act(c) != DRIN_ACT_SIGMOID) {
-    set_error("fused path: built for the reference's default activations (gelu / sigmoid, args.py:35-36); use drin_forward");
-    return DRIN_E_UNSUPPORTED;
-  }
   if (c->vector_edges) {
     set_error("fused path: vector edge features (model.py:112-116) run on the layer-by-layer path; use drin_forward");
     return DRIN_E_UNSUPPORTED;
@@ -366,6 +362,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.Ke = cfg->entity_objects;
   sa.chunks = L.chunks;
   sa.dynamic = dyn ? 1 : 0;
+  sa.act_e = edge_act(cfg);
   sa.bf16_features = bf16_feat ? 1 : 0;
   for (int k = 0; k < 4; ++k) sa.mask[k] = cfg->edge_enabled[k];
   sa.cos_eps = cfg->cosine_eps;
@@ -383,7 +380,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_mention_input1(ws + L.tm, ws + L.tm2, ws + L.sig, params->b_entity_text, params->b_entity_image, vm0, ws + L.agg1, B, D, N, st));
   float* vm1 = ws + L.vm1;
   DRIN_TRY(lin(ws + L.agg1, D, L1.w_h, D, P.p_wh1, DD, L1.b_h, vm1, D, 2 * (int64_t)B, D, D));
-  DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st));
+  DRIN_TRY(launch_layernorm_gelu(vm1, L1.ln_weight, L1.ln_bias, vm1, nullptr, nullptr, 2 * (int64_t)B, D, cfg->layer_norm_eps, st,
+                                 vertex_act(cfg)));
   DRIN_TRY(lin(vm1, D, L2.w_h, D, P.p_wh2, DD, nullptr, ws + L.hm2, D, 2 * (int64_t)B, D, D));
   // (5) the two pair-sized layer-1 contractions on the folded weights
   // split-K scratch: the whole-product split when the batch is a few tiles, else the tail-split scratch
@@ -433,11 +431,13 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   pa.D4 = D / 4;
   pa.chunks = L.chunks;
   pa.ln_eps = cfg->layer_norm_eps;
+  pa.act_v = vertex_act(cfg);
   DRIN_TRY(launch_pair_layer1(pa, st));
   // (7) layer-2 mention-text vertex
   DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
   DRIN_TRY(lin(ws + L.agg2, D, L2.w_h, D, P.p_wh2, DD, L2.b_h, ws + L.mt2, D, B, D, D));
-  DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st));
+  DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st,
+                                 vertex_act(cfg)));
   // (8) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h_text;
   if (planes) {
@@ -462,6 +462,7 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   fa.D4 = D / 4;
   fa.chunks = L.chunks;
   fa.ln_eps = cfg->layer_norm_eps;
+  fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;
   return launch_pair_final(fa, st);
 }

@@ -172,10 +172,10 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       const float d_it = wave_sum(dot_row_lds<DV>(xt, l_mt + 2 * D, lane, D4));
       const float d_ti = wave_sum(dot_row_lds<RV>(xi, l_q, lane, R4));
       const float d_ii = wave_sum(dot_row_lds<RV>(xi, l_q + R, lane, R4));
-      n_tt = sigmoidf((d_tt + kap_tt) * inv_d + e_tt);
-      n_ti = sigmoidf((d_ti + kap_ti) * inv_d + e_ti);
-      n_it = sigmoidf((d_it + kap_it) * inv_d + e_it);
-      n_ii = sigmoidf((d_ii + kap_ii) * inv_d + e_ii);
+      n_tt = edge_act_apply(a.act_e, (d_tt + kap_tt) * inv_d + e_tt);
+      n_ti = edge_act_apply(a.act_e, (d_ti + kap_ti) * inv_d + e_ti);
+      n_it = edge_act_apply(a.act_e, (d_it + kap_it) * inv_d + e_it);
+      n_ii = edge_act_apply(a.act_e, (d_ii + kap_ii) * inv_d + e_ii);
     }
     if (lane == 0) {
       const int64_t M = (int64_t)a.B * a.N;
@@ -398,7 +398,7 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 //   et1[p] = gelu(LN(Hraw_t[p] + e_tt hm_t[b] + e_it hm_i[b] + c_t))          -> written (layer-2 GEMM operand)
 //   ei1[p] = gelu(LN(Hraw_i[p] + e_ti hm_t[b] + e_ii hm_i[b] + c_i))          -> registers only
 // and the layer-2 mention aggregates  S2_t[b] = sum_n e1_tt et1,  S2_i[b] = sum_n e1_ti ei1  per chunk.
-template <int DV, bool EXACT>
+template <int DV, bool EXACT, bool GENERIC_ACT = false>
 __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
   __shared__ __attribute__((aligned(16))) float l_red[2 * DV * 256];
   __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm_t, hm_i, c_t, c_i, gamma, beta
@@ -424,13 +424,13 @@ __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
     const Row<DV> ht = load_row_stream<DV>(a.h_text + p * D, lane, D4);  // read once: streaming cache policy
     const Row<DV> hi = load_row_stream<DV>(a.h_image + p * D, lane, D4);
     const float e_tt = a.e0m[p], e_ti = a.e0m[M + p], e_it = a.e0m[2 * M + p], e_ii = a.e0m[3 * M + p];
-    const Row<DV> et1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4), l_gamma,
-                                            l_beta, lane, D4, a.ln_eps);
+    const Row<DV> et1 = ln_gelu_row_lds<DV, GENERIC_ACT>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4),
+                                                         l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
     if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
     if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
     axpy_row<DV>(S_t, a.e1m[p], et1);
-    const Row<DV> ei1 = ln_gelu_row_lds<DV>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4), l_gamma,
-                                            l_beta, lane, D4, a.ln_eps);
+    const Row<DV> ei1 = ln_gelu_row_lds<DV, GENERIC_ACT>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4),
+                                                         l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
     axpy_row<DV>(S_i, a.e1m[M + p], ei1);
   }
   for (int w = 0; w < 4; ++w) {
@@ -456,7 +456,11 @@ __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
 int launch_pair_layer1(const PairArgs& a, hipStream_t st) {
   if (a.B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  if (a.D4 <= 64)
+  if (a.act_v != DRIN_ACT_GELU && a.D4 <= 64)          // non-default vertex activation (args.py:35): the generic-width instantiations
+    hipLaunchKernelGGL((k_pair_layer1<1, false, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.act_v != DRIN_ACT_GELU && a.D4 <= 192)
+    hipLaunchKernelGGL((k_pair_layer1<3, false, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 <= 64)
     hipLaunchKernelGGL((k_pair_layer1<1, false>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
   else if (a.D4 == 192)
     hipLaunchKernelGGL((k_pair_layer1<3, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
@@ -500,7 +504,7 @@ int launch_mention_input2(const float* part, const float* mt1, float* out, int B
 // Layer-2 entity-text vertex and the score (model.py:128 for et'', :207-209), grid (chunks, B), 256 threads:
 //   et2 = gelu(LN(H2raw[p] + e1_tt hm2_t[b] + e1_it hm2_i[b] + b_h2)),  score[p] = cos(mt2[b], et2)
 // The five per-mention / constant vectors live in LDS; each wave walks candidates of its chunk.
-template <int DV, bool EXACT>
+template <int DV, bool EXACT, bool GENERIC_ACT = false>
 __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
   __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm2_t, hm2_i, b_h2, gamma, beta, mt2
   const int D4 = EXACT ? DV * 64 : a.D4, D = D4 * 4;
@@ -522,9 +526,9 @@ __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
     const Row<DV> h = load_row_stream<DV>(a.h2 + p * D, lane, D4);
-    const Row<DV> et2 = ln_gelu_row_lds<DV>(
+    const Row<DV> et2 = ln_gelu_row_lds<DV, GENERIC_ACT>(
         combine_rows_lds<DV>(h, a.e1m[p], l_const, a.e1m[2 * M + p], l_const + LD, l_const + 2 * LD, lane, D4),
-        l_const + 3 * LD, l_const + 4 * LD, lane, D4, a.ln_eps);
+        l_const + 3 * LD, l_const + 4 * LD, lane, D4, a.ln_eps, a.act_v);
     const float xy = wave_sum(dot_rows<DV>(mt2, et2));
     const float yy = wave_sum(dot_rows<DV>(et2, et2));
     if (lane == 0) a.scores[p] = cosine_from_sums(xy, xx, yy, a.cos_eps);
@@ -534,7 +538,11 @@ __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
 int launch_pair_final(const FinalArgs& a, hipStream_t st) {
   if (a.B <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  if (a.D4 <= 64)
+  if (a.act_v != DRIN_ACT_GELU && a.D4 <= 64)          // non-default vertex activation (args.py:35): the generic-width instantiations
+    hipLaunchKernelGGL((k_pair_final<1, false, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.act_v != DRIN_ACT_GELU && a.D4 <= 192)
+    hipLaunchKernelGGL((k_pair_final<3, false, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
+  else if (a.D4 <= 64)
     hipLaunchKernelGGL((k_pair_final<1, false>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);
   else if (a.D4 == 192)
     hipLaunchKernelGGL((k_pair_final<3, true>), dim3((unsigned)a.chunks, (unsigned)a.B), dim3(256), 0, st, a);

@@ -98,10 +98,12 @@ __device__ __forceinline__ float dot_row_lds(const Row<V>& a, const float* lds, 
   return s;
 }
 
-// LayerNorm + GELU of one row held in registers (model.py:128), gamma / beta in LDS (per-workgroup constants)
-template <int DV>
+// LayerNorm + GELU of one row held in registers (model.py:128), gamma / beta in LDS (per-workgroup constants).
+// GENERIC_ACT: the vertex activation by id (`act`, drin_activation resolved) instead of the default's branch-free gelu -
+// a separate instantiation, so the default's code is what it was.
+template <int DV, bool GENERIC_ACT = false>
 __device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float* gamma, const float* beta, int lane,
-                                                   int D4, float eps) {
+                                                   int D4, float eps, int act = DRIN_ACT_GELU) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
@@ -123,10 +125,10 @@ __device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float
     const int c4 = lane + 64 * j;
     if (c4 < D4) {
       const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
-      y.v[j].x = gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
-      y.v[j].y = gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
-      y.v[j].z = gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
-      y.v[j].w = gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
+      y.v[j].x = GENERIC_ACT ? act_apply(act, (h.v[j].x - mu) * rstd * g.x + bt.x) : gelu_fast((h.v[j].x - mu) * rstd * g.x + bt.x);
+      y.v[j].y = GENERIC_ACT ? act_apply(act, (h.v[j].y - mu) * rstd * g.y + bt.y) : gelu_fast((h.v[j].y - mu) * rstd * g.y + bt.y);
+      y.v[j].z = GENERIC_ACT ? act_apply(act, (h.v[j].z - mu) * rstd * g.z + bt.z) : gelu_fast((h.v[j].z - mu) * rstd * g.z + bt.z);
+      y.v[j].w = GENERIC_ACT ? act_apply(act, (h.v[j].w - mu) * rstd * g.w + bt.w) : gelu_fast((h.v[j].w - mu) * rstd * g.w + bt.w);
     } else {
       y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }

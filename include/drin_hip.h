@@ -93,8 +93,8 @@ typedef struct {
 
 /* The reference resolves `getattr(torch.nn.functional, name)` (model.py:117-118) - any function name.  Built here: the
  * five below for the vertices; sigmoid, tanh and relu for the edges (their backward needs the derivative from the stored
- * OUTPUT; gelu / silu do not offer it).  Anything but the defaults runs on the layer-by-layer path (drin_forward /
- * drin_backward); the folded inference entry points return DRIN_E_UNSUPPORTED for it. */
+ * OUTPUT; gelu / silu do not offer it).  Every entry point takes them: the layer-by-layer forward / backward and the folded
+ * inference paths (whose default-activation kernels are separate instantiations, unchanged by the switch). */
 typedef enum {
   DRIN_ACT_DEFAULT = 0, /* gelu for vertex_activation, sigmoid for edge_activation (a zero-initialised config is the reference's) */
   DRIN_ACT_GELU = 1,    /* exact-erf gelu (F.gelu default)                                              */

@@ -143,7 +143,7 @@ def test_activation_ids_are_validated_on_host():
     assert lib.drin_fused_supported(C.byref(c)) == _lib.OK
     c.vertex_activation = _lib.ACTIVATIONS["relu"]
     assert lib.drin_workspace_bytes(C.byref(c), 1) > 0
-    assert lib.drin_fused_supported(C.byref(c)) == _lib.E_UNSUPPORTED     # the folded path is built for gelu / sigmoid
+    assert lib.drin_fused_supported(C.byref(c)) == _lib.OK                # the folded paths take the built activations too
     c.edge_activation = _lib.ACTIVATIONS["silu"]                          # no derivative-from-output: not built for edges
     assert lib.drin_workspace_bytes(C.byref(c), 1) == 0 and b"edge_activation" in lib.drin_last_error()
     c.edge_activation, c.vertex_activation = 0, 17

@@ -1045,7 +1045,10 @@ def test_bf16_stored_entity_table():
     dict(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=7, gcn_edge_enabled=(1, 0, 1, 1), **TINY),
     dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16,
          resnet_num_region=4),
-], ids=["tiny_tokens", "tiny_pooled", "tiny_static", "tiny_mask", "wikimel_dims"])
+    dict(num_candidates_data=20, gcn_vertex_activation="silu", gcn_edge_activation="tanh", **TINY),
+    dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16,
+         resnet_num_region=4, gcn_vertex_activation="relu", gcn_edge_activation="relu"),
+], ids=["tiny_tokens", "tiny_pooled", "tiny_static", "tiny_mask", "wikimel_dims", "tiny_silu_tanh", "wikimel_dims_relu"])
 def test_entity_cache_scores_match_oracle_and_uncached(kw):
     """Scoring from the per-entity cache == the oracle on the gathered 14-sequence (1e-5) == the un-cached
     table path (fp32 re-association only), for both precisions; a weight update rebuilds the cache."""
@@ -1060,7 +1063,8 @@ def test_entity_cache_scores_match_oracle_and_uncached(kw):
     cand = torch.randint(0, E, (B, N), generator=torch.Generator().manual_seed(3)).to(DEV)
     ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
     ref = O.forward(sd, [t.cpu() for t in ib.gathered()], dynamic=cfg.gcn_edge_type == "dynamic",
-                    edge_enabled=cfg.gcn_edge_enabled)
+                    edge_enabled=cfg.gcn_edge_enabled, vertex_activation=cfg.gcn_vertex_activation,
+                    edge_activation=cfg.gcn_edge_activation)
     for precision in ("bf16x3_all", "f32"):
         model = Model(cfg, precision=precision).to(DEV).eval()
         model.load_state_dict(sd)

@@ -794,14 +794,18 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     return p;
   };
   float* g_vm[2] = {carve(2 * BD), carve(2 * BD)};
-  float* g_ve[2] = {carve(2 * MD), carve(2 * MD)};
+  // entity-vertex gradients: one generation per level (g_ve[l + 1] = dL/dH of layer l, g_ve[0] = the vertex encoders'
+  // output gradient) - they are operands of the weight-gradient products, which run as ONE group at the end
+  float* g_ve[DRIN_MAX_LAYERS + 1];
+  for (int l = 0; l <= nl; ++l) g_ve[l] = carve(2 * MD);
   const bool vec = cfg->vector_edges != 0;
   const size_t EW = vec ? (size_t)D : 1, ES = M * EW;  // floats per edge per pair, stride between edge types
   float* g_e[2] = {carve(4 * ES), carve(4 * ES)};
   float* dA_m = carve(2 * BD);
   float* dA_e = carve(2 * MD);
   float* dfu = carve(2 * BD);
-  float* dfv = carve(2 * MD);
+  float* dfv_of[DRIN_MAX_LAYERS];   // per layer, for the same reason (the last layer has no live edge update)
+  for (int l = 0; l < (nl > 1 ? nl - 1 : 1); ++l) dfv_of[l] = carve(2 * MD);
   float* dpre = carve(4 * ES);
   float* cos_scratch = carve(3 * M);
   if ((size_t)(sp - (ws + L.bwd_scratch)) > L.bwd_scratch_floats) {
@@ -850,10 +854,29 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
   };
   ColsumBatch bias_sums;   // the bias gradients of W_u / W_v and of the vertex encoders: one launch
+  // dW (+)= dY^T X.  The pair-sized products of the whole pass (dW_h, dW_v of every layer, the two entity encoders) are
+  // collected and run as ONE launch at the end: alone, each deals its ~15-stage slices over the chip between a pipeline
+  // fill and a partial tile per workgroup; together the workgroups walk ~4x longer slices.  Mention-sized products
+  // (exact fp32) and the vector-edge ones (their operands are overwritten layer by layer) run where they arise.
+  TnGroup dw_group;
+  const bool defer_dw = x3 && !vec && tnp != nullptr;
+  auto dw_product = [&](const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, int64_t lddw, int64_t rows,
+                        int n_out, int k_red, const int64_t* x_index = nullptr) -> int {
+    if (dw == nullptr) return DRIN_OK;
+    if (defer_dw && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x)) {
+      if (dw_group.n == TnGroup::MAX) {   // deeper than three layers: the group goes in instalments
+        DRIN_TRY(launch_gemm_tn_group(dw_group, st, tnp, tnf));
+        dw_group = TnGroup();
+      }
+      return dw_group.add(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, x_index);
+    }
+    if (x_index != nullptr) return launch_gemm_tn_bf16x3(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, st, tnp, tnf, x_index);
+    return launch_gemm_tn(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, prec, st, tnp, tnf);
+  };
 
   // score = cos(mt_L, et_L) (model.py:207-209)
   int cur = 0;
-  DRIN_TRY(launch_cosine_bwd(ws + L.vm[nl], ws + L.ve[nl], grad_scores, g_vm[cur], g_ve[cur], cos_scratch, B, N, D,
+  DRIN_TRY(launch_cosine_bwd(ws + L.vm[nl], ws + L.ve[nl], grad_scores, g_vm[cur], g_ve[nl], cos_scratch, B, N, D,
                              cfg->cosine_eps, st));
   bool have_image = false;  // gradients w.r.t. the image vertices of the current level exist
   bool have_edge = false;   // gradients w.r.t. the current level's edges exist
@@ -864,7 +887,9 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     const int nxt = cur ^ 1;
     const int types = have_image ? 2 : 1;
     float* gm = g_vm[cur];  // dL/d(new mention vertices) -> dL/dH in place
-    float* ge = g_ve[cur];
+    float* ge = g_ve[l + 1];
+    float* ge_next = g_ve[l];
+    float* dfv = dfv_of[l < nl - 1 ? l : 0];
     const float* st_m = ws + L.ln_stat_m[l];
     const float* st_e = ws + L.ln_stat_e[l];
     // (a) LayerNorm + GELU backward; column sums give dgamma, dbeta and db_h
@@ -875,7 +900,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     // (b) dW_h += dH^T A
     if (G.w_h) {
       DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st, tnp, tnf));
-      DRIN_TRY(launch_gemm_tn(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D, prec, st, tnp, tnf));
+      DRIN_TRY(dw_product(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D));
     }
     // (c) dA = dH W_h
     DRIN_TRY(gemm_nn(gm, D, W.w_h, dA_m, D, (int64_t)types * B, D, D, false));
@@ -919,7 +944,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
         DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
         DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
       }
-      if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, prec, st, tnp, tnf));
+      DRIN_TRY(dw_product(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D));
       DRIN_TRY(bias_sums.add(dfv, G.b_v, 2 * (int64_t)M, D));
       if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st, tnp, tnf));
       DRIN_TRY(bias_sums.add(dfu, G.b_u, 2 * (int64_t)B, D));
@@ -930,9 +955,9 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     if (vec) {
       const int H = D / 2;
       // (e) entity side of the aggregation backward + edge gradients, element-wise with vector edges
-      DRIN_TRY(launch_entity_side_bwd_vec(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt],
-                                          g_ve[nxt] + MD, g_e[nxt], B, N, D, cfg->edge_enabled, st));
-      if (edge_update) DRIN_TRY(gemm_nn(dfv, H, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, H, true));
+      DRIN_TRY(launch_entity_side_bwd_vec(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, ge_next,
+                                          ge_next + MD, g_e[nxt], B, N, D, cfg->edge_enabled, st));
+      if (edge_update) DRIN_TRY(gemm_nn(dfv, H, W.w_v, ge_next, D, 2 * (int64_t)M, D, H, true));
       // (f) mention side
       DRIN_TRY(launch_mention_reduce_vec(e, dA_et, e + ES, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, false, st));
       DRIN_TRY(launch_mention_reduce_vec(e + 2 * ES, dA_et, e + 3 * ES, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, false, st));
@@ -940,8 +965,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     } else {
       // (e) entity side of the aggregation backward + edge gradients
       // (the edge update's dfv W_v goes first and the row kernel adds onto it)
-      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, g_ve[nxt], D, 2 * (int64_t)M, D, D, false, pre_t ? wt_slot(l, 1) : nullptr));
-      DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, g_ve[nxt], g_ve[nxt] + MD,
+      if (edge_update) DRIN_TRY(gemm_nn(dfv, D, W.w_v, ge_next, D, 2 * (int64_t)M, D, D, false, pre_t ? wt_slot(l, 1) : nullptr));
+      DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, ge_next, ge_next + MD,
                                       g_e[nxt], B, N, D, cfg->edge_enabled, edge_update, st));
       // (f) mention side
       if (B <= 65535) {
@@ -966,29 +991,20 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   // VertexEncoder (model.py:26-46): four Linears over the pooled inputs
   const float* g_mt = g_vm[cur];
   const float* g_mi = g_vm[cur] + BD;
-  const float* g_et = g_ve[cur];
-  const float* g_ei = g_ve[cur] + MD;
+  const float* g_et = g_ve[0];
+  const float* g_ei = g_ve[0] + MD;
   if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st, tnp, tnf));
   DRIN_TRY(bias_sums.add(g_mt, grads->b_mention_text, B, D));
-  if (grads->w_entity_text) {
-    if (eidx)
-      DRIN_TRY(launch_gemm_tn_bf16x3(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, st, tnp, tnf, eidx));
-    else
-      DRIN_TRY(launch_gemm_tn(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, prec, st, tnp, tnf));
-  }
+  DRIN_TRY(dw_product(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, eidx));
   DRIN_TRY(bias_sums.add(g_et, grads->b_entity_text, (int64_t)M, D));
   if (have_image) {
     if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st, tnp, tnf));
     DRIN_TRY(bias_sums.add(g_mi, grads->b_mention_image, B, D));
-    if (grads->w_entity_image) {
-      if (eidx)
-        DRIN_TRY(launch_gemm_tn_bf16x3(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, st, tnp, tnf, eidx));
-      else
-        DRIN_TRY(launch_gemm_tn(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, prec, st, tnp, tnf));
-    }
+    DRIN_TRY(dw_product(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, eidx));
     DRIN_TRY(bias_sums.add(g_ei, grads->b_entity_image, (int64_t)M, D));
   }
-  return launch_colsum_batch(bias_sums, st);
+  DRIN_TRY(launch_colsum_batch(bias_sums, st));
+  return launch_gemm_tn_group(dw_group, st, tnp, tnf);
 }
 
 }  // extern "C"

@@ -36,6 +36,9 @@ constexpr int THREADS = 512;
 constexpr int PLANE = TILE * 64;             // one bf16 plane of one operand: 256 rows x 64 B
 constexpr int BUF_BYTES = 4 * PLANE;         // A hi, A lo, B hi, B lo
 constexpr int LDS_BYTES = 2 * BUF_BYTES;     // double buffered: 128 KiB
+// (Measured and not adopted, same box: 128 x 128 tiles with four waves of 64 x 64 and TWO workgroups per CU - a quarter of
+//  the slices, half the partial-tile traffic: B = 64 step 0.845 against 0.835 ms of split-bf16 GEMM time, B = 512 4.90
+//  against 4.47.)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return ((((row & 3) * (TILE / 4)) + (row >> 2)) << 6) + ((chunk ^ (row & 3)) << 4);
@@ -43,10 +46,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 
 // 32 (m) x 256 (columns) fp32 staged by 512 threads: lane = (m-group mg = lane >> 3, column group cgl = lane & 7),
 // wave w covers column groups 8 w .. 8 w + 7; a column group is 4 adjacent columns.
-// INDEXED: reduction row m of the operand is row index[m] of a TABLE (the entity tables of table-form training: the
+// index != NULL: reduction row m of the operand is row index[m] of a TABLE (the entity tables of table-form training: the
 // vertex-encoder inputs are gathered here instead of being materialised per step).  The indices of the NEXT stage are
 // fetched one call ahead, so the dependent address -> data chain never sits inside a stage.
-template <bool INDEXED>
 struct TransposeStager {
   const float* p;   // first row of the reduction range (or of the table), this thread's column
   int64_t ld;
@@ -65,7 +67,7 @@ struct TransposeStager {
     p = src + col;
     ld = ld_;
     index = index_;
-    if (INDEXED) {
+    if (index != nullptr) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t m = m_first + 4 * mg + i;
@@ -80,10 +82,10 @@ struct TransposeStager {
     for (int i = 0; i < 4; ++i) {
       const int64_t m = m0 + 4 * mg + i;
       const bool live = m < m_end;
-      const int64_t row = INDEXED ? next_row[i] : (live ? m : m_end - 1);
+      const int64_t row = index != nullptr ? next_row[i] : (live ? m : m_end - 1);
       const float4 x = ld4(p + row * ld);
       v[i] = live ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (INDEXED) {
+      if (index != nullptr) {
         const int64_t mn = m + BK;
         next_row[i] = index[mn < m_end ? mn : m_end - 1];
       }
@@ -109,15 +111,47 @@ struct TransposeStager {
   }
 };
 
-// grid: x = output tile (n-tile major), y = slice of the reduction
-template <bool B_INDEXED>
-__global__ void __launch_bounds__(THREADS, 1)
-    k_gemm_tn_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
-                     float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, int64_t rows_per_slice, int k_tiles,
-                     float* __restrict__ partial, const int64_t* __restrict__ b_index) {
+// One launch runs a GROUP of such products (TnGroup, internal.h: the pair-sized weight gradients of a backward pass).
+// grid: 1-D; a problem's work items are (slice of the reduction, output tile n-tile major), tile fastest; problems in order.
+struct Problem {
+  const float* a;
+  const float* b;
+  float* y;
+  float* partial;            // [slices][N][K] partial tiles, or NULL: fp32 atomics onto y
+  const int64_t* b_index;
+  int64_t lda, ldb, ldy, M, rows_per_slice;
+  int N, K, k_tiles, tiles;
+  unsigned first;            // first work item
+  int slices;
+};
+struct GroupArgs {
+  Problem p[TnGroup::MAX];
+  int n;
+};
+
+__global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n0 = (blockIdx.x / k_tiles) * TILE, k0 = (blockIdx.x % k_tiles) * TILE;
-  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_slice;
+  // XCD-aware order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  All
+  // tiles of one slice read the same rows of both operands (fp32: a slice is megabytes), so XCD x takes a contiguous range
+  // of the work-item sequence - a slice's rows then come through ONE L2 instead of up to eight.
+  unsigned t = blockIdx.x;
+  {
+    const unsigned total = gridDim.x, xcd = t & 7, k = t >> 3, q = total >> 3, rem = total & 7;
+    t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  }
+  int pi = 0;
+  for (int i = 1; i < g.n; ++i) pi = t >= g.p[i].first ? i : pi;
+  const Problem& P = g.p[pi];
+  const float* __restrict__ A = P.a;
+  const float* __restrict__ Bm = P.b;
+  float* __restrict__ Y = P.y;
+  float* __restrict__ partial = P.partial;
+  const int64_t lda = P.lda, ldb = P.ldb, ldy = P.ldy, M = P.M, rows_per_slice = P.rows_per_slice;
+  const int N = P.N, K = P.K, k_tiles = P.k_tiles, tiles = P.tiles;
+  t -= P.first;
+  const unsigned slice = t / (unsigned)tiles, tile = t - slice * (unsigned)tiles;
+  const int n0 = (int)(tile / (unsigned)k_tiles) * TILE, k0 = (int)(tile % (unsigned)k_tiles) * TILE;
+  const int64_t m_begin = (int64_t)slice * rows_per_slice;
   const int64_t m_end = m_begin + rows_per_slice < M ? m_begin + rows_per_slice : M;
   const int nkb = (int)((m_end - m_begin + BK - 1) / BK);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -133,10 +167,9 @@ __global__ void __launch_bounds__(THREADS, 1)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
-  TransposeStager<false> sa;
-  TransposeStager<B_INDEXED> sb;
+  TransposeStager sa, sb;
   sa.init(A, lda, n0, N);
-  sb.init(Bm, ldb, k0, K, b_index, m_begin, m_end);
+  sb.init(Bm, ldb, k0, K, P.b_index, m_begin, m_end);
   sa.load(m_begin, m_end);
   sb.load(m_begin, m_end);
   sa.store(smem, smem + PLANE);
@@ -165,9 +198,10 @@ __global__ void __launch_bounds__(THREADS, 1)
       const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + PLANE + off);
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        // the k-side fragment is the FIRST operand: a lane then holds four consecutive k of one n - one 16-byte store
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -194,33 +228,43 @@ __global__ void __launch_bounds__(THREADS, 1)
     __syncthreads();
   }
 
-  // C / D of a 16 x 16 tile: column lane & 15, rows 4 (lane >> 4) + v
+  // C / D of a 16 x 16 tile (operands swapped above): n = lane & 15, k = 4 (lane >> 4) + v
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const int nrow = n0 + wm * 128 + i * 16 + r;
+    if (nrow >= N) continue;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int kcol = k0 + wn * 64 + j * 16 + r;
-      if (kcol >= K) continue;
+      const int kcol = k0 + wn * 64 + j * 16 + c * 4;
+      if (kcol >= K) continue;  // K % 4 == 0: a group of four is inside or outside as a whole
+      if (partial != nullptr) {
+        st4(partial + ((int64_t)slice * N + nrow) * K + kcol, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+      } else {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int nrow = n0 + wm * 128 + i * 16 + c * 4 + v;
-        if (nrow >= N) continue;
-        if (partial != nullptr)
-          partial[((int64_t)blockIdx.y * N + nrow) * K + kcol] = acc[i][j][v];
-        else
-          unsafeAtomicAdd(Y + (int64_t)nrow * ldy + kcol, acc[i][j][v]);
+        for (int v = 0; v < 4; ++v) unsafeAtomicAdd(Y + (int64_t)nrow * ldy + kcol + v, acc[i][j][v]);
       }
     }
+  }
 }
 
-// y[n, k] += sum_slices partial[slice][n][k], slices in order
-__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ partial, int slices, float* __restrict__ Y,
-                                                   int64_t ldy, int N, int K4) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// y[n, k] += sum_slices partial[slice][n][k], slices in order; every problem of the group in one launch
+struct ReduceArgs {
+  const float* partial[TnGroup::MAX];
+  float* y[TnGroup::MAX];
+  int64_t ldy[TnGroup::MAX];
+  int N[TnGroup::MAX], K4[TnGroup::MAX], slices[TnGroup::MAX];
+  unsigned first[TnGroup::MAX];   // first block
+  int n;
+};
+__global__ void __launch_bounds__(256) k_tn_reduce(const ReduceArgs g) {
+  int pi = 0;
+  for (int i = 1; i < g.n; ++i) pi = blockIdx.x >= g.first[i] ? i : pi;
+  const int N = g.N[pi], K4 = g.K4[pi], slices = g.slices[pi];
+  const int64_t i = (int64_t)(blockIdx.x - g.first[pi]) * 256 + threadIdx.x;
   if (i >= (int64_t)N * K4) return;
   const int n = (int)(i / K4), c4 = (int)(i - (int64_t)n * K4);
   const int64_t stride = (int64_t)N * K4 * 4;
-  const float* p = partial + (int64_t)n * K4 * 4 + (int64_t)c4 * 4;
+  const float* p = g.partial[pi] + (int64_t)n * K4 * 4 + (int64_t)c4 * 4;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
   int z = 0;
   for (; z + 2 <= slices; z += 2) {  // two chains, fixed association
@@ -228,7 +272,7 @@ __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ par
     s1 = s1 + ld4(p + (z + 1) * stride);
   }
   if (z < slices) s0 = s0 + ld4(p + z * stride);
-  float* dst = Y + (int64_t)n * ldy + c4 * 4;
+  float* dst = g.y[pi] + (int64_t)n * g.ldy[pi] + c4 * 4;
   st4(dst, ld4(dst) + (s0 + s1));
 }
 
@@ -239,51 +283,96 @@ bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, cons
          aligned16(a) && aligned16(b);
 }
 
-int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
-                          int N, int K, hipStream_t st, float* scratch, size_t scratch_floats, const int64_t* b_index) {
-  if (M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
+int TnGroup::add(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K,
+                 const int64_t* b_index) {
+  if (y == nullptr || M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
   if (!gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b)) {
     set_error("gemm_tn_bf16x3: shape M=%lld N=%d K=%d / alignment outside the kernel's contract", (long long)M, N, K);
     return DRIN_E_SHAPE;
   }
-  const int n_tiles = (int)cdiv(N, x3tn::TILE), k_tiles = (int)cdiv(K, x3tn::TILE);
-  const int tiles = n_tiles * k_tiles;
-  // One workgroup per CU in all (the 128 KiB tile buffers allow one per CU at a time): every extra slice adds
-  // 65 536 fp32 atomics per tile and a pipeline fill, which at M ~ 10^4 cost more than the MFMA work itself
-  // (measured at M = 12 928: 86 slices 162 us, 28 slices see DESIGN.md).  A slice is a whole number of 32-row stages.
-  int64_t slices = tiles >= 256 ? 1 : 256 / tiles;
-  int64_t rows = cdiv(cdiv(M, slices), x3tn::BK) * x3tn::BK;
-  if (rows < 4 * x3tn::BK) rows = 4 * x3tn::BK;
-  slices = cdiv(M, rows);
-  if (slices > 65535) {
-    set_error("gemm_tn_bf16x3: %lld reduction slices exceed the grid limit", (long long)slices);
+  if (n == MAX) {
+    set_error("internal: more than %d weight-gradient products in one group", MAX);
+    return DRIN_E_SHAPE;
+  }
+  item[n++] = {a, lda, b, ldb, y, ldy, M, N, K, b_index};
+  return DRIN_OK;
+}
+
+int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, size_t scratch_floats) {
+  if (grp.n == 0) return DRIN_OK;
+  // One workgroup per CU in all (the 128 KiB tile buffers allow one per CU at a time): every extra slice adds a pipeline
+  // fill and a 256 KiB partial tile (or 65 536 fp32 atomics), which at M ~ 10^4 cost more than the MFMA work itself
+  // (measured at M = 12 928: 86 slices 162 us, 28 slices 92 us).  So the chip's 256 workgroups are dealt over ALL the
+  // products of the group in proportion to their work: one target slice length, a whole number of 32-row stages,
+  // grown until the group fits.  (Five products of one B = 64 backward pass: slices of ~62 stages instead of 15, same box
+  // 0.835 -> 0.74 ms of split-bf16 GEMM time per step; at B = 512, 58 .. 160 stages per slice already, neither better nor worse.)
+  int tiles[TnGroup::MAX];
+  int64_t work = 0, longest = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    const auto& it = grp.item[i];
+    tiles[i] = (int)(cdiv(it.N, x3tn::TILE) * cdiv(it.K, x3tn::TILE));
+    work += (int64_t)tiles[i] * it.M;
+    longest = it.M > longest ? it.M : longest;
+  }
+  int64_t target = cdiv(cdiv(work, 256), x3tn::BK) * x3tn::BK;
+  if (target < 4 * x3tn::BK) target = 4 * x3tn::BK;
+  for (;; target += x3tn::BK) {
+    int64_t wgs = 0;
+    for (int i = 0; i < grp.n; ++i) wgs += tiles[i] * cdiv(grp.item[i].M, target);
+    if (wgs <= 256 || target >= longest) break;
+  }
+  x3tn::GroupArgs ga;
+  x3tn::ReduceArgs ra;
+  ga.n = ra.n = grp.n;
+  int64_t items = 0, blocks = 0;
+  size_t part = 0;
+  bool two_stage = scratch != nullptr && aligned16(scratch);
+  for (int i = 0; i < grp.n; ++i) {
+    const auto& it = grp.item[i];
+    int64_t slices = cdiv(it.M, target);
+    const int64_t rows = cdiv(cdiv(it.M, slices), x3tn::BK) * x3tn::BK;   // equal slices of this product
+    slices = cdiv(it.M, rows);
+    auto& P = ga.p[i];
+    P.a = it.a, P.b = it.b, P.y = it.y, P.b_index = it.b_index;
+    P.lda = it.lda, P.ldb = it.ldb, P.ldy = it.ldy, P.M = it.M, P.rows_per_slice = rows;
+    P.N = it.N, P.K = it.K, P.k_tiles = (int)cdiv(it.K, x3tn::TILE), P.tiles = tiles[i];
+    P.first = (unsigned)items, P.slices = (int)slices;
+    P.partial = scratch != nullptr ? scratch + part : nullptr;
+    items += slices * tiles[i];
+    part += (size_t)slices * it.N * it.K;
+    two_stage = two_stage && (it.ldy % 4) == 0 && aligned16(it.y);
+    ra.partial[i] = P.partial, ra.y[i] = it.y, ra.ldy[i] = it.ldy, ra.N[i] = it.N, ra.K4[i] = it.K / 4, ra.slices[i] = (int)slices;
+    ra.first[i] = (unsigned)blocks;
+    blocks += cdiv((int64_t)it.N * (it.K / 4), 256);
+  }
+  two_stage = two_stage && part <= scratch_floats;
+  if (!two_stage)
+    for (int i = 0; i < grp.n; ++i) ga.p[i].partial = nullptr;
+  if (items > (int64_t)1 << 30) {
+    set_error("gemm_tn_bf16x3: %lld work items exceed the grid limit", (long long)items);
     return DRIN_E_SHAPE;
   }
   {
-    static DynLdsOptIn opt_in[2];
-    DRIN_TRY(ensure_dynamic_lds(opt_in[0], reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<false>), x3tn::LDS_BYTES,
-                                "hipFuncSetAttribute(gemm_tn_bf16x3)"));
-    DRIN_TRY(ensure_dynamic_lds(opt_in[1], reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<true>), x3tn::LDS_BYTES,
+    static DynLdsOptIn opt_in;
+    DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3), x3tn::LDS_BYTES,
                                 "hipFuncSetAttribute(gemm_tn_bf16x3)"));
   }
-  const bool two_stage = scratch != nullptr && slices > 1 && (size_t)slices * N * K <= scratch_floats && (ldy % 4) == 0 &&
-                         aligned16(y) && aligned16(scratch);
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
-  if (b_index != nullptr)
-    hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3<true>, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS),
-                       x3tn::LDS_BYTES, st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles,
-                       two_stage ? scratch : (float*)nullptr, b_index);
-  else
-    hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3<false>, dim3((unsigned)tiles, (unsigned)slices), dim3(x3tn::THREADS),
-                       x3tn::LDS_BYTES, st, a, lda, b, ldb, y, ldy, M, N, K, rows, k_tiles,
-                       two_stage ? scratch : (float*)nullptr, b_index);
+  hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)items), dim3(x3tn::THREADS), x3tn::LDS_BYTES, st, ga);
   DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
   if (two_stage) {
-    hipLaunchKernelGGL(x3tn::k_tn_reduce, dim3((unsigned)cdiv((int64_t)N * (K / 4), 256)), dim3(256), 0, st, scratch, (int)slices,
-                       y, ldy, N, K / 4);
+    hipLaunchKernelGGL(x3tn::k_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, st, ra);
     DRIN_CHECK_LAUNCH("k_tn_reduce");
   }
   return DRIN_OK;
+}
+
+int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
+                          int N, int K, hipStream_t st, float* scratch, size_t scratch_floats, const int64_t* b_index) {
+  if (M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
+  TnGroup one;
+  DRIN_TRY(one.add(a, lda, b, ldb, y, ldy, M, N, K, b_index));
+  return launch_gemm_tn_group(one, st, scratch, scratch_floats);
 }
 
 }  // namespace drin

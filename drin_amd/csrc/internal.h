@@ -119,6 +119,24 @@ int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t l
                           int N, int K, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0,
                           const int64_t* b_index = nullptr);
 // (b_index: reduction row m of b is row b_index[m] of a table - the gathered form never materialised)
+// up to 8 such products in ONE launch (+ one for the slice reduction): the chip's workgroups are dealt over all of them
+struct TnGroup {
+  static constexpr int MAX = 8;
+  struct Item {
+    const float* a;
+    int64_t lda;
+    const float* b;
+    int64_t ldb;
+    float* y;
+    int64_t ldy, M;
+    int N, K;
+    const int64_t* b_index;
+  } item[MAX];
+  int n = 0;
+  int add(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K,
+          const int64_t* b_index = nullptr);   // no-op for y == NULL; DRIN_E_SHAPE outside gemm_tn_bf16x3_fits or past MAX
+};
+int launch_gemm_tn_group(const TnGroup& g, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 // (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,

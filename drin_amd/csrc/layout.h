@@ -102,13 +102,14 @@ struct Layout {
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
       wt = take(((size_t)2 * nl + 1) * D * D);   // slots 2 l, 2 l + 1: W_h^T, W_v^T of layer l; slot 2 nl: the product in flight
       ln_part = take((1024 + 16) * 3 * D);
-      {  // one workgroup per CU: 256 / tiles slices of the largest product (D x D: 9 tiles at 768; D x R: 24)
-        const size_t t_dd = ((D + 255) / 256) * ((D + 255) / 256), t_dr = ((D + 255) / 256) * ((R + 255) / 256);
-        const size_t s_dd = t_dd >= 256 ? 1 : 256 / t_dd, s_dr = t_dr >= 256 ? 1 : 256 / t_dr;
-        tn_part_floats = s_dd * D * D > s_dr * D * R ? s_dd * D * D : s_dr * D * R;
+      {  // one workgroup per CU over the whole group of weight-gradient products (launch_gemm_tn_group): at most 256 partial
+        // tiles of 256 x 256 - or, where one product alone has more tiles than that, one slice of each product
+        const size_t one_slice = ((size_t)2 * nl + 1) * D * D + D * R;
+        tn_part_floats = (size_t)256 * 65536 > one_slice ? (size_t)256 * 65536 : one_slice;
         tn_part = take(tn_part_floats);
       }
-      bwd_scratch_floats = 4 * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
+      // backward temporaries: entity-vertex gradients per level (nl + 1) + dA_e + dfv per layer; mention side x4; edges x3
+      bwd_scratch_floats = ((size_t)2 * nl + 2) * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
       bwd_scratch = take(bwd_scratch_floats);
     } else {
       size_t e2[2] = {take(4 * M * EW), take(4 * M * EW)};

@@ -631,7 +631,7 @@ def test_backward_bf16x3_vs_oracle_autograd():
     loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], model(dbatch[:-1]))
     grads = _grads_of(model, loss)
     prof = _lib.profile_end()
-    assert prof["gemm_x3"][1] >= 10, "forward and backward pair-sized contractions should run split-bf16"
+    assert prof["gemm_x3"][1] >= 9, "forward and backward pair-sized contractions should run split-bf16 (the weight gradients as one group)"
     assert abs(loss.item() - ref_loss.item()) <= 1e-5
     worst = 0.0
     for (k, got), r in zip(grads.items(), ref):

@@ -860,15 +860,21 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   // (exact fp32) and the vector-edge ones (their operands are overwritten layer by layer) run where they arise.
   TnGroup dw_group;
   const bool defer_dw = x3 && !vec && tnp != nullptr;
+  // (db: the bias gradient that goes with it = the column sums of dy; the group takes them from the rows it stages)
   auto dw_product = [&](const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, int64_t lddw, int64_t rows,
-                        int n_out, int k_red, const int64_t* x_index = nullptr) -> int {
+                        int n_out, int k_red, const int64_t* x_index = nullptr, float* db = nullptr) -> int {
+    const bool grouped = dw != nullptr && defer_dw && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x);
+    if (db != nullptr && !(grouped && lddy == n_out)) {
+      DRIN_TRY(bias_sums.add(dy, db, rows, n_out));
+      db = nullptr;
+    }
     if (dw == nullptr) return DRIN_OK;
-    if (defer_dw && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x)) {
+    if (grouped) {
       if (dw_group.n == TnGroup::MAX) {   // deeper than three layers: the group goes in instalments
         DRIN_TRY(launch_gemm_tn_group(dw_group, st, tnp, tnf));
         dw_group = TnGroup();
       }
-      return dw_group.add(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, x_index);
+      return dw_group.add(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, x_index, db);
     }
     if (x_index != nullptr) return launch_gemm_tn_bf16x3(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, st, tnp, tnf, x_index);
     return launch_gemm_tn(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, prec, st, tnp, tnf);
@@ -944,8 +950,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
         DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
         DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
       }
-      DRIN_TRY(dw_product(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D));
-      DRIN_TRY(bias_sums.add(dfv, G.b_v, 2 * (int64_t)M, D));
+      DRIN_TRY(dw_product(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, nullptr, G.b_v));
       if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st, tnp, tnf));
       DRIN_TRY(bias_sums.add(dfu, G.b_u, 2 * (int64_t)B, D));
       de_extra = dpre;
@@ -995,13 +1000,11 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   const float* g_ei = g_ve[0] + MD;
   if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st, tnp, tnf));
   DRIN_TRY(bias_sums.add(g_mt, grads->b_mention_text, B, D));
-  DRIN_TRY(dw_product(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, eidx));
-  DRIN_TRY(bias_sums.add(g_et, grads->b_entity_text, (int64_t)M, D));
+  DRIN_TRY(dw_product(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, eidx, grads->b_entity_text));
   if (have_image) {
     if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st, tnp, tnf));
     DRIN_TRY(bias_sums.add(g_mi, grads->b_mention_image, B, D));
-    DRIN_TRY(dw_product(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, eidx));
-    DRIN_TRY(bias_sums.add(g_ei, grads->b_entity_image, (int64_t)M, D));
+    DRIN_TRY(dw_product(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, eidx, grads->b_entity_image));
   }
   DRIN_TRY(launch_colsum_batch(bias_sums, st));
   return launch_gemm_tn_group(dw_group, st, tnp, tnf);

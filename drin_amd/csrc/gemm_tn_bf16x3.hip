@@ -91,6 +91,8 @@ struct TransposeStager {
       }
     }
   }
+  // the sum over m of this thread's four columns, of everything staged so far (rows past m_end were loaded as zeros)
+  __device__ __forceinline__ void add_to(float4& s) const { s = s + ((v[0] + v[1]) + (v[2] + v[3])); }
   __device__ __forceinline__ void store(char* __restrict__ hi_plane, char* __restrict__ lo_plane) const {
     const float col[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x},
                              {v[0].y, v[1].y, v[2].y, v[3].y},
@@ -123,6 +125,8 @@ struct Problem {
   int N, K, k_tiles, tiles;
   unsigned first;            // first work item
   int slices;
+  float* colsum;             // optional: column sums of a (the bias gradient that goes with dW = dY^T X) ...
+  float* colsum_partial;     // ... as [slices][N] partial rows, or NULL: fp32 atomics onto colsum
 };
 struct GroupArgs {
   Problem p[TnGroup::MAX];
@@ -172,6 +176,10 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
   sb.init(Bm, ldb, k0, K, P.b_index, m_begin, m_end);
   sa.load(m_begin, m_end);
   sb.load(m_begin, m_end);
+  // the workgroups of the first k-tile also sum the columns of a (they stage every row of their n-tile exactly once)
+  const bool sums = P.colsum != nullptr && k0 == 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sums) sa.add_to(csum);
   sa.store(smem, smem + PLANE);
   sb.store(smem + 2 * PLANE, smem + 3 * PLANE);
   if (nkb > 1) {
@@ -217,6 +225,7 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
     load_b(buf);
     row_tiles(buf, 0, MI / 2);
     if (more) {
+      if (sums) sa.add_to(csum);
       sa.store(nb, nb + PLANE);
       sb.store(nb + 2 * PLANE, nb + 3 * PLANE);
       if (kb + 2 < nkb) {
@@ -228,6 +237,26 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
     __syncthreads();
   }
 
+  if (sums) {  // the eight m-groups of a column group sit 8 lanes apart
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+      csum.x += __shfl_xor(csum.x, d);
+      csum.y += __shfl_xor(csum.y, d);
+      csum.z += __shfl_xor(csum.z, d);
+      csum.w += __shfl_xor(csum.w, d);
+    }
+    const int col = n0 + 4 * sa.cg;
+    if (sa.mg == 0 && col + 4 <= N) {
+      if (P.colsum_partial != nullptr) {
+        st4(P.colsum_partial + (int64_t)slice * N + col, csum);
+      } else {
+        unsafeAtomicAdd(P.colsum + col + 0, csum.x);
+        unsafeAtomicAdd(P.colsum + col + 1, csum.y);
+        unsafeAtomicAdd(P.colsum + col + 2, csum.z);
+        unsafeAtomicAdd(P.colsum + col + 3, csum.w);
+      }
+    }
+  }
   // C / D of a 16 x 16 tile (operands swapped above): n = lane & 15, k = 4 (lane >> 4) + v
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -249,11 +278,12 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
 
 // y[n, k] += sum_slices partial[slice][n][k], slices in order; every problem of the group in one launch
 struct ReduceArgs {
-  const float* partial[TnGroup::MAX];
-  float* y[TnGroup::MAX];
-  int64_t ldy[TnGroup::MAX];
-  int N[TnGroup::MAX], K4[TnGroup::MAX], slices[TnGroup::MAX];
-  unsigned first[TnGroup::MAX];   // first block
+  static constexpr int MAX = 2 * TnGroup::MAX;   // a product's tiles and, as a one-row matrix, its column sums
+  const float* partial[MAX];
+  float* y[MAX];
+  int64_t ldy[MAX];
+  int N[MAX], K4[MAX], slices[MAX];
+  unsigned first[MAX];   // first block
   int n;
 };
 __global__ void __launch_bounds__(256) k_tn_reduce(const ReduceArgs g) {
@@ -284,7 +314,7 @@ bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, cons
 }
 
 int TnGroup::add(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K,
-                 const int64_t* b_index) {
+                 const int64_t* b_index, float* colsum) {
   if (y == nullptr || M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
   if (!gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b)) {
     set_error("gemm_tn_bf16x3: shape M=%lld N=%d K=%d / alignment outside the kernel's contract", (long long)M, N, K);
@@ -294,7 +324,7 @@ int TnGroup::add(const float* a, int64_t lda, const float* b, int64_t ldb, float
     set_error("internal: more than %d weight-gradient products in one group", MAX);
     return DRIN_E_SHAPE;
   }
-  item[n++] = {a, lda, b, ldb, y, ldy, M, N, K, b_index};
+  item[n++] = {a, lda, b, ldb, y, ldy, M, N, K, b_index, colsum};
   return DRIN_OK;
 }
 
@@ -323,7 +353,8 @@ int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, siz
   }
   x3tn::GroupArgs ga;
   x3tn::ReduceArgs ra;
-  ga.n = ra.n = grp.n;
+  ga.n = grp.n;
+  ra.n = 0;
   int64_t items = 0, blocks = 0;
   size_t part = 0;
   bool two_stage = scratch != nullptr && aligned16(scratch);
@@ -341,13 +372,25 @@ int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, siz
     items += slices * tiles[i];
     part += (size_t)slices * it.N * it.K;
     two_stage = two_stage && (it.ldy % 4) == 0 && aligned16(it.y);
-    ra.partial[i] = P.partial, ra.y[i] = it.y, ra.ldy[i] = it.ldy, ra.N[i] = it.N, ra.K4[i] = it.K / 4, ra.slices[i] = (int)slices;
-    ra.first[i] = (unsigned)blocks;
-    blocks += cdiv((int64_t)it.N * (it.K / 4), 256);
+    two_stage = two_stage && (it.colsum == nullptr || aligned16(it.colsum));
+    auto reduce_entry = [&](const float* partial, float* y, int64_t ldy, int n_rows, int k4) {
+      const int j = ra.n++;
+      ra.partial[j] = partial, ra.y[j] = y, ra.ldy[j] = ldy, ra.N[j] = n_rows, ra.K4[j] = k4, ra.slices[j] = (int)slices;
+      ra.first[j] = (unsigned)blocks;
+      blocks += cdiv((int64_t)n_rows * k4, 256);
+    };
+    reduce_entry(P.partial, it.y, it.ldy, it.N, it.K / 4);
+    P.colsum = it.colsum;
+    P.colsum_partial = nullptr;
+    if (it.colsum != nullptr) {
+      P.colsum_partial = scratch != nullptr ? scratch + part : nullptr;
+      reduce_entry(P.colsum_partial, it.colsum, it.N, 1, it.N / 4);
+      part += (size_t)slices * it.N;
+    }
   }
   two_stage = two_stage && part <= scratch_floats;
   if (!two_stage)
-    for (int i = 0; i < grp.n; ++i) ga.p[i].partial = nullptr;
+    for (int i = 0; i < grp.n; ++i) ga.p[i].partial = ga.p[i].colsum_partial = nullptr;
   if (items > (int64_t)1 << 30) {
     set_error("gemm_tn_bf16x3: %lld work items exceed the grid limit", (long long)items);
     return DRIN_E_SHAPE;

@@ -131,10 +131,14 @@ struct TnGroup {
     int64_t ldy, M;
     int N, K;
     const int64_t* b_index;
+    float* colsum;
   } item[MAX];
   int n = 0;
+  // no-op for y == NULL; DRIN_E_SHAPE outside gemm_tn_bf16x3_fits or past MAX
+  // (colsum: optional [N], += the column sums of a - the bias gradient that belongs to dW = dY^T X, from the rows the
+  //  product stages anyway)
   int add(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K,
-          const int64_t* b_index = nullptr);   // no-op for y == NULL; DRIN_E_SHAPE outside gemm_tn_bf16x3_fits or past MAX
+          const int64_t* b_index = nullptr, float* colsum = nullptr);
 };
 int launch_gemm_tn_group(const TnGroup& g, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0

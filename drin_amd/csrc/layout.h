@@ -105,7 +105,7 @@ struct Layout {
       {  // one workgroup per CU over the whole group of weight-gradient products (launch_gemm_tn_group): at most 256 partial
         // tiles of 256 x 256 - or, where one product alone has more tiles than that, one slice of each product
         const size_t one_slice = ((size_t)2 * nl + 1) * D * D + D * R;
-        tn_part_floats = (size_t)256 * 65536 > one_slice ? (size_t)256 * 65536 : one_slice;
+        tn_part_floats = ((size_t)256 * 65536 > one_slice ? (size_t)256 * 65536 : one_slice) + (size_t)8 * 256 * D;  // + column sums
         tn_part = take(tn_part_floats);
       }
       // backward temporaries: entity-vertex gradients per level (nl + 1) + dA_e + dfv per layer; mention side x4; edges x3

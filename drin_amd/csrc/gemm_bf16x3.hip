@@ -419,6 +419,9 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   if (big)
     return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
                   : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);
+  // (measured again in round 2, same box: 128 x 128 tiles with four waves of 64 x 64, two workgroups per CU, for 2 048 <= M <
+  //  16 384 - the B = 64 training step's split-bf16 GEMMs 0.745 -> 0.827 ms, a 64-mention scoring call 0.100 -> 0.116: the
+  //  three co-resident workgroups of the small tile hide each other's stage barriers better than the larger wave tile saves)
   return planes ? x3::launch<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
                 : x3::launch<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);
 }

@@ -793,9 +793,10 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     sp += (n + 63) & ~(size_t)63;
     return p;
   };
-  float* g_vm[2] = {carve(2 * BD), carve(2 * BD)};
-  // entity-vertex gradients: one generation per level (g_ve[l + 1] = dL/dH of layer l, g_ve[0] = the vertex encoders'
-  // output gradient) - they are operands of the weight-gradient products, which run as ONE group at the end
+  // vertex gradients: one generation per level (g_v?[l + 1] = dL/dH of layer l, g_v?[0] = the vertex encoders' output
+  // gradient) - they are operands of the weight-gradient products, which run as grouped launches at the end of the pass
+  float* g_vm[DRIN_MAX_LAYERS + 1];
+  for (int l = 0; l <= nl; ++l) g_vm[l] = carve(2 * BD);
   float* g_ve[DRIN_MAX_LAYERS + 1];
   for (int l = 0; l <= nl; ++l) g_ve[l] = carve(2 * MD);
   const bool vec = cfg->vector_edges != 0;
@@ -803,7 +804,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   float* g_e[2] = {carve(4 * ES), carve(4 * ES)};
   float* dA_m = carve(2 * BD);
   float* dA_e = carve(2 * MD);
-  float* dfu = carve(2 * BD);
+  float* dfu_of[DRIN_MAX_LAYERS];
+  for (int l = 0; l < (nl > 1 ? nl - 1 : 1); ++l) dfu_of[l] = carve(2 * BD);
   float* dfv_of[DRIN_MAX_LAYERS];   // per layer, for the same reason (the last layer has no live edge update)
   for (int l = 0; l < (nl > 1 ? nl - 1 : 1); ++l) dfv_of[l] = carve(2 * MD);
   float* dpre = carve(4 * ES);
@@ -859,6 +861,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   // fill and a partial tile per workgroup; together the workgroups walk ~4x longer slices.  Mention-sized products
   // (exact fp32) and the vector-edge ones (their operands are overwritten layer by layer) run where they arise.
   TnGroup dw_group;
+  F32GemmGroup dw_small;   // the mention-sized ones (exact fp32, atomics onto dW): one launch as well
   const bool defer_dw = x3 && !vec && tnp != nullptr;
   // (db: the bias gradient that goes with it = the column sums of dy; the group takes them from the rows it stages)
   auto dw_product = [&](const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, int64_t lddw, int64_t rows,
@@ -877,12 +880,19 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       return dw_group.add(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, x_index, db);
     }
     if (x_index != nullptr) return launch_gemm_tn_bf16x3(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, st, tnp, tnf, x_index);
+    const bool takes_x3 = x3 && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x);
+    if (!vec && !takes_x3 && rows <= 2048 && (n_out % 4) == 0 && (k_red % 4) == 0 && (prec == DRIN_PREC_F32 || x3)) {
+      if (dw_small.n == F32GemmGroup::MAX) {
+        DRIN_TRY(launch_gemm_tn_f32_group(dw_small, st));
+        dw_small = F32GemmGroup();
+      }
+      return dw_small.add_tn(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red);
+    }
     return launch_gemm_tn(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, prec, st, tnp, tnf);
   };
 
   // score = cos(mt_L, et_L) (model.py:207-209)
-  int cur = 0;
-  DRIN_TRY(launch_cosine_bwd(ws + L.vm[nl], ws + L.ve[nl], grad_scores, g_vm[cur], g_ve[nl], cos_scratch, B, N, D,
+  DRIN_TRY(launch_cosine_bwd(ws + L.vm[nl], ws + L.ve[nl], grad_scores, g_vm[nl], g_ve[nl], cos_scratch, B, N, D,
                              cfg->cosine_eps, st));
   bool have_image = false;  // gradients w.r.t. the image vertices of the current level exist
   bool have_edge = false;   // gradients w.r.t. the current level's edges exist
@@ -890,12 +900,14 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   for (int l = nl - 1; l >= 0; --l) {
     const drin_layer_params& W = params->layer[l];
     const auto& G = grads->layer[l];
-    const int nxt = cur ^ 1;
     const int types = have_image ? 2 : 1;
-    float* gm = g_vm[cur];  // dL/d(new mention vertices) -> dL/dH in place
+    float* gm = g_vm[l + 1];  // dL/d(new mention vertices) -> dL/dH in place
     float* ge = g_ve[l + 1];
+    float* gm_next = g_vm[l];
     float* ge_next = g_ve[l];
     float* dfv = dfv_of[l < nl - 1 ? l : 0];
+    float* dfu = dfu_of[l < nl - 1 ? l : 0];
+    const int cur = (nl - 1 - l) & 1, nxt = cur ^ 1;  // the edge gradients keep two generations
     const float* st_m = ws + L.ln_stat_m[l];
     const float* st_e = ws + L.ln_stat_e[l];
     // (a) LayerNorm + GELU backward; column sums give dgamma, dbeta and db_h
@@ -905,7 +917,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
                                         G.b_h, ws + L.ln_part, D, st, act_v));
     // (b) dW_h += dH^T A
     if (G.w_h) {
-      DRIN_TRY(launch_gemm_tn(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D, prec, st, tnp, tnf));
+      DRIN_TRY(dw_product(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D));
       DRIN_TRY(dw_product(ge, D, ws + L.agg_e[l], D, G.w_h, D, (int64_t)types * M, D, D));
     }
     // (c) dA = dH W_h
@@ -951,8 +963,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
         DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
       }
       DRIN_TRY(dw_product(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, nullptr, G.b_v));
-      if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, prec, st, tnp, tnf));
-      DRIN_TRY(bias_sums.add(dfu, G.b_u, 2 * (int64_t)B, D));
+      DRIN_TRY(dw_product(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, nullptr, G.b_u));
       de_extra = dpre;
     } else if (!cfg->dynamic_edges && have_edge) {
       de_extra = g_e[cur];  // static edges pass through (model.py:136)
@@ -964,9 +975,9 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
                                           ge_next + MD, g_e[nxt], B, N, D, cfg->edge_enabled, st));
       if (edge_update) DRIN_TRY(gemm_nn(dfv, H, W.w_v, ge_next, D, 2 * (int64_t)M, D, H, true));
       // (f) mention side
-      DRIN_TRY(launch_mention_reduce_vec(e, dA_et, e + ES, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, false, st));
-      DRIN_TRY(launch_mention_reduce_vec(e + 2 * ES, dA_et, e + 3 * ES, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, false, st));
-      if (edge_update) DRIN_TRY(gemm_nn(dfu, H, W.w_u, g_vm[nxt], D, 2 * (int64_t)B, D, H, true));
+      DRIN_TRY(launch_mention_reduce_vec(e, dA_et, e + ES, dA_ei, dA_mt, gm_next, B, N, D, 1.0f, false, st));
+      DRIN_TRY(launch_mention_reduce_vec(e + 2 * ES, dA_et, e + 3 * ES, dA_ei, dA_mi, gm_next + BD, B, N, D, 1.0f, false, st));
+      if (edge_update) DRIN_TRY(gemm_nn(dfu, H, W.w_u, gm_next, D, 2 * (int64_t)B, D, H, true));
     } else {
       // (e) entity side of the aggregation backward + edge gradients
       // (the edge update's dfv W_v goes first and the row kernel adds onto it)
@@ -975,16 +986,15 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
                                       g_e[nxt], B, N, D, cfg->edge_enabled, edge_update, st));
       // (f) mention side
       if (B <= 65535) {
-        DRIN_TRY(launch_mention_reduce2(e, dA_et, dA_ei, dA_mt, dA_mi, g_vm[nxt], g_vm[nxt] + BD, B, N, D, 1.0f, st));
+        DRIN_TRY(launch_mention_reduce2(e, dA_et, dA_ei, dA_mt, dA_mi, gm_next, gm_next + BD, B, N, D, 1.0f, st));
       } else {
-        DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, g_vm[nxt], B, N, D, 1.0f, st));
-        DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, g_vm[nxt] + BD, B, N, D, 1.0f, st));
+        DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, gm_next, B, N, D, 1.0f, st));
+        DRIN_TRY(launch_mention_reduce(e + 2 * M, dA_et, e + 3 * M, dA_ei, dA_mi, gm_next + BD, B, N, D, 1.0f, st));
       }
-      if (edge_update) DRIN_TRY(gemm_nn(dfu, D, W.w_u, g_vm[nxt], D, 2 * (int64_t)B, D, D, true));
+      if (edge_update) DRIN_TRY(gemm_nn(dfu, D, W.w_u, gm_next, D, 2 * (int64_t)B, D, D, true));
     }
     have_image = true;
     have_edge = true;
-    cur = nxt;
     // dfv / dfu are overwritten by the next layer down: their column sums go now - except layer 0's, which share the
     // launch of the vertex encoders' bias gradients below
     if (l > 0 && bias_sums.n > 0) {
@@ -994,19 +1004,18 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   }
 
   // VertexEncoder (model.py:26-46): four Linears over the pooled inputs
-  const float* g_mt = g_vm[cur];
-  const float* g_mi = g_vm[cur] + BD;
+  const float* g_mt = g_vm[0];
+  const float* g_mi = g_vm[0] + BD;
   const float* g_et = g_ve[0];
   const float* g_ei = g_ve[0] + MD;
-  if (grads->w_mention_text) DRIN_TRY(launch_gemm_tn(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, prec, st, tnp, tnf));
-  DRIN_TRY(bias_sums.add(g_mt, grads->b_mention_text, B, D));
+  DRIN_TRY(dw_product(g_mt, D, P.span_mean, D, grads->w_mention_text, D, B, D, D, nullptr, grads->b_mention_text));
   DRIN_TRY(dw_product(g_et, D, P.entity_text, D, grads->w_entity_text, D, (int64_t)M, D, D, eidx, grads->b_entity_text));
   if (have_image) {
-    if (grads->w_mention_image) DRIN_TRY(launch_gemm_tn(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, prec, st, tnp, tnf));
-    DRIN_TRY(bias_sums.add(g_mi, grads->b_mention_image, B, D));
+    DRIN_TRY(dw_product(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, nullptr, grads->b_mention_image));
     DRIN_TRY(dw_product(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, eidx, grads->b_entity_image));
   }
   DRIN_TRY(launch_colsum_batch(bias_sums, st));
+  DRIN_TRY(launch_gemm_tn_f32_group(dw_small, st));
   return launch_gemm_tn_group(dw_group, st, tnp, tnf);
 }
 

@@ -99,19 +99,20 @@ __device__ __forceinline__ float4 read_frag(const float* __restrict__ lds, int r
 enum : int { GEMM_ACCUMULATE = 1, GEMM_ATOMIC = 2, GEMM_PARTIAL = 4 };  // PARTIAL: split z writes its tile to C + z * part_stride
 
 // BM x BN output tile (128 or 64 each): 4 waves as 2 x 2, each wave (BM/2) x (BN/2)
+// (tile_x / tile_y / split: the workgroup's column tile, row tile and K slice - blockIdx of the one-problem kernel)
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
-__global__ void __launch_bounds__(256, 2)
-    k_gemm_f32(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
-               const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-               int k_per_split, int flags, int64_t part_stride) {
+__device__ __forceinline__ void gemm_f32_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+                                              const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M,
+                                              int N, int K, int k_per_split, int flags, int64_t part_stride, unsigned tile_x,
+                                              unsigned tile_y, unsigned split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TA = Tile<BM>::FLOATS, TB = Tile<BN>::FLOATS, TBUF = TA + TB;  // buffer c: A at c*TBUF, B after it
   constexpr int MI = BM / 64, NI = BN / 64;                                   // MFMA tiles per wave
   constexpr int WM = BM / 2, WN = BN / 2;
 
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
-  const int k_begin = blockIdx.z * k_per_split;
+  const int64_t m0 = (int64_t)tile_y * BM;
+  const int n0 = tile_x * BN;
+  const int k_begin = split * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
   const int nkb = (k_end - k_begin + BK - 1) / BK;
 
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256, 2)
   }
 
   // epilogue: C/D register v of a 32x32 tile is row (v & 3) + 8 (v >> 2) + 4 h, column r
-  const bool first_split = blockIdx.z == 0;
+  const bool first_split = split == 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256, 2)
         float* dst = C + row * ldc + col;
         const float val = acc[i][j][v] + bv;
         if (flags & GEMM_PARTIAL) {
-          dst[(int64_t)blockIdx.z * part_stride] = acc[i][j][v];  // bias is added by the reduction
+          dst[(int64_t)split * part_stride] = acc[i][j][v];  // bias is added by the reduction
         } else if (flags & GEMM_ATOMIC) {
           atomicAdd(dst, val);
         } else if (flags & GEMM_ACCUMULATE) {
@@ -196,6 +197,43 @@ __global__ void __launch_bounds__(256, 2)
         }
       }
     }
+}
+
+template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
+__global__ void __launch_bounds__(256, 2)
+    k_gemm_f32(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+               const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+               int k_per_split, int flags, int64_t part_stride) {
+  gemm_f32_tile<BM, BN, A_KMAJOR, B_KMAJOR>(A, lda, Bm, ldb, bias, C, ldc, M, N, K, k_per_split, flags, part_stride, blockIdx.x,
+                                            blockIdx.y, blockIdx.z);
+}
+
+// Several mention-sized products of ONE operand layout in one launch (F32GemmGroup, internal.h): a 1-D grid, a problem's
+// work items are (K slice, row tile, column tile), column tile fastest.  Each product alone is a launch of a few
+// microseconds of work between a fill and a drain; the chain of them is what a B = 64 training step spends 0.2 ms on.
+struct GroupItem {
+  const float* a;
+  const float* b;
+  float* c;
+  int64_t lda, ldb, ldc, M;
+  int N, K, k_per_split, flags;
+  unsigned col_tiles, row_tiles, first;
+};
+struct GroupArgs {
+  GroupItem p[F32GemmGroup::MAX];
+  int n;
+};
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ void __launch_bounds__(256, 2) k_gemm_f32_group(const GroupArgs g) {
+  unsigned t = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < g.n; ++i) pi = t >= g.p[i].first ? i : pi;
+  const GroupItem& P = g.p[pi];
+  t -= P.first;
+  const unsigned per_split = P.col_tiles * P.row_tiles;
+  const unsigned split = t / per_split, rest = t - split * per_split;
+  gemm_f32_tile<64, 64, A_KMAJOR, B_KMAJOR>(P.a, P.lda, P.b, P.ldb, nullptr, P.c, P.ldc, P.M, P.N, P.K, P.k_per_split, P.flags, 0,
+                                            rest % P.col_tiles, rest / P.col_tiles, split);
 }
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
@@ -341,6 +379,8 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
                    size_t splitk_floats, const float* w_planes) {
   // split-bf16 contraction for the pair-sized GEMMs; the mention-sized ones (a few hundred rows) stay on
   // the exact fp32 kernel: they are latency-bound, not rate-bound
+  // (the 256-row threshold measured again in round 2, same box, 16 / 64 rows instead: a 64-mention scoring call 0.551 -> 0.576 ms,
+  //  the B = 64 training step 1.406 -> 1.424 - below a tile row of the 256-wide kernel the exact one is as fast and exact)
   if (!accumulate && ((precision == DRIN_PREC_BF16X3 && M >= 256) || precision == DRIN_PREC_BF16X3_ALL)) {
     // (pre-split weight planes: contiguous [N][K] weights only, K a multiple of 32 - what the LDS-DMA path reads)
     const bool planes = w_planes != nullptr && ldw == K && (K % 32) == 0;
@@ -382,6 +422,50 @@ int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, flo
                                        "gemm_nn");
   return launch<128, 128, false, true>(x, ldx, w, ldw, nullptr, y, ldy, M, N, K, 1, accumulate ? GEMM_ACCUMULATE : 0, st,
                                        "gemm_nn");
+}
+
+int F32GemmGroup::add_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K) {
+  if (y == nullptr || M <= 0 || N <= 0 || K <= 0) return DRIN_OK;
+  if ((N % 4) || (K % 4) || M > 2048 || !aligned16(a) || !aligned16(b) || (lda % 4) || (ldb % 4)) {
+    set_error("gemm_tn group: M=%lld N=%d K=%d outside the mention-sized kernel's contract", (long long)M, N, K);
+    return DRIN_E_SHAPE;
+  }
+  if (n == MAX) {
+    set_error("internal: more than %d products in one exact-fp32 group", MAX);
+    return DRIN_E_SHAPE;
+  }
+  item[n++] = {a, lda, b, ldb, y, ldy, M, N, K};
+  return DRIN_OK;
+}
+
+// y[n, k] += sum_m a[m, n] b[m, k] for every item: the mention-sized branch of launch_gemm_tn (64 x 64 tiles, up to four
+// slices of the reduction, fp32 atomics onto y), all items in one launch
+int launch_gemm_tn_f32_group(const F32GemmGroup& grp, hipStream_t st) {
+  if (grp.n == 0) return DRIN_OK;
+  GroupArgs ga;
+  ga.n = grp.n;
+  unsigned items = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    const auto& it = grp.item[i];
+    int splits = (int)cdiv(it.M, 4 * BK);
+    splits = splits > 4 ? 4 : (splits < 1 ? 1 : splits);
+    const int kps = (int)(cdiv(cdiv(it.M, splits), BK) * BK);
+    splits = (int)cdiv(it.M, kps);
+    auto& P = ga.p[i];
+    // the kernel's (M, N, K) are (output rows, output columns, reduction length) = (N, K, M) of the product
+    P.a = it.a, P.b = it.b, P.c = it.y, P.lda = it.lda, P.ldb = it.ldb, P.ldc = it.ldy;
+    P.M = it.N, P.N = it.K, P.K = (int)it.M, P.k_per_split = kps, P.flags = GEMM_ATOMIC;
+    P.col_tiles = (unsigned)cdiv(it.K, 64), P.row_tiles = (unsigned)cdiv(it.N, 64), P.first = items;
+    items += P.col_tiles * P.row_tiles * (unsigned)splits;
+  }
+  const size_t lds = sizeof(float) * 2 * (Tile<64>::FLOATS + Tile<64>::FLOATS);
+  static DynLdsOptIn opt_in;
+  auto kern = k_gemm_f32_group<true, true>;
+  DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(gemm group)"));
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  hipLaunchKernelGGL(kern, dim3(items), dim3(256), lds, st, ga);
+  DRIN_CHECK_LAUNCH("k_gemm_f32_group");
+  return DRIN_OK;
 }
 
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,

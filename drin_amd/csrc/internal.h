@@ -168,6 +168,22 @@ int launch_transpose_split_batch(const SplitBatch& b, int rows, int cols, hipStr
 // y[m, n] (+)= sum_k x[m, k] * w[k, n]        (used by backward: dX = dY * W)
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
                    int K, bool accumulate, int precision, hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
+// up to 8 MENTION-sized (M <= 2048 reduction rows) exact-fp32 products y[n, k] += sum_m a[m, n] b[m, k] in one launch
+struct F32GemmGroup {
+  static constexpr int MAX = 8;
+  struct Item {
+    const float* a;
+    int64_t lda;
+    const float* b;
+    int64_t ldb;
+    float* y;
+    int64_t ldy, M;
+    int N, K;
+  } item[MAX];
+  int n = 0;
+  int add_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K);
+};
+int launch_gemm_tn_f32_group(const F32GemmGroup& g, hipStream_t st);
 // y[n, k] += sum_m a[m, n] * b[m, k]          (used by backward: dW = dY^T * X), split over m
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
                    int K, int precision, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);

@@ -108,8 +108,8 @@ struct Layout {
         tn_part_floats = ((size_t)256 * 65536 > one_slice ? (size_t)256 * 65536 : one_slice) + (size_t)8 * 256 * D;  // + column sums
         tn_part = take(tn_part_floats);
       }
-      // backward temporaries: entity-vertex gradients per level (nl + 1) + dA_e + dfv per layer; mention side x4; edges x3
-      bwd_scratch_floats = ((size_t)2 * nl + 2) * (2 * M * D + 64) + 4 * (2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
+      // backward temporaries: vertex gradients per level (nl + 1) + dA + dfv / dfu per layer, entity and mention side; edges x3
+      bwd_scratch_floats = ((size_t)2 * nl + 2) * (2 * M * D + 64 + 2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);
       bwd_scratch = take(bwd_scratch_floats);
     } else {
       size_t e2[2] = {take(4 * M * EW), take(4 * M * EW)};

@@ -581,10 +581,37 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     }
     DRIN_TRY(launch_split_planes_batch(sb, st));
   }
-  DRIN_TRY(launch_gemm_nt(P.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false,
-                          prec, st, msk, mskf, wp(L.wp_enc[0])));
-  DRIN_TRY(launch_gemm_nt(P.mention_image, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D,
-                          D, B, D, R, false, prec, st, msk, mskf, wp(L.wp_enc[1])));
+  // Two mention-sized products that do not depend on each other: when both would run as the exact-fp32 split-K kernel + slice
+  // reduction (a few hundred rows: 6-9 us + 5 us each, nearly all fill and drain), the two kernels share a launch and so do
+  // the two reductions - same slices, same order, same bits.
+  struct NtProduct {
+    const float *x, *w, *bias;
+    float* y;
+    int64_t ldx, ldw, ldy, rows;
+    int n_out, k_red;
+    const float* planes;
+  };
+  auto nt_pair = [&](const NtProduct& a, const NtProduct& b) -> int {
+    const NtProduct* two[2] = {&a, &b};
+    bool grouped = msk != nullptr;
+    size_t need = 8;
+    for (const NtProduct* q : two) {
+      grouped = grouped && gemm_nt_f32_group_fits(q->x, q->ldx, q->w, q->ldw, q->y, q->ldy, q->rows, q->n_out, q->k_red, prec);
+      need += (size_t)8 * q->rows * q->n_out;
+    }
+    if (grouped && need <= mskf) {
+      F32GemmGroup g;
+      for (const NtProduct* q : two) DRIN_TRY(g.add_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k_red));
+      return launch_gemm_nt_f32_group(g, st, msk, mskf);
+    }
+    for (const NtProduct* q : two)
+      DRIN_TRY(launch_gemm_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k_red, false, prec, st, msk, mskf,
+                              q->planes));
+    return DRIN_OK;
+  };
+  DRIN_TRY(nt_pair({P.span_mean, params->w_mention_text, params->b_mention_text, vm0, D, D, D, B, D, D, wp(L.wp_enc[0])},
+                   {P.mention_image, params->w_mention_image, params->b_mention_image, vm0 + (size_t)B * D, R, R, D, B, D, R,
+                    wp(L.wp_enc[1])}));
   if (eidx) {  // rows of the entity tables, addressed through the candidate index by the GEMM's stager
     const __bf16* pt = reinterpret_cast<const __bf16*>(wp(L.wp_enc[2]));
     const __bf16* pi = reinterpret_cast<const __bf16*>(wp(L.wp_enc[3]));
@@ -646,7 +673,13 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     // shared W_h + LayerNorm + GELU for all vertex types of the layer (model.py:128)
     float* h_m = ws + L.h_m[l];
     float* h_e = ws + L.h_e[l];
-    DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, msk, mskf, wp(L.wp_h[l])));
+    const bool scalar_update = live_edges && !vec;   // then W_u(mt, mi) is due too and shares the launch of W_h(agg_m)
+    if (scalar_update) {
+      DRIN_TRY(nt_pair({agg_m, W.w_h, W.b_h, h_m, D, D, D, (int64_t)types * B, D, D, wp(L.wp_h[l])},
+                       {mt, W.w_u, W.b_u, ws + L.fu[l], D, D, D, 2 * (int64_t)B, D, D, wp(L.wp_u[l])}));
+    } else {
+      DRIN_TRY(launch_gemm_nt(agg_m, D, W.w_h, D, W.b_h, h_m, D, (int64_t)types * B, D, D, false, prec, st, msk, mskf, wp(L.wp_h[l])));
+    }
     DRIN_TRY(launch_gemm_nt(agg_e, D, W.w_h, D, W.b_h, h_e, D, (int64_t)types * M, D, D, false, prec, st, tl, tlf, wp(L.wp_h[l])));
     float* st_m = L.training ? ws + L.ln_stat_m[l] : nullptr;
     float* st_e = L.training ? ws + L.ln_stat_e[l] : nullptr;
@@ -670,8 +703,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
-      DRIN_TRY(launch_gemm_nt(mt, D, W.w_u, D, W.b_u, fu, D, 2 * (int64_t)B, D, D, false, prec, st, msk, mskf, wp(L.wp_u[l])));
-      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf, wp(L.wp_v[l])));
+      DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf, wp(L.wp_v[l])));   // fu: with W_h above
       DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st, act_e));
     } else if (!cfg->dynamic_edges) {
       hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);

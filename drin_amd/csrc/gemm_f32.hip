@@ -215,7 +215,7 @@ struct GroupItem {
   const float* a;
   const float* b;
   float* c;
-  int64_t lda, ldb, ldc, M;
+  int64_t lda, ldb, ldc, M, part_stride;
   int N, K, k_per_split, flags;
   unsigned col_tiles, row_tiles, first;
 };
@@ -232,8 +232,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f32_group(const GroupArgs g) {
   t -= P.first;
   const unsigned per_split = P.col_tiles * P.row_tiles;
   const unsigned split = t / per_split, rest = t - split * per_split;
-  gemm_f32_tile<64, 64, A_KMAJOR, B_KMAJOR>(P.a, P.lda, P.b, P.ldb, nullptr, P.c, P.ldc, P.M, P.N, P.K, P.k_per_split, P.flags, 0,
-                                            rest % P.col_tiles, rest / P.col_tiles, split);
+  gemm_f32_tile<64, 64, A_KMAJOR, B_KMAJOR>(P.a, P.lda, P.b, P.ldb, nullptr, P.c, P.ldc, P.M, P.N, P.K, P.k_per_split, P.flags,
+                                            P.part_stride, rest % P.col_tiles, rest / P.col_tiles, split);
 }
 
 template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
@@ -374,6 +374,95 @@ static bool small_splitk_fits(int64_t M, int N, int K, int64_t ldy, const float*
          scratch_floats >= (size_t)2 * M * N;
 }
 
+// the slice reductions of a group of split-K products in one launch (k_splitk_reduce per item)
+struct ReduceGroupArgs {
+  const float* partial[F32GemmGroup::MAX];
+  const float* bias[F32GemmGroup::MAX];
+  float* y[F32GemmGroup::MAX];
+  int64_t ldy[F32GemmGroup::MAX], M[F32GemmGroup::MAX], part_stride[F32GemmGroup::MAX];
+  int N4[F32GemmGroup::MAX], splits[F32GemmGroup::MAX];
+  unsigned first[F32GemmGroup::MAX];
+  int n;
+};
+__global__ void __launch_bounds__(256) k_splitk_reduce_group(const ReduceGroupArgs g) {
+  int pi = 0;
+  for (int i = 1; i < g.n; ++i) pi = blockIdx.x >= g.first[i] ? i : pi;
+  const int64_t i = (int64_t)(blockIdx.x - g.first[pi]) * 256 + threadIdx.x;
+  const int N4 = g.N4[pi];
+  if (i >= g.M[pi] * N4) return;
+  const int64_t m = i / N4;
+  const int c4 = (int)(i - m * N4);
+  const int64_t off = m * (int64_t)N4 * 4 + (int64_t)c4 * 4;
+  float4 s = g.bias[pi] != nullptr ? ld4(g.bias[pi] + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < g.splits[pi]; ++z) s = s + ld4(g.partial[pi] + z * g.part_stride[pi] + off);
+  st4(g.y[pi] + m * g.ldy[pi] + c4 * 4, s);
+}
+
+bool gemm_nt_f32_group_fits(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N,
+                            int K, int precision) {
+  // exactly the products launch_gemm_nt sends to the exact-fp32 split-K pair (kernel + slice reduction)
+  if (precision == DRIN_PREC_BF16X3_ALL || (precision == DRIN_PREC_BF16X3 && M >= 256)) return false;
+  if (precision != DRIN_PREC_F32 && precision != DRIN_PREC_BF16X3) return false;
+  if ((K % 4) || gemv_fits(x, ldx, w, ldw, M, K)) return false;
+  return M >= 1 && M <= 512 && K >= 512 && (N % 4) == 0 && (ldy % 4) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0 && aligned16(y) &&
+         aligned16(x) && aligned16(w);
+}
+
+int F32GemmGroup::add_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy, int64_t M,
+                         int N, int K) {
+  if (n == MAX) {
+    set_error("internal: more than %d products in one exact-fp32 group", MAX);
+    return DRIN_E_SHAPE;
+  }
+  item[n] = {x, ldx, w, ldw, y, ldy, M, N, K};
+  bias_of[n++] = bias;
+  return DRIN_OK;
+}
+
+// y = x w^T + bias for every item (each one passed gemm_nt_f32_group_fits): the split-K kernel of all items in one launch,
+// their slice reductions in a second - the same slices in the same order as launch_gemm_nt's own pair of launches
+int launch_gemm_nt_f32_group(const F32GemmGroup& grp, hipStream_t st, float* scratch, size_t scratch_floats) {
+  if (grp.n == 0) return DRIN_OK;
+  GroupArgs ga;
+  ReduceGroupArgs ra;
+  ga.n = ra.n = grp.n;
+  unsigned items = 0, blocks = 0;
+  size_t used = 0;
+  for (int i = 0; i < grp.n; ++i) {
+    const auto& it = grp.item[i];
+    int splits = it.K / 128;   // as launch_small_splitk
+    if (splits > 8) splits = 8;
+    if (splits < 1) splits = 1;
+    const int kps = (int)(cdiv(cdiv(it.K, splits), BK) * BK);
+    splits = (int)cdiv(it.K, kps);
+    const int64_t part_stride = it.M * (int64_t)it.N;
+    if (scratch == nullptr || !aligned16(scratch) || used + (size_t)splits * part_stride > scratch_floats) {
+      set_error("gemm_nt group: split-K scratch of %zu floats is too small", scratch_floats);
+      return DRIN_E_WORKSPACE;
+    }
+    auto& P = ga.p[i];
+    P.a = it.a, P.b = it.b, P.c = scratch + used, P.lda = it.lda, P.ldb = it.ldb, P.ldc = it.N;
+    P.M = it.M, P.N = it.N, P.K = it.K, P.k_per_split = kps, P.flags = GEMM_PARTIAL, P.part_stride = part_stride;
+    P.col_tiles = (unsigned)cdiv(it.N, 64), P.row_tiles = (unsigned)cdiv(it.M, 64), P.first = items;
+    items += P.col_tiles * P.row_tiles * (unsigned)splits;
+    ra.partial[i] = scratch + used, ra.bias[i] = grp.bias_of[i], ra.y[i] = it.y, ra.ldy[i] = it.ldy, ra.M[i] = it.M;
+    ra.part_stride[i] = part_stride, ra.N4[i] = it.N / 4, ra.splits[i] = splits, ra.first[i] = blocks;
+    blocks += (unsigned)cdiv(it.M * (it.N / 4), 256);
+    used += (size_t)splits * part_stride;
+    used = (used + 3) & ~(size_t)3;
+  }
+  const size_t lds = sizeof(float) * 2 * (Tile<64>::FLOATS + Tile<64>::FLOATS);
+  static DynLdsOptIn opt_in;
+  auto kern = k_gemm_f32_group<false, false>;
+  DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(gemm group)"));
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  hipLaunchKernelGGL(kern, dim3(items), dim3(256), lds, st, ga);
+  DRIN_CHECK_LAUNCH("k_gemm_f32_group");
+  hipLaunchKernelGGL(k_splitk_reduce_group, dim3(blocks), dim3(256), 0, st, ra);
+  DRIN_CHECK_LAUNCH("k_splitk_reduce_group");
+  return DRIN_OK;
+}
+
 int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                    int64_t M, int N, int K, bool accumulate, int precision, hipStream_t st, float* splitk,
                    size_t splitk_floats, const float* w_planes) {
@@ -454,7 +543,7 @@ int launch_gemm_tn_f32_group(const F32GemmGroup& grp, hipStream_t st) {
     auto& P = ga.p[i];
     // the kernel's (M, N, K) are (output rows, output columns, reduction length) = (N, K, M) of the product
     P.a = it.a, P.b = it.b, P.c = it.y, P.lda = it.lda, P.ldb = it.ldb, P.ldc = it.ldy;
-    P.M = it.N, P.N = it.K, P.K = (int)it.M, P.k_per_split = kps, P.flags = GEMM_ATOMIC;
+    P.M = it.N, P.N = it.K, P.K = (int)it.M, P.k_per_split = kps, P.flags = GEMM_ATOMIC, P.part_stride = 0;
     P.col_tiles = (unsigned)cdiv(it.K, 64), P.row_tiles = (unsigned)cdiv(it.N, 64), P.first = items;
     items += P.col_tiles * P.row_tiles * (unsigned)splits;
   }

@@ -180,10 +180,17 @@ struct F32GemmGroup {
     int64_t ldy, M;
     int N, K;
   } item[MAX];
+  const float* bias_of[MAX];
   int n = 0;
   int add_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K);
+  // y = x w^T + bias (item fields: a = x, b = w, M = rows, N = outputs, K = reduction); only for products that passed
+  // gemm_nt_f32_group_fits - the ones launch_gemm_nt would run as the exact-fp32 split-K kernel + slice reduction
+  int add_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K);
 };
 int launch_gemm_tn_f32_group(const F32GemmGroup& g, hipStream_t st);
+bool gemm_nt_f32_group_fits(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N,
+                            int K, int precision);
+int launch_gemm_nt_f32_group(const F32GemmGroup& g, hipStream_t st, float* scratch, size_t scratch_floats);
 // y[n, k] += sum_m a[m, n] * b[m, k]          (used by backward: dW = dY^T * X), split over m
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
                    int K, int precision, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);

@@ -72,7 +72,7 @@ struct Layout {
     eobj_pool = take(c.entity_object_inner > 1 ? M * c.entity_objects * R : 0);
     eimg_pool = take(c.entity_image_inner > 1 ? M * R : 0);
     xet_pool = take(c.entity_tokens > 0 ? M * D : 0);
-    splitk_floats = 2 * B <= 512 ? 8 * 2 * B * D : 0;
+    splitk_floats = 2 * B <= 512 ? 16 * 2 * B * D + 64 : 0;   // 8 slices of two [2 B][D] products (grouped launches, gemm_f32.hip)
     splitk = take(splitk_floats);
     // split-bf16 precision with scalar edges and at least a tile row of pairs: the weights as planes
     weight_planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL) && !c.vector_edges && M >= 256 &&

@@ -581,34 +581,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     }
     DRIN_TRY(launch_split_planes_batch(sb, st));
   }
-  // Two mention-sized products that do not depend on each other: when both would run as the exact-fp32 split-K kernel + slice
-  // reduction (a few hundred rows: 6-9 us + 5 us each, nearly all fill and drain), the two kernels share a launch and so do
-  // the two reductions - same slices, same order, same bits.
-  struct NtProduct {
-    const float *x, *w, *bias;
-    float* y;
-    int64_t ldx, ldw, ldy, rows;
-    int n_out, k_red;
-    const float* planes;
-  };
-  auto nt_pair = [&](const NtProduct& a, const NtProduct& b) -> int {
-    const NtProduct* two[2] = {&a, &b};
-    bool grouped = msk != nullptr;
-    size_t need = 8;
-    for (const NtProduct* q : two) {
-      grouped = grouped && gemm_nt_f32_group_fits(q->x, q->ldx, q->w, q->ldw, q->y, q->ldy, q->rows, q->n_out, q->k_red, prec);
-      need += (size_t)8 * q->rows * q->n_out;
-    }
-    if (grouped && need <= mskf) {
-      F32GemmGroup g;
-      for (const NtProduct* q : two) DRIN_TRY(g.add_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k_red));
-      return launch_gemm_nt_f32_group(g, st, msk, mskf);
-    }
-    for (const NtProduct* q : two)
-      DRIN_TRY(launch_gemm_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k_red, false, prec, st, msk, mskf,
-                              q->planes));
-    return DRIN_OK;
-  };
+  auto nt_pair = [&](const NtProduct& a, const NtProduct& b) -> int { return launch_gemm_nt_pair(a, b, prec, st, msk, mskf); };
   DRIN_TRY(nt_pair({P.span_mean, params->w_mention_text, params->b_mention_text, vm0, D, D, D, B, D, D, wp(L.wp_enc[0])},
                    {P.mention_image, params->w_mention_image, params->b_mention_image, vm0 + (size_t)B * D, R, R, D, B, D, R,
                     wp(L.wp_enc[1])}));

@@ -584,8 +584,9 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   DRIN_TRY(launch_span_mean(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B, cfg->mention_tokens, D, st));
   DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
   float* vm0 = ws + L.vm0;
-  DRIN_TRY(launch_gemm_nt(ws + L.span_mean, D, params->w_mention_text, D, params->b_mention_text, vm0, D, B, D, D, false, prec, st, sk, skf));
-  DRIN_TRY(launch_gemm_nt(ws + L.mimg, R, params->w_mention_image, R, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R, false, prec, st, sk, skf));
+  DRIN_TRY(launch_gemm_nt_pair({ws + L.span_mean, params->w_mention_text, params->b_mention_text, vm0, D, D, D, B, D, D, nullptr},
+                               {ws + L.mimg, params->w_mention_image, params->b_mention_image, vm0 + (size_t)B * D, R, R, D, B, D, R, nullptr},
+                               prec, st, sk, skf));
   float* hmfu = ws + L.hmfu;
   DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st, sk, skf));
 

@@ -297,6 +297,37 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
     return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, false, prec, st,
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
   };
+  // Two such products that do not depend on each other, both on the exact-fp32 split-K kernel (small batches): one launch for
+  // the two kernels, one for the two slice reductions (gemm_f32.hip: F32GemmGroup; same slices, same order, same bits)
+  struct Lin {
+    const float* x;
+    int64_t ldx;
+    const float* w;
+    int64_t ldw;
+    size_t plane_off, plane_elems;
+    const float* bias;
+    float* y;
+    int64_t ldy, rows;
+    int n_out, k;
+  };
+  auto lin_pair = [&](const Lin& a, const Lin& b) -> int {
+    const Lin* two[2] = {&a, &b};
+    bool grouped = L.splitk_floats > 0;
+    size_t need = 8;
+    for (const Lin* q : two) {
+      const bool x3 = planes && (q->rows >= 256 || prec == DRIN_PREC_BF16X3_ALL) && (q->k % 32) == 0 && (q->ldw % 8) == 0;
+      grouped = grouped && !x3 && gemm_nt_f32_group_fits(q->x, q->ldx, q->w, q->ldw, q->y, q->ldy, q->rows, q->n_out, q->k, prec);
+      need += (size_t)8 * q->rows * q->n_out;
+    }
+    if (grouped && need <= L.splitk_floats) {
+      F32GemmGroup g;
+      for (const Lin* q : two) DRIN_TRY(g.add_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k));
+      return launch_gemm_nt_f32_group(g, st, ws + L.splitk, L.splitk_floats);
+    }
+    for (const Lin* q : two)
+      DRIN_TRY(lin(q->x, q->ldx, q->w, q->ldw, q->plane_off, q->plane_elems, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k));
+    return DRIN_OK;
+  };
   const size_t DD = (size_t)D * D, DR = (size_t)D * R;
   // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears
   if (bf16_feat) {
@@ -311,8 +342,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   float* vm0 = ws + L.vm0;
   // mention-sized contractions take the configured precision too: launch_gemm_nt keeps problems of fewer
   // than 1024 rows on the fp32 kernel (latency-bound), larger ones (WikiDiverse batches) go split-bf16
-  DRIN_TRY(lin(ws + L.span_mean, D, params->w_mention_text, D, P.p_wmt, DD, params->b_mention_text, vm0, D, B, D, D));
-  DRIN_TRY(lin(ws + L.mimg, R, params->w_mention_image, R, P.p_wmi, DR, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R));
+  DRIN_TRY(lin_pair({ws + L.span_mean, D, params->w_mention_text, D, P.p_wmt, DD, params->b_mention_text, vm0, D, B, D, D},
+                    {ws + L.mimg, R, params->w_mention_image, R, P.p_wmi, DR, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R}));
   // (2) [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1], then q = fu [W_v1 W_et | W_v1 W_ei]
   float* hmfu = ws + L.hmfu;
   DRIN_TRY(lin(vm0, D, pb + P.wcat1, D, P.p_wcat1, 2 * DD, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D));
@@ -375,8 +406,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   if (L.chunks > 1)
     DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
   // (4) layer-1 mention vertices: T = S_text W_et^T + S_img W_ei^T, then the W_h input, W_h, LN, GELU
-  DRIN_TRY(lin(ws + L.s_text, D, params->w_entity_text, D, P.p_wet, DD, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D));
-  DRIN_TRY(lin(ws + L.s_img, R, params->w_entity_image, R, P.p_wei, DR, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R));
+  DRIN_TRY(lin_pair({ws + L.s_text, D, params->w_entity_text, D, P.p_wet, DD, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D},
+                    {ws + L.s_img, R, params->w_entity_image, R, P.p_wei, DR, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R}));
   DRIN_TRY(launch_mention_input1(ws + L.tm, ws + L.tm2, ws + L.sig, params->b_entity_text, params->b_entity_image, vm0, ws + L.agg1, B, D, N, st));
   float* vm1 = ws + L.vm1;
   DRIN_TRY(lin(ws + L.agg1, D, L1.w_h, D, P.p_wh1, DD, L1.b_h, vm1, D, 2 * (int64_t)B, D, D));

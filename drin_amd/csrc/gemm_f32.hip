@@ -495,6 +495,25 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
                                         "gemm_nt");
 }
 
+int launch_gemm_nt_pair(const NtProduct& a, const NtProduct& b, int precision, hipStream_t st, float* splitk, size_t splitk_floats) {
+  const NtProduct* two[2] = {&a, &b};
+  bool grouped = splitk != nullptr;
+  size_t need = 8;
+  for (const NtProduct* q : two) {
+    grouped = grouped && gemm_nt_f32_group_fits(q->x, q->ldx, q->w, q->ldw, q->y, q->ldy, q->rows, q->n_out, q->k_red, precision);
+    need += (size_t)8 * q->rows * q->n_out;
+  }
+  if (grouped && need <= splitk_floats) {
+    F32GemmGroup g;
+    for (const NtProduct* q : two) DRIN_TRY(g.add_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k_red));
+    return launch_gemm_nt_f32_group(g, st, splitk, splitk_floats);
+  }
+  for (const NtProduct* q : two)
+    DRIN_TRY(launch_gemm_nt(q->x, q->ldx, q->w, q->ldw, q->bias, q->y, q->ldy, q->rows, q->n_out, q->k_red, false, precision, st, splitk,
+                            splitk_floats, q->planes));
+  return DRIN_OK;
+}
+
 int launch_gemm_nn(const float* x, int64_t ldx, const float* w, int64_t ldw, float* y, int64_t ldy, int64_t M, int N,
                    int K, bool accumulate, int precision, hipStream_t st, float* splitk, size_t splitk_floats) {
   // y[m, n] = sum_k x[m, k] * w[k, n]: b(n, k) = w[k * ldw + n] is k-major

@@ -191,6 +191,17 @@ int launch_gemm_tn_f32_group(const F32GemmGroup& g, hipStream_t st);
 bool gemm_nt_f32_group_fits(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N,
                             int K, int precision);
 int launch_gemm_nt_f32_group(const F32GemmGroup& g, hipStream_t st, float* scratch, size_t scratch_floats);
+// Two NT products that do not depend on each other.  When both would run as the exact-fp32 split-K kernel + slice reduction
+// (a few hundred rows: 6-9 us + 5 us each, nearly all fill and drain) the two kernels share a launch and so do the two
+// reductions - same slices, same order, same bits; otherwise two launch_gemm_nt calls (planes: as its w_planes).
+struct NtProduct {
+  const float *x, *w, *bias;
+  float* y;
+  int64_t ldx, ldw, ldy, rows;
+  int n_out, k_red;
+  const float* planes;
+};
+int launch_gemm_nt_pair(const NtProduct& a, const NtProduct& b, int precision, hipStream_t st, float* splitk, size_t splitk_floats);
 // y[n, k] += sum_m a[m, n] * b[m, k]          (used by backward: dW = dY^T * X), split over m
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
                    int K, int precision, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);

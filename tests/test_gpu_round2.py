@@ -328,18 +328,19 @@ def test_second_device_opts_into_large_lds():
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("layers", [3, 5])
-def test_deep_backward_at_512_mentions_keeps_its_operands(layers):
+@pytest.mark.parametrize("layers,mentions", [(3, 600), (5, 600), (5, 20)])
+def test_deep_backward_at_512_mentions_keeps_its_operands(layers, mentions):
     """Regression (round 2): the split-bf16 dX = dY W products run against weights transposed ONCE per backward; a product that
     is transposed on the fly (W_u at >= 512 mentions: 2 B >= 1024 rows) must not overwrite one of them.  And the pair-sized
     weight gradients run as ONE group at the end of the pass (TnGroup: up to eight products; five layers have eleven, so the
     group goes in instalments) from per-level gradient buffers nothing may have overwritten.  Dynamic layers, 600 mentions,
-    TINY widths raised to the split-bf16 kernel's range; every gradient against autograd through the oracle."""
+    TINY widths raised to the split-bf16 kernel's range; every gradient against autograd through the oracle.  (20 mentions:
+    every weight gradient is mention-sized - 22 exact-fp32 products through the F32GemmGroup of eight, in instalments too.)"""
     from drin_amd.metrics import TripletLoss
     cfg = DrinConfig(num_gcn_layers=layers, num_candidates_data=2, bert_embed_dim=128, gcn_embed_dim=128, resnet_embed_dim=128,
                      max_mention_sentence_len=8, resnet_num_region=2)
     sd = synth.make_state_dict(cfg, 9)
-    batch = synth.make_batch(cfg, 600, 45)
+    batch = synth.make_batch(cfg, mentions, 45)
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref_loss = O.triplet_loss(batch[-1], O.forward(p, batch, **O.config_kwargs(cfg)), cfg.triplet_margin)
     ref = torch.autograd.grad(ref_loss, list(p.values()), allow_unused=True)

@@ -233,12 +233,74 @@ class History:
     seconds: float = 0.0
 
 
+class StepProfiler:
+    """The `profiling` switch of `train.py:64-70,84-85,101-109` (`args.py:131`): the reference wraps the fit in
+    `torch.profiler.profile(schedule(wait=1, warmup=1, active=3, repeat=2), tensorboard_trace_handler("log/profiler"))`,
+    started at fit start, stepped after every training batch, stopped at the end of the training epoch.  Same schedule
+    here, over the library's own profiler (`drin_profile_begin/end`: HIP events around every launch, on the launch stream):
+    each of the `repeat` cycles skips `wait` steps, runs `warmup` more, then times `active` steps and writes
+    `<out_dir>/drin_profile_<cycle>.json` - kernel class -> ms per step and launches per step - and logs the line.
+    Launch names for rocprofv3 come from `DRIN_ROCTX=1` (roctx ranges over the entry points)."""
+
+    def __init__(self, wait: int = 1, warmup: int = 1, active: int = 3, repeat: int = 2, out_dir: str = "log/profiler",
+                 log: Optional[Callable[[str], None]] = None):
+        self.wait, self.warmup, self.active, self.repeat = wait, warmup, active, repeat
+        self.out_dir, self.log = out_dir, log
+        self.step_idx, self.cycle, self.open = 0, 0, False
+        self.reports: List[dict] = []
+
+    def start(self) -> None:
+        self.step_idx, self.cycle = 0, 0
+        self._maybe_open()
+
+    def _maybe_open(self) -> None:
+        from . import _lib
+        if self.cycle < self.repeat and self.step_idx == self.wait + self.warmup and not self.open:
+            _lib.profile_begin(1 << 16)
+            self.open = True
+
+    def step(self) -> None:
+        """after every training batch (`on_train_batch_end`)"""
+        self.step_idx += 1
+        if self.open and self.step_idx == self.wait + self.warmup + self.active:
+            self._close()
+            self.step_idx = 0
+            self.cycle += 1
+        self._maybe_open()
+
+    def _close(self) -> None:
+        import json
+        import os
+
+        from . import _lib
+        prof = _lib.profile_end()
+        self.open = False
+        steps = max(self.step_idx - self.wait - self.warmup, 1)
+        report = {"cycle": self.cycle, "steps": steps,
+                  "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
+                  "launches_per_step": {k: v[1] / steps for k, v in prof.items() if v[1]}}
+        self.reports.append(report)
+        if _rank() == 0:
+            os.makedirs(self.out_dir, exist_ok=True)
+            with open(os.path.join(self.out_dir, f"drin_profile_{self.cycle}.json"), "w") as f:
+                json.dump(report, f, indent=1)
+            if self.log:
+                self.log("profile cycle %d: %s" % (self.cycle, {k: round(v, 4) for k, v in report["kernel_ms_per_step"].items()}))
+
+    def stop(self) -> None:
+        """end of the training epoch (`on_train_epoch_end`): an unfinished cycle reports what it has"""
+        if self.open:
+            self._close()
+        self.cycle = self.repeat
+
+
 class MELRunner:
     """`MELModel` of `train.py:20-56` without Lightning."""
 
     def __init__(self, cfg: DrinConfig, model: nn.Module, device, global_batch_loss: bool = False,
                  log: Optional[Callable[[str], None]] = None, entity_table=None, device_loss: Optional[bool] = None,
-                 fused_adam: bool = False, library_adam: Optional[bool] = None, output_test_result: Optional[str] = None):
+                 fused_adam: bool = False, library_adam: Optional[bool] = None, output_test_result: Optional[str] = None,
+                 profiling: bool = False, profile_dir: str = "log/profiler"):
         """`entity_table`: a device-resident `drin_amd.model.EntityTable`; the loaders then yield the 11-item
         table-form batches of `drin_amd.data.IndexedMELData` (candidate indices instead of gathered features).
         `device_loss`: loss + top-k counters through the library's `drin_triplet_topk` (default on a GPU; the
@@ -246,7 +308,8 @@ class MELRunner:
         `library_adam`: the one-launch `LibraryAdam` (default for a `drin_amd.model.Model` on a GPU), else `torch.optim.Adam`.
         `output_test_result`: a path - the per-sample dump of `train.py:16-17,40-43` (`args.output_test_result`): every
         test-split sample's score row and answer row, `"{index}:\t{scores}\n{answer}\n"` (rank r > 0 of a data-parallel
-        run appends `.rank{r}` to the name and numbers its own shard's samples)."""
+        run appends `.rank{r}` to the name and numbers its own shard's samples).
+        `profiling`: the switch of `train.py:64-70` (`args.profiling`), see `StepProfiler` (GPU only)."""
         self.cfg, self.model, self.device = cfg, model, torch.device(device)
         self.entity_table = entity_table
         self.fused_adam, self.library_adam = fused_adam, library_adam
@@ -263,6 +326,9 @@ class MELRunner:
         self.bucket = GradBucket(list(model.parameters()))
         self.global_batch_loss = global_batch_loss
         self.log = log
+        if profiling and self.device.type != "cuda":
+            raise ValueError("profiling times the library's launches: it needs the model on a GPU")
+        self.profiler = StepProfiler(out_dir=profile_dir, log=log) if profiling else None
 
     def _to_device(self, batch):
         return [t.to(self.device, non_blocking=True) for t in batch]
@@ -316,11 +382,15 @@ class MELRunner:
                 loss.backward()
                 self.bucket.allreduce_mean()
                 optimizer.step()
+                if self.profiler is not None:
+                    self.profiler.step()                               # on_train_batch_end (train.py:105-109)
             else:
                 with torch.no_grad():
                     loss = self.forward_step(batch, split, batch_idx)
             total += loss.detach()
             steps += 1
+        if training and self.profiler is not None:
+            self.profiler.stop()                                       # on_train_epoch_end (train.py:84-85)
         for m in meters:
             m.sync()
         mean_loss = float(total) / max(steps, 1)
@@ -345,6 +415,8 @@ class MELRunner:
             # LibraryAdam (default for the HIP Model on a GPU): the same update as torch's default, bit for bit, in one launch
             optimizer = make_adam(self.model, cfg.learning_rate, library=False if self.fused_adam else self.library_adam,
                                   fused=self.fused_adam)
+            if self.profiler is not None:
+                self.profiler.start()                                  # on_fit_start (train.py:101-103), per Trainer
             for _ in range(interval):
                 sampler = getattr(loaders[0], "sampler", None)
                 if hasattr(sampler, "set_epoch"):
@@ -377,7 +449,7 @@ def seed_everything(seed: int) -> None:
 
 def main(argv: Optional[Sequence[str]] = None) -> None:
     """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I] [--on-device]
-    [--precision bf16x3|f32] [--torch-adam] [--output-test-result PATH]; N GPUs: python -m torch.distributed.run --nproc-per-node N -m drin_amd.train ..."""
+    [--precision bf16x3|f32] [--torch-adam] [--output-test-result PATH] [--profiling]; N GPUs: python -m torch.distributed.run --nproc-per-node N -m drin_amd.train ..."""
     import argparse
     import os
 
@@ -397,6 +469,9 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the one-launch LibraryAdam (same arithmetic)")
     ap.add_argument("--output-test-result", default=None, metavar="PATH",
                     help="per-sample dump of the test split (args.output_test_result, train.py:16-17,40-43)")
+    ap.add_argument("--profiling", action="store_true",
+                    help="args.profiling (train.py:64-70): wait 1 / warmup 1 / active 3 steps x 2 cycles per fit through the library's "
+                         "profiler, kernel class -> ms per step written to log/profiler/drin_profile_<cycle>.json")
     ap.add_argument("--on-device", action="store_true",
                     help="every split (and, wikimel, the entity tables) resident on the GPU (create_device_splits, load_entity_table): "
                          "no host gather, no host-to-device copy in the step")
@@ -418,7 +493,8 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
         loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())
     model = Model(cfg, precision=a.precision).to(dev)
     runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print, entity_table=table,
-                       library_adam=False if a.torch_adam else None, output_test_result=a.output_test_result)
+                       library_adam=False if a.torch_adam else None, output_test_result=a.output_test_result,
+                       profiling=a.profiling)
     runner.fit(loaders, a.epochs, a.interval)
     if world > 1:
         dist.destroy_process_group()

@@ -441,8 +441,15 @@ def test_train_cli_runs_end_to_end(tmp_path, dataset, monkeypatch):
     monkeypatch.setattr(T, "DrinConfig", lambda **kw: cfg)
     lines = []
     monkeypatch.setattr("builtins.print", lambda *a, **k: lines.append(" ".join(map(str, a))))
-    T.main(["--data", str(tmp_path), "--dataset", dataset, "--on-device", "--output-test-result", dump])
+    monkeypatch.chdir(tmp_path)
+    T.main(["--data", str(tmp_path), "--dataset", dataset, "--on-device", "--output-test-result", dump]
+           + (["--profiling"] if dataset == "wikimel" else []))
     assert sum("test after epoch" in ln for ln in lines) == 2 and sum(ln.startswith("epoch ") for ln in lines) == 2
+    if dataset == "wikimel":   # args.profiling (train.py:64-70): wait 1, warmup 1, then the third (last) step of each fit is timed
+        import json
+        rep = json.load(open(tmp_path / "log" / "profiler" / "drin_profile_0.json"))
+        assert rep["steps"] == 1 and rep["kernel_ms_per_step"]["optim"] > 0 and rep["launches_per_step"]["optim"] == 1
+        assert sum(rep["launches_per_step"].values()) >= 30 and sum(ln.startswith("profile cycle 0") for ln in lines) == 2
     rows = open(dump).read().splitlines()
     import re
     assert sum(bool(re.match(r"^\d+:\t\[", r)) for r in rows) == 2 * 8   # two test passes x 8 mentions (the answer rows' repr may wrap)

@@ -255,3 +255,31 @@ def test_shard_sampler_properties():
         assert sorted(sum(exact, [])) == list(range(n))
 
     check()
+
+
+def test_step_profiler_follows_the_reference_schedule(tmp_path, monkeypatch):
+    """`StepProfiler` = `torch.profiler.schedule(wait=1, warmup=1, active=3, repeat=2)` of `train.py:64-70` over the
+    library's profiler: per fit, two cycles of (skip 1, run 1, time 3); an epoch that ends inside a cycle reports what it has."""
+    import json
+    from drin_amd import _lib
+    from drin_amd.train import StepProfiler
+    calls = []
+    monkeypatch.setattr(_lib, "profile_begin", lambda n: calls.append("begin"))
+    monkeypatch.setattr(_lib, "profile_end", lambda: (calls.append("end") or {"gemm": (3.0, 12), "optim": (0.375, 3), "edge": (0.0, 0)}))
+    prof = StepProfiler(out_dir=str(tmp_path))
+    prof.start()
+    opened_at = []
+    for step in range(14):
+        if prof.open:
+            opened_at.append(step)
+        prof.step()
+    prof.stop()
+    assert opened_at == [2, 3, 4, 7, 8, 9] and calls == ["begin", "end", "begin", "end"]
+    rep = json.load(open(tmp_path / "drin_profile_1.json"))
+    assert rep["steps"] == 3 and rep["kernel_ms_per_step"] == {"gemm": 1.0, "optim": 0.125} and rep["launches_per_step"]["gemm"] == 4
+    short = StepProfiler(out_dir=str(tmp_path / "short"))
+    short.start()
+    for _ in range(3):
+        short.step()
+    short.stop()                                        # the epoch ended after one timed step
+    assert short.reports[0]["steps"] == 1 and not short.open

@@ -329,6 +329,7 @@ class MELRunner:
         if profiling and self.device.type != "cuda":
             raise ValueError("profiling times the library's launches: it needs the model on a GPU")
         self.profiler = StepProfiler(out_dir=profile_dir, log=log) if profiling else None
+        self._epoch = None                                             # (current, last) for the epoch banners; set by fit()
 
     def _to_device(self, batch):
         return [t.to(self.device, non_blocking=True) for t in batch]
@@ -370,8 +371,11 @@ class MELRunner:
 
     def run_epoch(self, loader, split: int, optimizer: Optional[torch.optim.Optimizer]) -> StepLog:
         meters = [self.device_loss] if self.device_loss is not None else self.metrics
-        for m in meters:                                               # EpochLogger.epoch_start (train.py:72-74)
+        for m in meters:                                               # EpochLogger.epoch_start (train.py:72-77)
             m.reset()
+        if self.log and _rank() == 0 and self._epoch is not None:
+            from datetime import datetime
+            self.log(f"\n***** Epoch {self._epoch[0]}/{self._epoch[1]} - {('training', 'validating', 'testing')[split]} - {datetime.now()}")
         training = optimizer is not None
         self.model.train(training)
         total, steps = torch.zeros((), dtype=torch.float64, device=self.device), 0   # summed on the device: no per-step read-back
@@ -421,6 +425,7 @@ class MELRunner:
                 sampler = getattr(loaders[0], "sampler", None)
                 if hasattr(sampler, "set_epoch"):
                     sampler.set_epoch(epoch)
+                self._epoch = (epoch + 1, num_epoch)
                 tr = self.run_epoch(loaders[0], 0, optimizer)
                 va = self.run_epoch(loaders[1], 1, None)
                 hist.train.append(tr)
@@ -491,6 +496,12 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
         loaders = create_device_splits(cfg, a.data, dev, a.batch_size, _rank(), _world(), mention_mmap="r")
     else:
         loaders = create_datasets(cfg, a.data, a.batch_size, a.workers, _rank(), _world())
+    if _rank() == 0:                                                   # train.py:126-133: every setting, strings quoted
+        import dataclasses
+        print("=============== parameters ===============")
+        for f in sorted(dataclasses.fields(cfg), key=lambda f: f.name):
+            v = getattr(cfg, f.name)
+            print(f.name, "'" + v + "'" if isinstance(v, str) else v, sep=" = ")
     model = Model(cfg, precision=a.precision).to(dev)
     runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print, entity_table=table,
                        library_adam=False if a.torch_adam else None, output_test_result=a.output_test_result,

@@ -445,6 +445,9 @@ def test_train_cli_runs_end_to_end(tmp_path, dataset, monkeypatch):
     T.main(["--data", str(tmp_path), "--dataset", dataset, "--on-device", "--output-test-result", dump]
            + (["--profiling"] if dataset == "wikimel" else []))
     assert sum("test after epoch" in ln for ln in lines) == 2 and sum(ln.startswith("epoch ") for ln in lines) == 2
+    # train.py:126-133 (every setting, strings quoted) and the epoch banners of train.py:72-77
+    assert lines[0] == "=============== parameters ===============" and f"dataset_name '{dataset}'" in lines  # (the patched print joins with a blank)
+    assert sum("***** Epoch" in ln and " - training - " in ln for ln in lines) == 2 and sum(" - testing - " in ln for ln in lines) == 2
     if dataset == "wikimel":   # args.profiling (train.py:64-70): wait 1, warmup 1, then the third (last) step of each fit is timed
         import json
         rep = json.load(open(tmp_path / "log" / "profiler" / "drin_profile_0.json"))

@@ -86,6 +86,8 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.stub = args.stub
+        self.force = bool(getattr(args, "force_collective", False))
+        self.pg_error = None
         if self.world != args.gpus:
             raise SystemExit(f"bench.py: WORLD_SIZE={self.world} but --gpus {args.gpus}: start N ranks with "
                              f"`python bench.py --gpus N` (self-launching) or torch.distributed.run --nproc-per-node N ... --gpus N")
@@ -98,15 +100,34 @@ class Ctx:
         else:
             self.dev = torch.device("cuda", 0 if share else self.local_rank)
             torch.cuda.set_device(self.dev)
-        if self.world > 1:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            import datetime
-            limit = datetime.timedelta(seconds=300)          # a collective that never completes fails the run instead of hanging it
-            if self.stub or backend == "gloo":
-                dist.init_process_group("gloo", timeout=limit)
+        self.backend = "gloo" if (self.stub or backend == "gloo") else "nccl"
+        if self.world > 1 or self.force:
+            self.init_group()
+
+    def init_group(self):
+        """The process group: always at N > 1; at N = 1 only for --force-collective / the `train_step_rccl` leg (a world of
+        ONE rank - what a one-GPU box can run of the RCCL path).  Idempotent; returns whether a group is up."""
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if self.world == 1 and "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        import datetime
+        limit = datetime.timedelta(seconds=300)              # a collective that never completes fails the run instead of hanging it
+        try:
+            if self.backend == "gloo":
+                dist.init_process_group("gloo", timeout=limit, rank=self.rank, world_size=self.world)
             else:
-                dist.init_process_group("nccl", device_id=self.dev, timeout=limit)
+                dist.init_process_group("nccl", device_id=self.dev, timeout=limit, rank=self.rank, world_size=self.world)
+        except Exception as e:  # noqa: BLE001 - at N = 1 the group is an extra: reported, never fatal; at N > 1 it is the run
+            if self.world > 1:
+                raise
+            self.pg_error = f"{type(e).__name__}: {e}"
+            return False
+        return True
 
     def sync(self):
         if not self.stub:
@@ -145,8 +166,8 @@ class Ctx:
         return elapsed, per_rank, out
 
     def finish(self):
-        if self.world > 1:
-            import torch.distributed as dist
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
 
@@ -361,10 +382,19 @@ def cpu_baseline(cfg, sd, seconds=10.0):
         wd_sd = synth.make_state_dict(wd, 7)
         wd_batch = synth.make_batch(wd, 64, 3)
         it_w, el_w = _time_oracle(lambda: O.forward(wd_sd, wd_batch), 4.0, 2000)
+        b64 = None
+        if cfg.token_level_entities:
+            # the headline shape at the B = 64 SURVEY.md 8d names (1.4 GB of host features): one warm-up + up to three forwards
+            del batch
+            big = synth.make_batch(cfg, 64, 4)
+            it_b, el_b = _time_oracle(lambda: O.forward(sd, big), 3.0, 3)
+            b64 = it_b * 64 * N / el_b
+            del big
     return {"value": it * B * N / el, "unit": "pairs/s", "cores": host["threads_used"], "kind": "port",
             "host": host,
             "reference_style_loops_value": it_r * B * N / el_r,
             "wikidiverse_b64_value": it_w * 64 * wd.num_candidates_model / el_w,
+            "headline_shape_b64_value": b64,
             "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={N} fp32, torch "
                       f"{torch.get_num_threads()} threads, {el:.1f} s; reference-style loops {it_r} forwards {el_r:.1f} s; "
                       f"wikidiverse-shaped B=64 N={wd.num_candidates_model}: {it_w} forwards {el_w:.1f} s"}
@@ -561,10 +591,24 @@ def train_roofline(cfg, B, N, prof, steps, precision):
     return out
 
 
+def step_floor(cfg, B, N, bytes_per_pair, flops_per_pair, precision):
+    """What a training step cannot go below on this machine, from two measured rates: its compulsory input bytes at the
+    6.3 TB/s MI355X_MICROARCH.md measures for streaming reads, and its executed matrix-core FLOPs (three bf16 passes per
+    product in split-bf16 precision) at the 1.3 PF/s this library's own K-loops sustain.  `ms` = the
+    larger of the two (they could overlap at best); `serial_ms` = their sum (what back-to-back kernels could reach)."""
+    passes = 3 if precision in ("bf16x3",) else 1
+    hbm_ms = bytes_per_pair * B * N / 6.3e12 * 1e3
+    mfma_ms = passes * flops_per_pair * B * N / (1.3e15 if passes == 3 else 0.82 * PEAK_F32_MATRIX_TFLOPS * 1e12) * 1e3
+    return {"ms": max(hbm_ms, mfma_ms), "serial_ms": hbm_ms + mfma_ms, "hbm_ms": hbm_ms, "mfma_ms": mfma_ms,
+            "rates": "6.3 TB/s streaming reads (MI355X_MICROARCH.md); 1.3 PF/s executed bf16 (this library's K-loop, DESIGN.md 4.2)"}
+
+
 def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f32", train_form="gathered", train_entities=50_000,
-                graph=False, fused_adam=False, torch_loss=False, library_adam=True):
+                graph=False, fused_adam=False, torch_loss=False, library_adam=True, force_collective=False):
     """One optimisation step of train.py:30-56 per "step": forward (intermediates kept), TripletLoss, backward
-    through the HIP kernels, one RCCL all-reduce of the flat gradient bucket (world > 1), Adam."""
+    through the HIP kernels, the RCCL all-reduce of the flat gradient bucket (world > 1, or a forced world of one), Adam.
+    With collectives the bucket goes in two pieces, the GCN layers' started inside backward (GradBucket(overlap=True));
+    `allreduce_exposed_ms` = what the step's stream still waits for, `allreduce_ms` = the one-piece collective after backward."""
     from drin_amd import _lib
     from drin_amd.metrics import DeviceLossMetric
     from drin_amd.model import Model
@@ -598,21 +642,26 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
         from drin_amd.metrics import TripletLoss
         loss_fn = TripletLoss(cfg.triplet_margin)
     opt = make_adam(model, cfg.learning_rate, library=library_adam and not graph and not fused_adam, capturable=graph, fused=fused_adam)
-    bucket = GradBucket(list(model.parameters()))
+    import torch.distributed as dist
+    collectives = world > 1 or (force_collective and dist.is_available() and dist.is_initialized())
+    overlap = collectives and not graph and os.environ.get("DRIN_NO_OVERLAP") != "1"
+    plain_bucket = GradBucket(list(model.parameters()), force=force_collective)
+    bucket = GradBucket(list(model.parameters()), force=force_collective, overlap=True, model=model) if overlap else plain_bucket
     ar_events = []
 
-    def eager_step(record=False):
+    def eager_step(record=False, use=None):
+        use = use or bucket
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(y, model(batch if batch is not None else ib.gathered()))
         loss.backward()
-        if record and world > 1:
+        if record and collectives:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            bucket.allreduce_mean()
+            use.allreduce_mean()
             e1.record()
             ar_events.append((e0, e1))
         else:
-            bucket.allreduce_mean()
+            use.allreduce_mean()
         opt.step()
         return loss
 
@@ -641,8 +690,26 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
         eager_step(record=True)
     prof = _lib.profile_end()
     ctx.sync()
-    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
+    exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
+    ar_ms = exposed_ms
+    if overlap:                                       # the same step with the one-piece collective after backward, for comparison
+        ar_events.clear()
+        model._layers_ready_hook = None
+        for _ in range(steps):
+            eager_step(record=True, use=plain_bucket)
+        ctx.sync()
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
+        model._layers_ready_hook = bucket._layers_ready
     N = cfg.num_candidates_model
+    ab = algorithmic_bytes(cfg, full[:14]) if full is not None else None
+    roof = train_roofline(cfg, B, N, prof, steps, precision)
+    floor = step_floor(cfg, B, N, ab["whole_path"], roof["flops_per_pair"], precision) if (ab and roof) else None
+    coll = None
+    if collectives:
+        coll = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_world_of_one": world == 1,
+                "pieces": 2 if overlap else 1, "in_place": bool(bucket.in_place), "collectives_issued": bucket.collectives + plain_bucket.collectives * (plain_bucket is not bucket),
+                "steps_overlapped": bucket.overlapped}
+    bucket.close()
     return {
         "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)" + (" [hipGraph replay]" if graph else ""),
         "value": B * N * world * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps,
@@ -654,11 +721,12 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
                                    "table-tokens": f", candidates gathered from a device-resident table of {train_entities} entities with torch indexing every step"}[train_form]),
                    "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
         "rank_ms_per_step": [t / steps * 1e3 for t in per_rank],
-        "allreduce_ms": ar_ms, "allreduce_bytes": bucket.nbytes(),
+        "allreduce_ms": ar_ms, "allreduce_exposed_ms": exposed_ms, "allreduce_bytes": plain_bucket.nbytes(), "collective": coll,
+        "step_floor_ms": floor["ms"] if floor else None, "step_floor": floor,
         "optimizer": opt.describe() if hasattr(opt, "describe") else type(opt).__name__,
         "library_launches_per_step": sum(v[1] for v in prof.values()) / steps,
         "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items()},
-        "roofline": train_roofline(cfg, B, N, prof, steps, precision),
+        "roofline": roof,
         "final_loss": float(loss.detach())}
 
 
@@ -672,7 +740,7 @@ def stub_worker(ctx, args):
     if os.environ.get("DRIN_BENCH_STUB_FAIL_RANK") == str(ctx.rank):    # tests: a rank that dies must fail the parent
         raise SystemExit(3)
     params = [torch.nn.Parameter(torch.zeros(257)), torch.nn.Parameter(torch.zeros(31, 3))]
-    bucket = GradBucket(params)
+    bucket = GradBucket(params, force=ctx.force)
 
     def step():
         time.sleep(1e-3 * (ctx.rank + 1))
@@ -691,7 +759,7 @@ def stub_worker(ctx, args):
                           "value": args.steps * ctx.world / elapsed, "unit": "steps/s", "n_gpus": ctx.world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
-                          "config": {"workload": f"stub {args.mode}"},
+                          "config": {"workload": f"stub {args.mode}"}, "collectives_issued": bucket.collectives,
                           "rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}), flush=True)
     ctx.finish()
 
@@ -734,6 +802,9 @@ def parse_args(argv=None):
     ap.add_argument("--fused-adam", action="store_true", help="train mode: torch's fused single-kernel Adam (different rounding)")
     ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.optim.Adam (multi-tensor, ~9 launches) instead of the library's one-launch Adam over the flat parameter bucket")
     ap.add_argument("--torch-loss", action="store_true", help="train mode: the torch TripletLoss instead of the library's loss/metric call")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: initialise a process group of ONE rank (RCCL unless DRIN_BENCH_BACKEND=gloo) and run the training step's "
+                         "gradient all-reduce in it - the real collective code path on a one-GPU box; allreduce_ms is then non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--legs", default="auto",
                     help="secondary legs of the default run, comma separated: f32_exact,wikimel_bf16_features,wikidiverse_b4,train_step,train_b512,wikidiverse,table_cache | all | none "
@@ -797,7 +868,10 @@ def main(argv=None):
 
     if args.mode == "train":
         line = bench_train(ctx, cfg, sd, args.batch or 64, args.steps, args.warmup, args.precision, args.features, args.train_form,
-                           args.train_entities, args.graph, args.fused_adam, args.torch_loss, not args.torch_adam)
+                           args.train_entities, args.graph, args.fused_adam, args.torch_loss, not args.torch_adam,
+                           force_collective=args.force_collective)
+        if ctx.pg_error:
+            line["collective_error"] = ctx.pg_error
         if rank == 0:
             print(json.dumps(line), flush=True)
         return ctx.finish()
@@ -897,6 +971,14 @@ def main(argv=None):
 
     if "train_step" in legs:
         extra["train_step"] = leg_guard("train_step", lambda: bench_train(ctx, cfg, sd, 64, 20, 30))
+        if world == 1:
+            def rccl_leg():
+                # BASELINE config 4's collective code path as far as ONE GPU can run it: an RCCL process group of one rank, the
+                # flat gradient bucket all-reduced (ReduceOp.AVG, in place) in two pieces, the first started inside backward
+                if not ctx.init_group():
+                    return {"error": "process group of one rank: " + str(ctx.pg_error)}
+                return bench_train(ctx, cfg, sd, 64, 20, 30, force_collective=True)
+            extra["train_step_rccl_world1"] = leg_guard("train_step_rccl_world1", rccl_leg)
 
     if "train_b512" in legs and world == 1:
         # the same step at a rate-bound batch, and with the candidates indexed into a device-resident entity table
@@ -942,7 +1024,7 @@ def main(argv=None):
                                     f"--mentions 1000000 --chunk 4096 runs the full 1 M)",
                         "value": mentions * N / el, "ms_per_step": el / n_chunks * 1e3, "steps": n_chunks,
                         "resident_chunk_value": ln["value"],
-                        "parity": parity_of_timed_batch(tc, tsd, last, o2, n_slices=2, width=1)})
+                        "parity": parity_of_timed_batch(tc, tsd, last, o2, n_slices=8, width=1)})
             return res
         extra["table_cache"] = leg_guard("table_cache", table_leg)
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DRIN_LIB_PATH: another build of the same library (the sanitizer build of `python -m drin_amd.build --asan-host`)
 LIB_PATH = os.environ.get("DRIN_LIB_PATH") or os.path.join(_HERE, "libdrin_hip.so")
 MAX_LAYERS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
@@ -84,6 +84,8 @@ EXPORTS = {
                                C.c_size_t, C.c_void_p, C.c_int, C.POINTER(DrinTraceC), C.c_void_p]),
     "drin_backward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                 C.c_size_t, C.c_void_p, C.POINTER(DrinParamGradsC), C.c_void_p]),
+    "drin_backward_staged": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
+                                       C.c_size_t, C.c_void_p, C.POINTER(DrinParamGradsC), C.c_void_p, C.c_void_p]),
     "drin_fused_supported": (C.c_int, [C.POINTER(DrinConfigC)]),
     "drin_prepared_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
     "drin_fused_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),

@@ -111,15 +111,19 @@ def config_from_reference_args(args=None) -> DrinConfig:
 
 
 def default_config() -> DrinConfig:
-    """What `Model()` without arguments builds: the configuration of an importable reference `common.args` (the drop-in
-    case: this package sits in a checkout of the reference, `INTEGRATION.md`), else the reference's WikiDiverse defaults."""
+    """What `Model()` without arguments builds.  Inside the reference's driver - `train.py:2-3` has imported `common.args`
+    before it builds `model_module.Model()` (`train.py:136`), and that module carries the reference's settings
+    (`model_type`, `gcn_edge_type`, `num_candidates_data`) - its configuration; anywhere else the reference's WikiDiverse
+    defaults.  Nothing is imported by name here (an unrelated package called `common` on `sys.path` can never change the
+    model): only a module the caller's process has ALREADY loaded is read; `reference_shim.Model` is the explicit form."""
+    import logging
     import sys
-    if "common.args" in sys.modules:
-        return config_from_reference_args(sys.modules["common.args"])
-    try:
-        return config_from_reference_args()
-    except ImportError:
-        return DrinConfig()
+    args = sys.modules.get("common.args")
+    if args is not None and all(hasattr(args, k) for k in ("model_type", "gcn_edge_type", "num_candidates_data")):
+        logging.getLogger("drin_amd").info("Model(): configuration read from the loaded module common.args (%s)",
+                                           getattr(args, "__file__", "?"))
+        return config_from_reference_args(args)
+    return DrinConfig()
 
 
 def wikidiverse_config(**kw) -> DrinConfig:

@@ -498,8 +498,10 @@ int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, 
       DRIN_TRY(launch_gemm_nn(dy, n_out, w, k, dx, k, rows, k, n_out, false, precision, st));
     }
   }
+  // (stream order makes the scratch reusable product after product; every split reduction goes through it and is added in
+  //  order - without scratch one workgroup per output tile / per 256 columns walks the whole reduction: no atomics either way)
   if (dw) DRIN_TRY(launch_gemm_tn(dy, n_out, x, k, dw, k, rows, n_out, k, precision, st, scratch, scratch ? scratch_floats : 0));
-  if (db) DRIN_TRY(launch_colsum(dy, db, rows, n_out, st));
+  if (db) DRIN_TRY(launch_colsum(dy, db, rows, n_out, st, scratch, scratch ? scratch_floats : 0));
   return DRIN_OK;
 }
 
@@ -758,6 +760,12 @@ const char* drin_kernel_class_name(int kernel_class) {
 
 int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                   size_t workspace_bytes, const float* grad_scores, const drin_param_grads* grads, void* stream) {
+  return drin_backward_staged(cfg, batch, params, workspace, workspace_bytes, grad_scores, grads, nullptr, stream);
+}
+
+int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
+                         size_t workspace_bytes, const float* grad_scores, const drin_param_grads* grads,
+                         void* layers_ready_event, void* stream) {
   RoctxRange range("drin_backward");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
@@ -824,6 +832,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
   float* const tnp = L.tn_part_floats ? ws + L.tn_part : nullptr;  // partial tiles of the split-bf16 dW products
   const size_t tnf = L.tn_part_floats;
+  float* const smp = ws + L.small_part;     // slices of the mention-sized exact-fp32 dW products
+  float* const csp = ws + L.colsum_part;    // partial rows of the bias column sums
   // dX (+)= dY W.  Pair-sized products in split-bf16 precision run on the NT kernel against W^T, transposed into
   // workspace scratch right before use (a D x D transpose is ~3 us; the product it feeds is 2.5x faster than
   // the exact-fp32 MFMA one); everything else takes the exact fp32 NN kernel.
@@ -871,7 +881,8 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
   // (db: the bias gradient that goes with it = the column sums of dy; the group takes them from the rows it stages)
   auto dw_product = [&](const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, int64_t lddw, int64_t rows,
                         int n_out, int k_red, const int64_t* x_index = nullptr, float* db = nullptr) -> int {
-    const bool grouped = dw != nullptr && defer_dw && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x);
+    const bool grouped = dw != nullptr && defer_dw && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x) &&
+                         gemm_tn_bf16x3_scratch_ok(dw, lddw, n_out, k_red, tnp, tnf);
     if (db != nullptr && !(grouped && lddy == n_out)) {
       DRIN_TRY(bias_sums.add(dy, db, rows, n_out));
       db = nullptr;
@@ -886,9 +897,10 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     }
     if (x_index != nullptr) return launch_gemm_tn_bf16x3(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, st, tnp, tnf, x_index);
     const bool takes_x3 = x3 && gemm_tn_bf16x3_fits(lddy, ldx, rows, n_out, k_red, dy, x);
-    if (!vec && !takes_x3 && rows <= 2048 && (n_out % 4) == 0 && (k_red % 4) == 0 && (prec == DRIN_PREC_F32 || x3)) {
+    if (!vec && !takes_x3 && rows <= 2048 && (n_out % 4) == 0 && (k_red % 4) == 0 && (prec == DRIN_PREC_F32 || x3) &&
+        aligned16(dw) && (lddw % 4) == 0) {
       if (dw_small.n == F32GemmGroup::MAX) {
-        DRIN_TRY(launch_gemm_tn_f32_group(dw_small, st));
+        DRIN_TRY(launch_gemm_tn_f32_group(dw_small, st, smp, L.small_part_floats));
         dw_small = F32GemmGroup();
       }
       return dw_small.add_tn(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red);
@@ -945,13 +957,13 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
       const int H = D / 2;
       DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st, act_e));  // dz
       if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st, tnp, tnf));
-      DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st));
+      DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st, csp, L.colsum_part_floats));
       DRIN_TRY(gemm_nn(dpre, D, W.w_m, g_e[cur], D, 4 * (int64_t)M, D, D, false));  // d(cat + e)
       DRIN_TRY(launch_edge_pre_vec_bwd(g_e[cur], dfu, dfv, B, N, D, st));
       if (G.w_v) DRIN_TRY(launch_gemm_tn(dfv, H, et, D, G.w_v, D, 2 * (int64_t)M, H, D, prec, st, tnp, tnf));
-      DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, H, st));
+      DRIN_TRY(launch_colsum(dfv, G.b_v, 2 * (int64_t)M, H, st, csp, L.colsum_part_floats));
       if (G.w_u) DRIN_TRY(launch_gemm_tn(dfu, H, mt, D, G.w_u, D, 2 * (int64_t)B, H, D, prec, st, tnp, tnf));
-      DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, H, st));
+      DRIN_TRY(launch_colsum(dfu, G.b_u, 2 * (int64_t)B, H, st, csp, L.colsum_part_floats));
       de_extra = g_e[cur];
     } else if (edge_update) {
       // (d) e'_k = sigmoid(mean_d(fu fv) + e_k)  (model.py:148-153,133)
@@ -1003,11 +1015,13 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     // dfv / dfu are overwritten by the next layer down: their column sums go now - except layer 0's, which share the
     // launch of the vertex encoders' bias gradients below
     if (l > 0 && bias_sums.n > 0) {
-      DRIN_TRY(launch_colsum_batch(bias_sums, st));
+      DRIN_TRY(launch_colsum_batch(bias_sums, st, csp, L.colsum_part_floats));
       bias_sums = ColsumBatch();
     }
   }
 
+  // what is collected up to here belongs to the GCN layers, what follows to the vertex encoders (drin_backward_staged)
+  const int layer_sums = bias_sums.n, layer_small = dw_small.n, layer_group = dw_group.n;
   // VertexEncoder (model.py:26-46): four Linears over the pooled inputs
   const float* g_mt = g_vm[0];
   const float* g_mi = g_vm[0] + BD;
@@ -1019,9 +1033,36 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
     DRIN_TRY(dw_product(g_mi, D, P.mention_image, R, grads->w_mention_image, R, B, D, R, nullptr, grads->b_mention_image));
     DRIN_TRY(dw_product(g_ei, D, P.entity_image, R, grads->w_entity_image, R, (int64_t)M, D, R, eidx, grads->b_entity_image));
   }
-  DRIN_TRY(launch_colsum_batch(bias_sums, st));
-  DRIN_TRY(launch_gemm_tn_f32_group(dw_small, st));
-  return launch_gemm_tn_group(dw_group, st, tnp, tnf);
+  // The split reductions left at the end of the pass - the bias column sums, the mention-sized and the pair-sized weight
+  // gradients - each store their slices, and ONE slice-sum launch adds them all to the gradients in a fixed order (two
+  // products of one destination, dW_h's mention and entity rows, as two segments of one entry).
+  // Staged (layers_ready_event): the same launches in two parts - first everything that lands in a GCN layer's gradients,
+  // then the event, then the vertex encoders' part.  Every product keeps the slices of the one-part launch (the whole
+  // group's target slice length goes to both parts; products of one destination are always in the same part), so the
+  // gradients are the same bit for bit; the scratch regions are reused in stream order.
+  const int64_t target = tn_group_target(dw_group, tnf);
+  auto flush = [&](int s0, int s1, int f0, int f1, int g0, int g1) -> int {
+    ColsumBatch cs;
+    for (int i = s0; i < s1; ++i) {
+      cs.x[cs.n] = bias_sums.x[i], cs.out[cs.n] = bias_sums.out[i], cs.rows[cs.n] = bias_sums.rows[i];
+      cs.c4[cs.n] = bias_sums.c4[i], cs.by[cs.n] = bias_sums.by[i];
+      ++cs.n;
+    }
+    F32GemmGroup fg;
+    for (int i = f0; i < f1; ++i) fg.item[fg.n] = dw_small.item[i], fg.bias_of[fg.n] = nullptr, ++fg.n;
+    TnGroup tg;
+    for (int i = g0; i < g1; ++i) tg.item[tg.n++] = dw_group.item[i];
+    SliceSum sums;
+    DRIN_TRY(launch_colsum_batch(cs, st, csp, L.colsum_part_floats, &sums));
+    DRIN_TRY(launch_gemm_tn_f32_group(fg, st, smp, L.small_part_floats, &sums));
+    DRIN_TRY(launch_gemm_tn_group(tg, st, tnp, tnf, &sums, target));
+    return launch_slice_sum(sums, st);
+  };
+  if (layers_ready_event == nullptr) return flush(0, bias_sums.n, 0, dw_small.n, 0, dw_group.n);
+  DRIN_TRY(flush(0, layer_sums, 0, layer_small, 0, layer_group));
+  hipError_t ev = hipEventRecord((hipEvent_t)layers_ready_event, st);
+  if (ev != hipSuccess) return hip_fail(ev, "hipEventRecord(layers_ready)");
+  return flush(layer_sums, bias_sums.n, layer_small, dw_small.n, layer_group, dw_group.n);
 }
 
 }  // extern "C"

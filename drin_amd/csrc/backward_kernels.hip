@@ -1,8 +1,8 @@
 // Backward of the row kernels of the path (loss.backward() through drin/model.py:121-153,207-209).
 // Same style as the forward: one wave per row / pair, 16-byte lane accesses, shuffle reductions;
 // column sums that feed bias / LayerNorm gradients are accumulated per lane across a grid-stride
-// row loop, combined across the block's waves in LDS and added to the caller's gradient buffer
-// with one fp32 atomic per column per block.
+// row loop, combined across the block's waves in LDS, stored as one partial row per block and added
+// to the caller's gradient buffer in block order by a second launch (no atomics: reproducible bits).
 #include "device_utils.h"
 #include "internal.h"
 
@@ -342,44 +342,11 @@ int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rs
 
 // ------------------------------------------------------------------------------------------------
 // out[c] += sum_rows x[row, c]      (bias gradients of W_u / W_v / the vertex encoders)
-__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
-                                                int C4) {
-  __shared__ float4 comb[4][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c4 = blockIdx.x * 64 + lane;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c4 < C4) {
-    const int64_t step = (int64_t)gridDim.y * 4;
-    const float* col = x + (int64_t)c4 * 4;
-    int64_t row = (int64_t)blockIdx.y * 4 + wave;
-    for (; row + 3 * step < rows; row += 4 * step) {  // four independent loads in flight per wave
-      const float4 v0 = ld4(col + row * (int64_t)C4 * 4), v1 = ld4(col + (row + step) * (int64_t)C4 * 4);
-      const float4 v2 = ld4(col + (row + 2 * step) * (int64_t)C4 * 4), v3 = ld4(col + (row + 3 * step) * (int64_t)C4 * 4);
-      acc = acc + ((v0 + v1) + (v2 + v3));
-    }
-    for (; row < rows; row += step) acc = acc + ld4(col + row * (int64_t)C4 * 4);
-  }
-  comb[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && c4 < C4) {
-    const float4 t = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
-    atomicAdd(out + c4 * 4 + 0, t.x);
-    atomicAdd(out + c4 * 4 + 1, t.y);
-    atomicAdd(out + c4 * 4 + 2, t.z);
-    atomicAdd(out + c4 * 4 + 3, t.w);
-  }
-}
-
-// up to 8 column sums in one launch (blockIdx.z = which): the bias gradients of one backward pass
-__global__ void __launch_bounds__(256) k_colsum_batch(const ColsumBatch b) {
-  __shared__ float4 comb[4][64];
-  const int seg = blockIdx.z;
-  const float* __restrict__ x = b.x[seg];
-  float* __restrict__ out = b.out[seg];
-  const int64_t rows = b.rows[seg];
-  const int C4 = b.c4[seg];
-  const int by = b.by[seg];
-  if ((int)blockIdx.y >= by || (int)blockIdx.x * 64 >= C4) return;   // uniform per block
+// Workgroup (x, y) sums the rows y, y + gridDim.y, ... of 256 columns (four waves interleaved, combined through LDS in a
+// fixed order) and stores the sums as row y of `partial` ([gridDim.y][C]); a SliceSum launch adds the rows to out in
+// order.  partial == NULL (one workgroup per 256 columns, gridDim.y == 1): added to out in place.  No atomics.
+__device__ __forceinline__ void colsum_block(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ partial,
+                                             int64_t rows, int C4, int by, float4 (*comb)[64]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c4 = blockIdx.x * 64 + lane;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -398,11 +365,37 @@ __global__ void __launch_bounds__(256) k_colsum_batch(const ColsumBatch b) {
   __syncthreads();
   if (wave == 0 && c4 < C4) {
     const float4 t = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
-    atomicAdd(out + c4 * 4 + 0, t.x);
-    atomicAdd(out + c4 * 4 + 1, t.y);
-    atomicAdd(out + c4 * 4 + 2, t.z);
-    atomicAdd(out + c4 * 4 + 3, t.w);
+    if (partial != nullptr) {
+      st4(partial + ((int64_t)blockIdx.y * C4 + c4) * 4, t);
+    } else {
+      st4(out + c4 * 4, ld4(out + c4 * 4) + t);
+    }
   }
+}
+
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ partial,
+                                                int64_t rows, int C4) {
+  __shared__ float4 comb[4][64];
+  colsum_block(x, out, partial, rows, C4, (int)gridDim.y, comb);
+}
+
+// up to 8 column sums in one launch (blockIdx.z = which): the bias gradients of one backward pass
+struct ColsumArgs {
+  const float* x[8];
+  float* partial[8];
+  int64_t rows[8];
+  int c4[8], by[8];
+};
+__global__ void __launch_bounds__(256) k_colsum_batch(const ColsumArgs b) {
+  __shared__ float4 comb[4][64];
+  const int seg = blockIdx.z;
+  if ((int)blockIdx.y >= b.by[seg] || (int)blockIdx.x * 64 >= b.c4[seg]) return;   // uniform per block
+  colsum_block(b.x[seg], nullptr, b.partial[seg], b.rows[seg], b.c4[seg], b.by[seg], comb);
+}
+
+static int colsum_slices(int64_t nrows) {
+  const int64_t want = cdiv(nrows, 4 * 16);
+  return (int)(want < 1 ? 1 : (want > kColsumMaxSlices ? kColsumMaxSlices : want));
 }
 
 int ColsumBatch::add(const float* src, float* dst, int64_t nrows, int C) {
@@ -411,37 +404,61 @@ int ColsumBatch::add(const float* src, float* dst, int64_t nrows, int C) {
     set_error("colsum: C=%d must be a multiple of 4 (and at most 8 sums per batch)", C);
     return DRIN_E_SHAPE;
   }
-  const int64_t want = cdiv(nrows, 4 * 16) < 256 ? cdiv(nrows, 4 * 16) : 256;
-  x[n] = src, out[n] = dst, rows[n] = nrows, c4[n] = C / 4, by[n] = (int)(want < 1 ? 1 : want);
+  x[n] = src, out[n] = dst, rows[n] = nrows, c4[n] = C / 4, by[n] = colsum_slices(nrows);
   ++n;
   return DRIN_OK;
 }
 
-int launch_colsum_batch(const ColsumBatch& b, hipStream_t st) {
+int launch_colsum_batch(const ColsumBatch& b, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer) {
   if (b.n == 0) return DRIN_OK;
+  SliceSum local;
+  SliceSum& sums = defer != nullptr ? *defer : local;
+  ColsumArgs a;
   int gx = 1, gy = 1;
+  size_t used = 0;
   for (int i = 0; i < b.n; ++i) {
     gx = gx > (int)cdiv(b.c4[i], 64) ? gx : (int)cdiv(b.c4[i], 64);
     gy = gy > b.by[i] ? gy : b.by[i];
+    const size_t need = (size_t)b.by[i] * b.c4[i] * 4;
+    if (scratch == nullptr || !aligned16(scratch) || used + need > scratch_floats) {
+      set_error("colsum batch: %zu floats of slice scratch, %zu needed", scratch_floats, used + need);
+      return DRIN_E_WORKSPACE;
+    }
+    a.x[i] = b.x[i], a.partial[i] = scratch + used, a.rows[i] = b.rows[i], a.c4[i] = b.c4[i], a.by[i] = b.by[i];
+    DRIN_TRY(sums.add(b.out[i], b.c4[i] * 4, 1, b.c4[i] * 4, scratch + used, b.by[i]));
+    used += need;
   }
-  KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_colsum_batch, dim3((unsigned)gx, (unsigned)gy, (unsigned)b.n), dim3(256), 0, st, b);
-  DRIN_CHECK_LAUNCH("k_colsum_batch");
-  return DRIN_OK;
+  {
+    KernelTimer timer(DRIN_KC_GCN, st);
+    hipLaunchKernelGGL(k_colsum_batch, dim3((unsigned)gx, (unsigned)gy, (unsigned)b.n), dim3(256), 0, st, a);
+    DRIN_CHECK_LAUNCH("k_colsum_batch");
+  }
+  return defer != nullptr ? DRIN_OK : launch_slice_sum(local, st);
 }
 
-int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st) {
+int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st, float* scratch, size_t scratch_floats) {
   if (rows <= 0 || !out) return DRIN_OK;
   if (C % 4) {
     set_error("colsum: C=%d must be a multiple of 4", C);
     return DRIN_E_SHAPE;
   }
-  const int64_t by = cdiv(rows, 4 * 16) < 256 ? cdiv(rows, 4 * 16) : 256;
-  KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(C / 4, 64), (unsigned)(by < 1 ? 1 : by)), dim3(256), 0, st, x, out,
-                     rows, C / 4);
-  DRIN_CHECK_LAUNCH("k_colsum");
-  return DRIN_OK;
+  if (!aligned16(out) || !aligned16(x)) {
+    set_error("colsum: operands must be 16-byte aligned");
+    return DRIN_E_ALIGN;
+  }
+  int by = colsum_slices(rows);
+  const bool sliced = by > 1 && scratch != nullptr && aligned16(scratch) && (size_t)by * C <= scratch_floats;
+  if (!sliced) by = 1;
+  {
+    KernelTimer timer(DRIN_KC_GCN, st);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(C / 4, 64), (unsigned)by), dim3(256), 0, st, x, out,
+                       sliced ? scratch : (float*)nullptr, rows, C / 4);
+    DRIN_CHECK_LAUNCH("k_colsum");
+  }
+  if (!sliced) return DRIN_OK;
+  SliceSum sums;
+  DRIN_TRY(sums.add(out, C, 1, C, scratch, by));
+  return launch_slice_sum(sums, st);
 }
 
 // ------------------------------------------------------------------------------------------------

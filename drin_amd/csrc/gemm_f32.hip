@@ -96,7 +96,9 @@ __device__ __forceinline__ float4 read_frag(const float* __restrict__ lds, int r
   }
 }
 
-enum : int { GEMM_ACCUMULATE = 1, GEMM_ATOMIC = 2, GEMM_PARTIAL = 4 };  // PARTIAL: split z writes its tile to C + z * part_stride
+// PARTIAL: split z writes its tile to C + z * part_stride (a slice reduction adds them in order; there is no atomic epilogue:
+// every split reduction of this library is reproducible bit for bit)
+enum : int { GEMM_ACCUMULATE = 1, GEMM_PARTIAL = 4 };
 
 // BM x BN output tile (128 or 64 each): 4 waves as 2 x 2, each wave (BM/2) x (BN/2)
 // (tile_x / tile_y / split: the workgroup's column tile, row tile and K slice - blockIdx of the one-problem kernel)
@@ -188,8 +190,6 @@ __device__ __forceinline__ void gemm_f32_tile(const float* __restrict__ A, int64
         const float val = acc[i][j][v] + bv;
         if (flags & GEMM_PARTIAL) {
           dst[(int64_t)split * part_stride] = acc[i][j][v];  // bias is added by the reduction
-        } else if (flags & GEMM_ATOMIC) {
-          atomicAdd(dst, val);
         } else if (flags & GEMM_ACCUMULATE) {
           *dst += val;
         } else {
@@ -301,6 +301,76 @@ int launch_splitk_reduce(const float* partial, int splits, int64_t part_stride, 
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, st, partial, splits, part_stride,
                      bias, y, ldy, M, N / 4, accumulate ? 1 : 0);
   DRIN_CHECK_LAUNCH("k_splitk_reduce");
+  return DRIN_OK;
+}
+
+// ---- SliceSum (internal.h): y += its segments' slices, in order --------------------------------------------------------
+__global__ void __launch_bounds__(256) k_slice_sum(const SliceSum g) {
+  int di = 0;
+  for (int i = 1; i < g.n; ++i) di = blockIdx.x >= g.dst[i].first_block ? i : di;
+  const SliceSum::Dst& d = g.dst[di];
+  const int64_t i = (int64_t)(blockIdx.x - d.first_block) * 256 + threadIdx.x;
+  const int64_t elems = (int64_t)d.rows * d.c4;
+  if (i >= elems) return;
+  const int r = (int)(i / d.c4), c4 = (int)(i - (int64_t)r * d.c4);
+  const int64_t stride = elems * 4;
+  float* dst = d.y + (int64_t)r * d.ldy + c4 * 4;
+  float4 total = ld4(dst);
+  for (int si = d.seg_head; si >= 0; si = g.seg[si].next) {
+    const float* p = g.seg[si].partial + i * 4;
+    const int slices = g.seg[si].slices;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int z = 0;
+    for (; z + 4 <= slices; z += 4) {  // four chains (the loads of a trip are independent), fixed association
+      s0 = s0 + ld4(p + z * stride);
+      s1 = s1 + ld4(p + (z + 1) * stride);
+      s2 = s2 + ld4(p + (z + 2) * stride);
+      s3 = s3 + ld4(p + (z + 3) * stride);
+    }
+    for (; z < slices; ++z) s0 = s0 + ld4(p + z * stride);
+    total = total + ((s0 + s1) + (s2 + s3));
+  }
+  st4(dst, total);
+}
+
+int SliceSum::add(float* y, int64_t ldy, int rows, int cols, const float* partial, int slices) {
+  if (y == nullptr || partial == nullptr || rows <= 0 || cols <= 0 || slices <= 0) return DRIN_OK;
+  if ((cols % 4) || !aligned16(y) || !aligned16(partial) || (rows > 1 && (ldy % 4))) {
+    set_error("slice sum: %d x %d destination (ld %lld) outside the kernel's contract (16-byte rows)", rows, cols, (long long)ldy);
+    return DRIN_E_ALIGN;
+  }
+  int di = -1;
+  for (int i = 0; i < n; ++i)
+    if (dst[i].y == y) di = i;
+  if (di >= 0 && (dst[di].rows != rows || dst[di].c4 != cols / 4 || (rows > 1 && dst[di].ldy != ldy))) {
+    set_error("slice sum: one destination given as %d x %d and as %d x %d", dst[di].rows, dst[di].c4 * 4, rows, cols);
+    return DRIN_E_SHAPE;
+  }
+  if ((di < 0 && n == MAX_DST) || n_seg == MAX_SEG) {
+    set_error("internal: slice sum over more than %d destinations / %d segments", MAX_DST, MAX_SEG);
+    return DRIN_E_SHAPE;
+  }
+  const int si = n_seg++;
+  seg[si] = {partial, slices, -1};
+  if (di < 0) {
+    dst[n++] = {y, ldy, rows, cols / 4, 0u, si, si};
+  } else {
+    seg[dst[di].seg_tail].next = si;
+    dst[di].seg_tail = si;
+  }
+  return DRIN_OK;
+}
+
+int launch_slice_sum(SliceSum& s, hipStream_t st) {
+  if (s.n == 0) return DRIN_OK;
+  int64_t blocks = 0;
+  for (int i = 0; i < s.n; ++i) {
+    s.dst[i].first_block = (unsigned)blocks;
+    blocks += cdiv((int64_t)s.dst[i].rows * s.dst[i].c4, 256);
+  }
+  KernelTimer timer(DRIN_KC_GEMM, st);
+  hipLaunchKernelGGL(k_slice_sum, dim3((unsigned)blocks), dim3(256), 0, st, s);
+  DRIN_CHECK_LAUNCH("k_slice_sum");
   return DRIN_OK;
 }
 
@@ -547,22 +617,41 @@ int F32GemmGroup::add_tn(const float* a, int64_t lda, const float* b, int64_t ld
 }
 
 // y[n, k] += sum_m a[m, n] b[m, k] for every item: the mention-sized branch of launch_gemm_tn (64 x 64 tiles, up to four
-// slices of the reduction, fp32 atomics onto y), all items in one launch
-int launch_gemm_tn_f32_group(const F32GemmGroup& grp, hipStream_t st) {
+// slices of the reduction), all items in one launch.  A product that is alone on its destination and has one slice adds
+// to it in place (one workgroup per output tile: no race); any other stores its slices to the scratch and the slice sum
+// adds them in order - two products of one destination as two segments of one entry.
+int launch_gemm_tn_f32_group(const F32GemmGroup& grp, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer) {
   if (grp.n == 0) return DRIN_OK;
   GroupArgs ga;
   ga.n = grp.n;
+  SliceSum local;
+  SliceSum& sums = defer != nullptr ? *defer : local;
   unsigned items = 0;
+  size_t used = 0;
   for (int i = 0; i < grp.n; ++i) {
     const auto& it = grp.item[i];
-    int splits = (int)cdiv(it.M, 4 * BK);
-    splits = splits > 4 ? 4 : (splits < 1 ? 1 : splits);
+    int splits = small_tn_slices(it.M);
     const int kps = (int)(cdiv(cdiv(it.M, splits), BK) * BK);
     splits = (int)cdiv(it.M, kps);
+    bool shared = false;   // another product of this launch adds to the same destination
+    for (int j = 0; j < grp.n; ++j) shared = shared || (j != i && grp.item[j].y == it.y);
+    const bool in_place = splits == 1 && !shared;
     auto& P = ga.p[i];
     // the kernel's (M, N, K) are (output rows, output columns, reduction length) = (N, K, M) of the product
-    P.a = it.a, P.b = it.b, P.c = it.y, P.lda = it.lda, P.ldb = it.ldb, P.ldc = it.ldy;
-    P.M = it.N, P.N = it.K, P.K = (int)it.M, P.k_per_split = kps, P.flags = GEMM_ATOMIC, P.part_stride = 0;
+    P.a = it.a, P.b = it.b, P.lda = it.lda, P.ldb = it.ldb;
+    P.M = it.N, P.N = it.K, P.K = (int)it.M, P.k_per_split = kps;
+    if (in_place) {
+      P.c = it.y, P.ldc = it.ldy, P.flags = GEMM_ACCUMULATE, P.part_stride = 0;
+    } else {
+      const size_t need = (size_t)splits * it.N * it.K;
+      if (scratch == nullptr || !aligned16(scratch) || used + need > scratch_floats) {
+        set_error("gemm_tn group: %zu floats of slice scratch, %zu needed", scratch_floats, used + need);
+        return DRIN_E_WORKSPACE;
+      }
+      P.c = scratch + used, P.ldc = it.K, P.flags = GEMM_PARTIAL, P.part_stride = (int64_t)it.N * it.K;
+      DRIN_TRY(sums.add(it.y, it.ldy, it.N, it.K, scratch + used, splits));
+      used += (need + 3) & ~(size_t)3;
+    }
     P.col_tiles = (unsigned)cdiv(it.K, 64), P.row_tiles = (unsigned)cdiv(it.N, 64), P.first = items;
     items += P.col_tiles * P.row_tiles * (unsigned)splits;
   }
@@ -570,20 +659,23 @@ int launch_gemm_tn_f32_group(const F32GemmGroup& grp, hipStream_t st) {
   static DynLdsOptIn opt_in;
   auto kern = k_gemm_f32_group<true, true>;
   DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(gemm group)"));
-  KernelTimer timer(DRIN_KC_GEMM, st);
-  hipLaunchKernelGGL(kern, dim3(items), dim3(256), lds, st, ga);
-  DRIN_CHECK_LAUNCH("k_gemm_f32_group");
-  return DRIN_OK;
+  {
+    KernelTimer timer(DRIN_KC_GEMM, st);
+    hipLaunchKernelGGL(kern, dim3(items), dim3(256), lds, st, ga);
+    DRIN_CHECK_LAUNCH("k_gemm_f32_group");
+  }
+  return defer != nullptr ? DRIN_OK : launch_slice_sum(local, st);
 }
 
 int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N,
                    int K, int precision, hipStream_t st, float* scratch, size_t scratch_floats) {
   // y[n, k] += sum_m a[m, n] * b[m, k]: both operands k-major over the reduction index m.
-  // The reduction runs over all B*N pairs while the output is one weight matrix, so it is split over
-  // m and the slices are combined with fp32 atomics (the caller's gradient buffer is the accumulator).
+  // The reduction runs over all B*N pairs while the output is one weight matrix, so it is split over m: the slices
+  // store their tiles to the scratch and are added to y in order (launch_splitk_reduce) - reproducible bit for bit.
+  // Without scratch one workgroup per output tile walks the whole reduction and adds to y in place.
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) {
     // pair-sized weight gradients: split-bf16 MFMA (gemm_tn_bf16x3.hip); mention-sized ones stay exact fp32
-    if (gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b))
+    if (gemm_tn_bf16x3_fits(lda, ldb, M, N, K, a, b) && gemm_tn_bf16x3_scratch_ok(y, ldy, N, K, scratch, scratch_floats))
       return launch_gemm_tn_bf16x3(a, lda, b, ldb, y, ldy, M, N, K, st, scratch, scratch_floats);
     precision = DRIN_PREC_F32;
   }
@@ -596,21 +688,34 @@ int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, flo
     set_error("gemm_tn: reduction length %lld too large", (long long)M);
     return DRIN_E_SHAPE;
   }
-  if (M <= 2048) {
-    // mention-sized reductions (a few hundred rows): the work is the epilogue; 64 x 64 tiles spread its atomics
-    // over 4x the workgroups
-    int s64 = (int)cdiv(M, 4 * BK);
-    if (s64 > 4) s64 = 4;
-    return launch<64, 64, true, true>(a, lda, b, ldb, nullptr, y, ldy, /*M=*/N, /*N=*/K, /*K=*/(int)M, s64 < 1 ? 1 : s64,
-                                      GEMM_ATOMIC, st, "gemm_tn");
+  const bool small = M <= 2048;   // mention-sized reductions (a few hundred rows): 64 x 64 tiles, 4x the workgroups
+  int splits;
+  if (small) {
+    splits = small_tn_slices(M);
+  } else {
+    const int64_t tiles = cdiv(N, 128) * cdiv(K, 128);
+    splits = (int)cdiv(1024, tiles);                      // aim at ~4 workgroups per CU
+    const int max_splits = (int)cdiv(M, 4 * BK);          // at least 4 K-blocks per slice
+    if (splits > max_splits) splits = max_splits;
   }
-  const int64_t tiles = cdiv(N, 128) * cdiv(K, 128);
-  int splits = (int)cdiv(1024, tiles);                 // aim at ~4 workgroups per CU
-  const int max_splits = (int)cdiv(M, 4 * BK);          // at least 4 K-blocks per slice
-  if (splits > max_splits) splits = max_splits;
+  const size_t tile_floats = (size_t)N * K;
+  const bool can_slice = scratch != nullptr && aligned16(scratch) && aligned16(y) && (ldy % 4) == 0;
+  if (!can_slice) splits = 1;
+  while (splits > 1 && (size_t)splits * tile_floats > scratch_floats) --splits;
   if (splits < 1) splits = 1;
-  return launch<128, 128, true, true>(a, lda, b, ldb, nullptr, y, ldy, /*M=*/N, /*N=*/K, /*K=*/(int)M, splits,
-                                      GEMM_ATOMIC, st, "gemm_tn");
+  float* c = splits > 1 ? scratch : y;
+  const int64_t ldc = splits > 1 ? K : ldy;
+  const int flags = splits > 1 ? GEMM_PARTIAL : GEMM_ACCUMULATE;
+  int used = 1;
+  if (small) {
+    DRIN_TRY((launch<64, 64, true, true>(a, lda, b, ldb, nullptr, c, ldc, /*M=*/N, /*N=*/K, /*K=*/(int)M, splits, flags, st,
+                                         "gemm_tn", (int64_t)tile_floats, &used)));
+  } else {
+    DRIN_TRY((launch<128, 128, true, true>(a, lda, b, ldb, nullptr, c, ldc, /*M=*/N, /*N=*/K, /*K=*/(int)M, splits, flags, st,
+                                           "gemm_tn", (int64_t)tile_floats, &used)));
+  }
+  if (splits > 1) return launch_splitk_reduce(scratch, used, (int64_t)tile_floats, nullptr, y, ldy, N, K, true, st);
+  return DRIN_OK;
 }
 
 }  // namespace drin

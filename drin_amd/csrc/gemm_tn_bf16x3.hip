@@ -14,11 +14,11 @@
 // 16-byte chunk index is XORed with (p & 3) so that the 16 rows of a fragment read (4 row residues x 4
 // physical neighbours) fall on 16 distinct bank quads.
 //
-// The reduction is split over workgroups (M is 10^4 .. 10^5, the output has 9 .. 24 tiles of 256 x 256).  With
-// caller scratch each slice stores its partial tile plainly and k_tn_reduce adds the slices to y in order
-// (deterministic); without it the tiles are added to y with fp32 atomics like the exact-fp32 kernel of
-// gemm_f32.hip - 65 536 atomics per workgroup cost ~50 us whatever the slice length (MI355X_MICROARCH.md: one
-// 256-byte atomic wave-instruction per ~50 ns per CU), more than the MFMA work at M ~ 10^4.
+// The reduction is split over workgroups (M is 10^4 .. 10^5, the output has 9 .. 24 tiles of 256 x 256).  Each
+// slice stores its partial tile plainly into caller scratch and a SliceSum launch (gemm_f32.hip) adds the slices to
+// y in order: reproducible bit for bit.  (An atomic epilogue was the first version: 65 536 fp32 atomics per workgroup
+// cost ~50 us whatever the slice length - MI355X_MICROARCH.md: one 256-byte atomic wave-instruction per ~50 ns per
+// CU - more than the MFMA work at M ~ 10^4, and left the last bits of dW run-order dependent.  It is gone.)
 #include "device_utils.h"
 #include "internal.h"
 
@@ -118,15 +118,13 @@ struct TransposeStager {
 struct Problem {
   const float* a;
   const float* b;
-  float* y;
-  float* partial;            // [slices][N][K] partial tiles, or NULL: fp32 atomics onto y
+  float* partial;            // [slices][N][K] partial tiles
   const int64_t* b_index;
-  int64_t lda, ldb, ldy, M, rows_per_slice;
+  int64_t lda, ldb, M, rows_per_slice;
   int N, K, k_tiles, tiles;
   unsigned first;            // first work item
   int slices;
-  float* colsum;             // optional: column sums of a (the bias gradient that goes with dW = dY^T X) ...
-  float* colsum_partial;     // ... as [slices][N] partial rows, or NULL: fp32 atomics onto colsum
+  float* colsum_partial;     // optional: column sums of a (the bias gradient that goes with dW = dY^T X) as [slices][N] rows
 };
 struct GroupArgs {
   Problem p[TnGroup::MAX];
@@ -148,9 +146,8 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
   const Problem& P = g.p[pi];
   const float* __restrict__ A = P.a;
   const float* __restrict__ Bm = P.b;
-  float* __restrict__ Y = P.y;
   float* __restrict__ partial = P.partial;
-  const int64_t lda = P.lda, ldb = P.ldb, ldy = P.ldy, M = P.M, rows_per_slice = P.rows_per_slice;
+  const int64_t lda = P.lda, ldb = P.ldb, M = P.M, rows_per_slice = P.rows_per_slice;
   const int N = P.N, K = P.K, k_tiles = P.k_tiles, tiles = P.tiles;
   t -= P.first;
   const unsigned slice = t / (unsigned)tiles, tile = t - slice * (unsigned)tiles;
@@ -177,7 +174,7 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
   sa.load(m_begin, m_end);
   sb.load(m_begin, m_end);
   // the workgroups of the first k-tile also sum the columns of a (they stage every row of their n-tile exactly once)
-  const bool sums = P.colsum != nullptr && k0 == 0;
+  const bool sums = P.colsum_partial != nullptr && k0 == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (sums) sa.add_to(csum);
   sa.store(smem, smem + PLANE);
@@ -246,16 +243,7 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
       csum.w += __shfl_xor(csum.w, d);
     }
     const int col = n0 + 4 * sa.cg;
-    if (sa.mg == 0 && col + 4 <= N) {
-      if (P.colsum_partial != nullptr) {
-        st4(P.colsum_partial + (int64_t)slice * N + col, csum);
-      } else {
-        unsafeAtomicAdd(P.colsum + col + 0, csum.x);
-        unsafeAtomicAdd(P.colsum + col + 1, csum.y);
-        unsafeAtomicAdd(P.colsum + col + 2, csum.z);
-        unsafeAtomicAdd(P.colsum + col + 3, csum.w);
-      }
-    }
+    if (sa.mg == 0 && col + 4 <= N) st4(P.colsum_partial + (int64_t)slice * N + col, csum);
   }
   // C / D of a 16 x 16 tile (operands swapped above): n = lane & 15, k = 4 (lane >> 4) + v
 #pragma unroll
@@ -266,44 +254,9 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
     for (int j = 0; j < NI; ++j) {
       const int kcol = k0 + wn * 64 + j * 16 + c * 4;
       if (kcol >= K) continue;  // K % 4 == 0: a group of four is inside or outside as a whole
-      if (partial != nullptr) {
-        st4(partial + ((int64_t)slice * N + nrow) * K + kcol, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) unsafeAtomicAdd(Y + (int64_t)nrow * ldy + kcol + v, acc[i][j][v]);
-      }
+      st4(partial + ((int64_t)slice * N + nrow) * K + kcol, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
     }
   }
-}
-
-// y[n, k] += sum_slices partial[slice][n][k], slices in order; every problem of the group in one launch
-struct ReduceArgs {
-  static constexpr int MAX = 2 * TnGroup::MAX;   // a product's tiles and, as a one-row matrix, its column sums
-  const float* partial[MAX];
-  float* y[MAX];
-  int64_t ldy[MAX];
-  int N[MAX], K4[MAX], slices[MAX];
-  unsigned first[MAX];   // first block
-  int n;
-};
-__global__ void __launch_bounds__(256) k_tn_reduce(const ReduceArgs g) {
-  int pi = 0;
-  for (int i = 1; i < g.n; ++i) pi = blockIdx.x >= g.first[i] ? i : pi;
-  const int N = g.N[pi], K4 = g.K4[pi], slices = g.slices[pi];
-  const int64_t i = (int64_t)(blockIdx.x - g.first[pi]) * 256 + threadIdx.x;
-  if (i >= (int64_t)N * K4) return;
-  const int n = (int)(i / K4), c4 = (int)(i - (int64_t)n * K4);
-  const int64_t stride = (int64_t)N * K4 * 4;
-  const float* p = g.partial[pi] + (int64_t)n * K4 * 4 + (int64_t)c4 * 4;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  int z = 0;
-  for (; z + 2 <= slices; z += 2) {  // two chains, fixed association
-    s0 = s0 + ld4(p + z * stride);
-    s1 = s1 + ld4(p + (z + 1) * stride);
-  }
-  if (z < slices) s0 = s0 + ld4(p + z * stride);
-  float* dst = g.y[pi] + (int64_t)n * g.ldy[pi] + c4 * 4;
-  st4(dst, ld4(dst) + (s0 + s1));
 }
 
 }  // namespace x3tn
@@ -328,69 +281,89 @@ int TnGroup::add(const float* a, int64_t lda, const float* b, int64_t ldb, float
   return DRIN_OK;
 }
 
-int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, size_t scratch_floats) {
-  if (grp.n == 0) return DRIN_OK;
-  // One workgroup per CU in all (the 128 KiB tile buffers allow one per CU at a time): every extra slice adds a pipeline
-  // fill and a 256 KiB partial tile (or 65 536 fp32 atomics), which at M ~ 10^4 cost more than the MFMA work itself
-  // (measured at M = 12 928: 86 slices 162 us, 28 slices 92 us).  So the chip's 256 workgroups are dealt over ALL the
-  // products of the group in proportion to their work: one target slice length, a whole number of 32-row stages,
-  // grown until the group fits.  (Five products of one B = 64 backward pass: slices of ~62 stages instead of 15, same box
-  // 0.835 -> 0.74 ms of split-bf16 GEMM time per step; at B = 512, 58 .. 160 stages per slice already, neither better nor worse.)
-  int tiles[TnGroup::MAX];
+bool gemm_tn_bf16x3_scratch_ok(const float* y, int64_t ldy, int N, int K, const float* scratch, size_t scratch_floats) {
+  return scratch != nullptr && aligned16(scratch) && aligned16(y) && (ldy % 4) == 0 && scratch_floats >= (size_t)N * K;
+}
+
+static int64_t tn_slices_of(const TnGroup::Item& it, int64_t target, int64_t* rows_out) {   // equal slices of one product
+  int64_t slices = cdiv(it.M, target);
+  const int64_t rows = cdiv(cdiv(it.M, slices), x3tn::BK) * x3tn::BK;
+  if (rows_out) *rows_out = rows;
+  return cdiv(it.M, rows);
+}
+
+// One workgroup per CU in all (the 128 KiB tile buffers allow one per CU at a time): every extra slice adds a pipeline
+// fill and a 256 KiB partial tile, which at M ~ 10^4 cost more than the MFMA work itself (measured at M = 12 928:
+// 86 slices 162 us, 28 slices 92 us).  So the chip's 256 workgroups are dealt over ALL the
+// products of the group in proportion to their work: one target slice length, a whole number of 32-row stages,
+// grown until the group fits - the chip and the scratch.  (Five products of one B = 64 backward pass: slices of ~62 stages
+// instead of 15, same box 0.835 -> 0.74 ms of split-bf16 GEMM time per step; at B = 512, 58 .. 160 stages per slice
+// already, neither better nor worse.)
+int64_t tn_group_target(const TnGroup& grp, size_t scratch_floats) {
   int64_t work = 0, longest = 0;
   for (int i = 0; i < grp.n; ++i) {
     const auto& it = grp.item[i];
-    tiles[i] = (int)(cdiv(it.N, x3tn::TILE) * cdiv(it.K, x3tn::TILE));
-    work += (int64_t)tiles[i] * it.M;
+    work += cdiv(it.N, x3tn::TILE) * cdiv(it.K, x3tn::TILE) * it.M;
     longest = it.M > longest ? it.M : longest;
   }
   int64_t target = cdiv(cdiv(work, 256), x3tn::BK) * x3tn::BK;
   if (target < 4 * x3tn::BK) target = 4 * x3tn::BK;
   for (;; target += x3tn::BK) {
     int64_t wgs = 0;
-    for (int i = 0; i < grp.n; ++i) wgs += tiles[i] * cdiv(grp.item[i].M, target);
-    if (wgs <= 256 || target >= longest) break;
+    size_t part = 0;
+    for (int i = 0; i < grp.n; ++i) {
+      const auto& it = grp.item[i];
+      const int64_t sl = tn_slices_of(it, target, nullptr);
+      wgs += cdiv(it.N, x3tn::TILE) * cdiv(it.K, x3tn::TILE) * sl;
+      part += (size_t)sl * it.N * ((size_t)it.K + (it.colsum ? 1 : 0));
+    }
+    if ((wgs <= 256 && part <= scratch_floats) || target >= longest) break;
   }
+  return target;
+}
+
+int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer,
+                         int64_t target_rows) {
+  if (grp.n == 0) return DRIN_OK;
+  if (scratch == nullptr || !aligned16(scratch)) {
+    set_error("gemm_tn_bf16x3: the slice scratch is NULL or not 16-byte aligned");
+    return DRIN_E_WORKSPACE;
+  }
+  const int64_t target = target_rows > 0 ? target_rows : tn_group_target(grp, scratch_floats);
+  int tiles[TnGroup::MAX];
+  for (int i = 0; i < grp.n; ++i) tiles[i] = (int)(cdiv(grp.item[i].N, x3tn::TILE) * cdiv(grp.item[i].K, x3tn::TILE));
+  auto slices_of = [&](int i, int64_t tgt, int64_t* rows_out) { return tn_slices_of(grp.item[i], tgt, rows_out); };
+  // products of one destination next to one another (their slices: segments of one slice-sum entry, added in this order)
+  SliceSum local;
+  SliceSum& sums = defer != nullptr ? *defer : local;
   x3tn::GroupArgs ga;
-  x3tn::ReduceArgs ra;
   ga.n = grp.n;
-  ra.n = 0;
-  int64_t items = 0, blocks = 0;
+  int64_t items = 0;
   size_t part = 0;
-  bool two_stage = scratch != nullptr && aligned16(scratch);
   for (int i = 0; i < grp.n; ++i) {
     const auto& it = grp.item[i];
-    int64_t slices = cdiv(it.M, target);
-    const int64_t rows = cdiv(cdiv(it.M, slices), x3tn::BK) * x3tn::BK;   // equal slices of this product
-    slices = cdiv(it.M, rows);
+    int64_t rows = 0;
+    const int64_t slices = slices_of(i, target, &rows);
     auto& P = ga.p[i];
-    P.a = it.a, P.b = it.b, P.y = it.y, P.b_index = it.b_index;
-    P.lda = it.lda, P.ldb = it.ldb, P.ldy = it.ldy, P.M = it.M, P.rows_per_slice = rows;
+    P.a = it.a, P.b = it.b, P.b_index = it.b_index;
+    P.lda = it.lda, P.ldb = it.ldb, P.M = it.M, P.rows_per_slice = rows;
     P.N = it.N, P.K = it.K, P.k_tiles = (int)cdiv(it.K, x3tn::TILE), P.tiles = tiles[i];
     P.first = (unsigned)items, P.slices = (int)slices;
-    P.partial = scratch != nullptr ? scratch + part : nullptr;
+    P.partial = scratch + part;
     items += slices * tiles[i];
     part += (size_t)slices * it.N * it.K;
-    two_stage = two_stage && (it.ldy % 4) == 0 && aligned16(it.y);
-    two_stage = two_stage && (it.colsum == nullptr || aligned16(it.colsum));
-    auto reduce_entry = [&](const float* partial, float* y, int64_t ldy, int n_rows, int k4) {
-      const int j = ra.n++;
-      ra.partial[j] = partial, ra.y[j] = y, ra.ldy[j] = ldy, ra.N[j] = n_rows, ra.K4[j] = k4, ra.slices[j] = (int)slices;
-      ra.first[j] = (unsigned)blocks;
-      blocks += cdiv((int64_t)n_rows * k4, 256);
-    };
-    reduce_entry(P.partial, it.y, it.ldy, it.N, it.K / 4);
-    P.colsum = it.colsum;
     P.colsum_partial = nullptr;
     if (it.colsum != nullptr) {
-      P.colsum_partial = scratch != nullptr ? scratch + part : nullptr;
-      reduce_entry(P.colsum_partial, it.colsum, it.N, 1, it.N / 4);
+      P.colsum_partial = scratch + part;
       part += (size_t)slices * it.N;
     }
+    if (part > scratch_floats) {
+      set_error("gemm_tn_bf16x3: %zu floats of slice scratch, more than %zu needed", scratch_floats, part);
+      return DRIN_E_WORKSPACE;
+    }
+    DRIN_TRY(sums.add(it.y, it.ldy, it.N, it.K, P.partial, (int)slices));
+    if (it.colsum != nullptr) DRIN_TRY(sums.add(it.colsum, it.N, 1, it.N, P.colsum_partial, (int)slices));
   }
-  two_stage = two_stage && part <= scratch_floats;
-  if (!two_stage)
-    for (int i = 0; i < grp.n; ++i) ga.p[i].partial = ga.p[i].colsum_partial = nullptr;
   if (items > (int64_t)1 << 30) {
     set_error("gemm_tn_bf16x3: %lld work items exceed the grid limit", (long long)items);
     return DRIN_E_SHAPE;
@@ -400,14 +373,12 @@ int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, siz
     DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3), x3tn::LDS_BYTES,
                                 "hipFuncSetAttribute(gemm_tn_bf16x3)"));
   }
-  KernelTimer timer(DRIN_KC_GEMM_X3, st);
-  hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)items), dim3(x3tn::THREADS), x3tn::LDS_BYTES, st, ga);
-  DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
-  if (two_stage) {
-    hipLaunchKernelGGL(x3tn::k_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, st, ra);
-    DRIN_CHECK_LAUNCH("k_tn_reduce");
+  {
+    KernelTimer timer(DRIN_KC_GEMM_X3, st);
+    hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)items), dim3(x3tn::THREADS), x3tn::LDS_BYTES, st, ga);
+    DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
   }
-  return DRIN_OK;
+  return defer != nullptr ? DRIN_OK : launch_slice_sum(local, st);
 }
 
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,

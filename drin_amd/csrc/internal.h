@@ -94,6 +94,32 @@ int launch_miei(const float* mobj, const float* mscore, const float* eobj, const
 // out[i] = in[i] * mul / div
 int launch_scale_div(const float* in, float* out, int64_t n, float mul, float div, hipStream_t st);
 
+// ---- ordered slice sums (gemm_f32.hip) -----------------------------------------------------------
+// y[r, c] += sum over the destination's segments (in the order they were added), over each segment's slices (in order), of
+// partial[slice][r][c].  Every split reduction of the backward pass - the weight-gradient products split over the B N pairs,
+// their bias sums, the column sums - stores its slices plainly and lands in its destination through this ONE kernel: no
+// fp32 atomics anywhere, the same bits every run.  Two products that add to the same destination (dW_h takes the mention
+// and the entity rows) become two segments of one entry, summed by one thread in a fixed order.
+struct SliceSum {
+  static constexpr int MAX_DST = 32, MAX_SEG = 40;
+  struct Dst {
+    float* y;
+    int64_t ldy;
+    int rows, c4;          // the destination is rows x 4 c4 floats
+    unsigned first_block;
+    int seg_head, seg_tail;
+  } dst[MAX_DST];
+  struct Seg {
+    const float* partial;  // [slices][rows][4 c4], contiguous
+    int slices, next;
+  } seg[MAX_SEG];
+  int n = 0, n_seg = 0;
+  // DRIN_E_ALIGN / DRIN_E_SHAPE outside the contract (cols % 4, 16-byte alignment of y / partial, ldy % 4 unless rows == 1,
+  // the same y with another shape, more than MAX_DST destinations / MAX_SEG segments)
+  int add(float* y, int64_t ldy, int rows, int cols, const float* partial, int slices);
+};
+int launch_slice_sum(SliceSum& s, hipStream_t st);   // no-op for an empty one
+
 // ---- GEMM (gemm_f32.hip) ------------------------------------------------------------------------
 // y[m, n] (+)= sum_k x[m, k] * w[n, k] + bias[n];  x row stride ldx, w row stride ldw, y row stride ldy
 // (splitk: optional scratch; mention-sized exact-fp32 products with K >= 512 then split K over workgroups into it
@@ -113,11 +139,13 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
 bool gemm_tn_bf16x3_fits(int64_t lda, int64_t ldb, int64_t M, int N, int K, const void* a, const void* b);
-// (scratch: optional [slices][N][K] floats - the slices then store plainly and are reduced in order instead of
-//  adding to y with atomics)
+// (scratch: [slices][N][K] floats, at least N K of them, 16-byte aligned - the slices store plainly and are added to y in
+//  order: DRIN_E_WORKSPACE without it)
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
-                          int N, int K, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0,
+                          int N, int K, hipStream_t st, float* scratch, size_t scratch_floats,
                           const int64_t* b_index = nullptr);
+// what launch_gemm_tn_bf16x3 / launch_gemm_tn_group need of y and the scratch besides gemm_tn_bf16x3_fits
+bool gemm_tn_bf16x3_scratch_ok(const float* y, int64_t ldy, int N, int K, const float* scratch, size_t scratch_floats);
 // (b_index: reduction row m of b is row b_index[m] of a table - the gathered form never materialised)
 // up to 8 such products in ONE launch (+ one for the slice reduction): the chip's workgroups are dealt over all of them
 struct TnGroup {
@@ -140,7 +168,14 @@ struct TnGroup {
   int add(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M, int N, int K,
           const int64_t* b_index = nullptr, float* colsum = nullptr);
 };
-int launch_gemm_tn_group(const TnGroup& g, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
+// (defer: the slice sums are appended to it instead of being launched - the caller launches it, after which the scratch
+//  may be reused; NULL: launched here)
+// (target_rows: the slice length to deal the products by, 0 = tn_group_target of this group - a caller that launches one
+//  group in two parts passes the whole group's target to both, so that every product keeps the slices, hence the bits, of
+//  the single launch)
+int launch_gemm_tn_group(const TnGroup& g, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer = nullptr,
+                         int64_t target_rows = 0);
+int64_t tn_group_target(const TnGroup& g, size_t scratch_floats);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 // (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
@@ -187,7 +222,13 @@ struct F32GemmGroup {
   // gemm_nt_f32_group_fits - the ones launch_gemm_nt would run as the exact-fp32 split-K kernel + slice reduction
   int add_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K);
 };
-int launch_gemm_tn_f32_group(const F32GemmGroup& g, hipStream_t st);
+// (a product alone on its destination with one slice adds to it in place; any other stores its slices to the scratch and
+//  goes through the slice sum - defer as for launch_gemm_tn_group; floats needed: small_tn_scratch_floats per item)
+int launch_gemm_tn_f32_group(const F32GemmGroup& g, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer = nullptr);
+inline int small_tn_slices(int64_t reduction_rows) {   // slices of a mention-sized (<= 2048 rows) weight-gradient product
+  const int64_t s = (reduction_rows + 127) / 128;
+  return (int)(s > 4 ? 4 : (s < 1 ? 1 : s));
+}
 bool gemm_nt_f32_group_fits(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N,
                             int K, int precision);
 int launch_gemm_nt_f32_group(const F32GemmGroup& g, hipStream_t st, float* scratch, size_t scratch_floats);
@@ -242,8 +283,12 @@ int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* r
                                const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
                                const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
                                hipStream_t st, int act = DRIN_ACT_GELU);
-// out[c] += sum_rows x[row, c]
-int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st);
+// out[c] += sum_rows x[row, c].  The rows are dealt over up to kColsumMaxSlices workgroups per 256 columns, whose sums go to
+// the scratch ([slices][C] floats) and from there to out in order (SliceSum); without scratch one workgroup per 256 columns
+// walks all rows and adds to out itself - slower, the same kind of result: no atomics either way.
+constexpr int kColsumMaxSlices = 64;
+int launch_colsum(const float* x, float* out, int64_t rows, int C, hipStream_t st, float* scratch = nullptr,
+                  size_t scratch_floats = 0);
 // up to 8 such column sums in ONE launch
 struct ColsumBatch {
   const float* x[8];
@@ -254,7 +299,8 @@ struct ColsumBatch {
   int n = 0;
   int add(const float* src, float* dst, int64_t nrows, int C);   // no-op for dst == NULL or nrows <= 0
 };
-int launch_colsum_batch(const ColsumBatch& b, hipStream_t st);
+// (scratch: sum over the entries of by * C floats <= 8 * kColsumMaxSlices * C; defer as for launch_gemm_tn_group)
+int launch_colsum_batch(const ColsumBatch& b, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer = nullptr);
 // sigmoid backward of the scalar edge update + both entity-side gradients dfv_t, dfv_i in one pass (see the kernel)
 int launch_edge_update_bwd(const float* g, const float* e_new, const float* fu, float* dpre, float* dfv, int B, int N, int D,
                            float scale, hipStream_t st, int act = DRIN_ACT_SIGMOID);

@@ -42,6 +42,8 @@ struct Layout {
   size_t pre[DRIN_MAX_LAYERS] = {};         // [4][M][D]  W_m input cat(fu, fv) + e (vector edges)
   size_t splitk = 0, splitk_floats = 0;     // split-K partials of the mention-sized exact-fp32 products (small batches only)
   size_t tn_part = 0, tn_part_floats = 0;   // [slices][N][K] partial tiles of the split-bf16 weight-gradient products
+  size_t small_part = 0, small_part_floats = 0;     // slices of the mention-sized exact-fp32 weight-gradient products (launch_gemm_tn_f32_group)
+  size_t colsum_part = 0, colsum_part_floats = 0;   // [8][kColsumMaxSlices][D] partial rows of the bias column sums
   size_t ln_part = 0;                       // [1024 + 16][3][D] per-block column sums of the LayerNorm backward and their first reduction level
   size_t wt = 0;                            // [2 layers + 1][D][D]: bf16 (hi, lo) planes of W_h^T / W_v^T of every layer (split-bf16 dX = dY W, one batched transpose + split per backward) + one fp32 slot for products transposed on the fly
   // bf16 (hi, lo) planes of the weights the split-bf16 NT products run against (one batched split per forward call):
@@ -107,6 +109,15 @@ struct Layout {
         const size_t one_slice = ((size_t)2 * nl + 1) * D * D + D * R;
         tn_part_floats = ((size_t)256 * 65536 > one_slice ? (size_t)256 * 65536 : one_slice) + (size_t)8 * 256 * D;  // + column sums
         tn_part = take(tn_part_floats);
+      }
+      {  // every weight-gradient product of at most 2048 reduction rows may store up to four slices (internal.h:
+        // small_tn_slices); the mention side has 2 B rows at most, the entity side 2 M
+        auto slices = [](size_t rows) { return rows > 2048 ? (size_t)0 : (rows + 127) / 128 > 4 ? (size_t)4 : (rows + 127) / 128 < 1 ? (size_t)1 : (rows + 127) / 128; };
+        const size_t per_side = ((size_t)2 * nl + 1) * D * D + D * R;   // dW_h, dW_u | dW_v of every layer, a text and an image encoder
+        small_part_floats = (slices(2 * B) + slices(2 * M)) * per_side + 64;
+        small_part = take(small_part_floats);
+        colsum_part_floats = (size_t)8 * 64 * D;
+        colsum_part = take(colsum_part_floats);
       }
       // backward temporaries: vertex gradients per level (nl + 1) + dA + dfv / dfu per layer, entity and mention side; edges x3
       bwd_scratch_floats = ((size_t)2 * nl + 2) * (2 * M * D + 64 + 2 * B * D + 64) + 3 * (4 * M * EW + 64) + (3 * M + 64);

@@ -54,10 +54,11 @@ class TopkAccuracy:
         self.correct.zero_()
         self.total.zero_()
 
-    def sync(self) -> None:
+    def sync(self, force: bool = False) -> None:
+        """`force`: also in a process group of one rank (the collective code path exercised on a one-GPU box)."""
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
             packed = torch.stack([self.correct, self.total])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
             self.correct, self.total = packed[0], packed[1]
@@ -122,10 +123,10 @@ class DeviceLossMetric:
         self.correct.zero_()
         self.total = 0
 
-    def sync(self) -> None:
+    def sync(self, force: bool = False) -> None:
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
             packed = torch.cat([self.correct, torch.tensor([self.total], dtype=torch.int64, device=self.correct.device)])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
             self.correct, self.total = packed[:-1].clone(), int(packed[-1])

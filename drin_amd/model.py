@@ -464,8 +464,20 @@ class _DrinScore(torch.autograd.Function):
         _fill_params(gc, grads, call.per_layer)
         g = grad_scores.to(torch.float32).contiguous()
         stream = torch.cuda.current_stream(call.device).cuda_stream
-        _lib.check(lib.drin_backward(C.byref(call.cfg), C.byref(call.batch), C.byref(ctx.pc), ctx.ws.data_ptr(),
-                                     ctx.ws.numel(), g.data_ptr(), C.byref(gc), stream))
+        # data-parallel overlap (drin_backward_staged): the library records `ready` once the GCN layers' gradients are
+        # complete; the hook - GradBucket's - starts their all-reduce behind it, under the vertex encoders' dW products
+        hook = getattr(owner, "_layers_ready_hook", None) if owner is not None and owner.grad_bucket_enabled else None
+        staged = hook is not None and owner._grad_flat is not None and grads[0].data_ptr() == owner._grad_flat.data_ptr()
+        if staged:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(call.device))        # creates the hipEvent_t; the library records it again
+            _lib.check(lib.drin_backward_staged(C.byref(call.cfg), C.byref(call.batch), C.byref(ctx.pc), ctx.ws.data_ptr(),
+                                                ctx.ws.numel(), g.data_ptr(), C.byref(gc), ready.cuda_event, stream))
+            offsets, live, _total = owner.bucket_layout()
+            hook(owner._grad_flat[:live], offsets[8], ready)             # [vertex encoders | GCN layers | dead]: the layers start at slot 8
+        else:
+            _lib.check(lib.drin_backward(C.byref(call.cfg), C.byref(call.batch), C.byref(ctx.pc), ctx.ws.data_ptr(),
+                                         ctx.ws.numel(), g.data_ptr(), C.byref(gc), stream))
         out = list(grads)
         # parameters the score does not depend on get no gradient at all in the reference (.grad is None):
         # the last layer's edge update is dead (model.py:130-134), and static edges never use w_u / w_v (/ w_m)
@@ -502,6 +514,8 @@ class Model(nn.Module):
         self._prepared = _Prepared() if fused else None
         self.grad_bucket_enabled = grad_bucket
         self._grad_flat: Optional[torch.Tensor] = None
+        self._bucket_in_flight = False                       # handed out by a backward pass that is still running
+        self._layers_ready_hook = None                       # set by train.GradBucket(overlap=True): see _DrinScore.backward
         self._param_flat: Optional[torch.Tensor] = None
         self._layout = None
         self.register_load_state_dict_post_hook(_invalidate_after_load)
@@ -531,7 +545,10 @@ class Model(nn.Module):
     def _bucket_grads(self, params: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
         """Views of the flat gradient bucket for `params` (`_param_list` order; the dead ones get their own slots behind
         the live prefix and are never returned to autograd), zeroed with one memset.  A bucket some `.grad` still aliases
-        (gradient accumulation over several backward passes) is left alone and a fresh one is taken."""
+        (gradient accumulation over several backward passes) is left alone and a fresh one is taken - and so is a bucket
+        an EARLIER node of the backward pass that is running now has handed out (two scoring calls in one graph:
+        `loss(model(b1)) + loss(model(b2))`, or a training batch above MAX_CALL_MENTIONS): its views sit in autograd's
+        input buffers while every `.grad` is still None, and the engine sums the two nodes' gradients itself."""
         offsets, live, total = self.bucket_layout()
         dev = params[0].device
         flat = self._grad_flat
@@ -541,11 +558,24 @@ class Model(nn.Module):
             base = flat.untyped_storage().data_ptr()
             if any(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.parameters()):
                 flat = None
+        views = lambda f: [f[o:o + p.numel()].view(p.shape) for o, p in zip(offsets, params)]
+        if self._bucket_in_flight:
+            extra = torch.empty(total, dtype=torch.float32, device=dev)   # not the model's bucket: the sums will be new tensors
+            extra[:live].zero_()
+            return views(extra)
         if flat is None:
             flat = torch.empty(total, dtype=torch.float32, device=dev)
         self._grad_flat = flat
         flat[:live].zero_()
-        return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offsets, params)]
+        self._bucket_in_flight = True
+        try:                                                  # cleared when the engine finishes this backward pass
+            torch.autograd.Variable._execution_engine.queue_callback(self._bucket_landed)
+        except RuntimeError:                                  # not inside a backward pass (a direct call): nothing in flight
+            self._bucket_in_flight = False
+        return views(flat)
+
+    def _bucket_landed(self) -> None:
+        self._bucket_in_flight = False
 
     def grad_bucket(self) -> Optional[torch.Tensor]:
         """The live prefix of the flat gradient bucket when every current `.grad` is a view of it, else None."""

@@ -36,19 +36,51 @@ def _rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _collectives(force: bool) -> bool:
+    """Whether the step's collectives run: with more than one rank always; `force`: also in a process group of ONE rank
+    (a one-GPU box then drives the real RCCL code path - communicator, `ReduceOp.AVG`, stream ordering - instead of
+    skipping it; `bench.py --force-collective`, `tests/test_gpu_round3.py`)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or force
+
+
 class GradBucket:
     """The gradients of all parameters that receive one (26.8 MB of the 31.5 MB carry gradients),
-    all-reduced with a single collective per step.
+    all-reduced once per step.
 
     `drin_amd.model.Model` writes its gradients into ONE flat bucket the `.grad`s are views of: the collective then runs
     on that bucket in place - no gather copy before, no scatter copy after.  Any other set of gradients (a foreign
-    module, `grad_bucket=False`, gradients accumulated over several backward passes) is packed into a staging bucket."""
+    module, `grad_bucket=False`, gradients accumulated over several backward passes) is packed into a staging bucket.
 
-    def __init__(self, params: Sequence[nn.Parameter]):
+    `overlap=True` (with a `drin_amd.model.Model`): the bucket is reduced in TWO pieces.  `drin_backward_staged` records an
+    event once the GCN layers' gradients are complete (only the four vertex encoders' weight-gradient products run after
+    it); the layers' piece - the bucket's tail, 9.4 of the 26.8 MB - is all-reduced behind that event on a side stream,
+    under those products, and `allreduce_mean()` reduces the vertex encoders' piece and joins.  Element for element the
+    same collective arithmetic, so the parameters follow the one-piece path bit for bit
+    (`tests/test_dist_gloo.py`, `tests/test_gpu_round3.py`)."""
+
+    def __init__(self, params: Sequence[nn.Parameter], force: bool = False, overlap: bool = False, model=None):
         self.params = [p for p in params if p.requires_grad]
         self.flat: Optional[torch.Tensor] = None          # staging bucket of the copy path
         self._view = None                                 # (storage ptr, lo, hi, flat view) of the in-place path
         self.in_place = False                             # what the last call did
+        self.force = force
+        self.collectives = 0                              # all_reduce calls issued so far
+        self.overlapped = 0                               # steps whose layers' piece started inside backward
+        self._early = None                                # (bucket ptr, split, work | None) of the piece in flight
+        self._comm: Optional[torch.cuda.Stream] = None
+        self.model = model if overlap else None
+        if self.model is not None:
+            if not hasattr(self.model, "_layers_ready_hook"):
+                raise ValueError("overlap=True needs a drin_amd.model.Model (drin_backward_staged)")
+            self.model._layers_ready_hook = self._layers_ready
+
+    def close(self) -> None:
+        """Detach from the model (its backward goes back to the one-stage drin_backward)."""
+        if self.model is not None and self.model._layers_ready_hook == self._layers_ready:
+            self.model._layers_ready_hook = None
+        self.model = None
 
     def nbytes(self) -> int:
         live = [p for p in self.params if p.grad is not None]
@@ -75,28 +107,65 @@ class GradBucket:
             self._view = (base, lo, hi, flat)
         return self._view[3]
 
+    def _reduce(self, t: torch.Tensor, async_op: bool = False):
+        avg = dist.get_backend() == "nccl"                 # RCCL averages inside the collective; gloo has no AVG
+        self.collectives += 1
+        work = dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+        return work, (None if avg else dist.get_world_size())
+
+    def _layers_ready(self, live_flat: torch.Tensor, split: int, ready: "torch.cuda.Event") -> None:
+        """Called inside `_DrinScore.backward` right after `drin_backward_staged` was enqueued: `live_flat[split:]` (the GCN
+        layers' gradients) is final once `ready` fires; the vertex encoders' products behind it write `live_flat[:split]` only."""
+        if not _collectives(self.force) or self._early is not None or split <= 0 or split >= live_flat.numel():
+            return
+        piece = live_flat[split:]
+        if live_flat.is_cuda:
+            if self._comm is None or self._comm.device != live_flat.device:
+                self._comm = torch.cuda.Stream(device=live_flat.device)
+            self._comm.wait_event(ready)
+            with torch.cuda.stream(self._comm):            # the collective is ordered behind the event, not behind the step's stream
+                work, div = self._reduce(piece, async_op=True)
+        else:                                              # host tensors (the gloo tests): the piece is final when the hook runs
+            work, div = self._reduce(piece, async_op=True)
+        self._early = (live_flat.data_ptr(), split, work, div, piece)
+
     def allreduce_mean(self) -> None:
-        world = _world()
-        if world == 1:
+        if not _collectives(self.force):
+            self._early = None
             return
         live = [p for p in self.params if p.grad is not None]
         if not live:
             return
-        avg = dist.get_backend() == "nccl"                 # RCCL averages inside the collective; gloo has no AVG
         flat = self._aliased_bucket(live)
         self.in_place = flat is not None
+        early, self._early = self._early, None
+        if early is not None:
+            ptr, split, work, div, piece = early
+            if flat is None or flat.data_ptr() != ptr or flat.numel() <= split:
+                # the gradients did not end up as views of the bucket the early piece was taken from (accumulation over several
+                # backward passes): nothing sound can be salvaged from a collective on memory that is no longer the gradient
+                work.wait()
+                raise RuntimeError("GradBucket(overlap=True): the gradients are not the flat bucket of this backward pass "
+                                   "(gradient accumulation / two scoring calls in one graph): use overlap=False")
+            _w, div_b = self._reduce(flat[:split])         # the vertex encoders' piece, on the step's stream
+            work.wait()                                    # the step's stream now waits for the layers' piece
+            if div is not None:                            # gloo: SUM, then the division - per piece, element for element
+                piece.div_(div)
+                flat[:split].div_(div_b)
+            self.overlapped += 1
+            return
         if flat is not None:
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
-            if not avg:
-                flat.div_(world)
+            _w, div = self._reduce(flat)
+            if div is not None:
+                flat.div_(div)
             return
         n = sum(p.numel() for p in live)
         if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].grad.device:
             self.flat = torch.empty(n, dtype=torch.float32, device=live[0].grad.device)
         torch._foreach_copy_(list(self.flat.split([p.numel() for p in live])), [p.grad.reshape(-1) for p in live])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
-        if not avg:
-            self.flat.div_(world)
+        _w, div = self._reduce(self.flat)
+        if div is not None:
+            self.flat.div_(div)
         torch._foreach_copy_([p.grad.reshape(-1) for p in live], list(self.flat.split([p.numel() for p in live])))
 
 
@@ -105,11 +174,15 @@ class LibraryAdam:
     launch of `drin_adam_step` over the model's flat parameter / gradient / moment buckets instead of torch's nine
     multi-tensor launches.  Same op sequence and per-op fp32 rounding as torch's default implementation, so a loop stepped
     with it follows the reference's loop bit for bit (`tests/test_gpu_round2.py::test_library_adam_matches_torch_adam_bitwise`).
-    Like torch's Adam it skips parameters whose `.grad` is None and creates its zero moments at the first step."""
+    Like torch's Adam it skips parameters whose `.grad` is None, and like torch's it counts the steps PER PARAMETER
+    (`state[p]["step"]`): a parameter that receives its first gradient at the optimiser's k-th step - unfrozen later - is
+    bias-corrected for ITS first step.  `t` is the largest count.  `state_dict()` is this class's own (flat moment buckets +
+    the per-parameter counts), not interchangeable with `torch.optim.Adam.state_dict()`."""
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         self.model, self.lr, self.betas, self.eps = model, float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.t = 0
+        self.steps: List[int] = []                           # per parameter, `_param_list` order
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
         self.one_launch_steps = 0
@@ -120,13 +193,14 @@ class LibraryAdam:
 
     def state_dict(self) -> dict:
         """Step count, hyper-parameters and the two moment buckets (laid out like `Model.bucket_layout`)."""
-        return {"t": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps,
+        return {"t": self.t, "steps": list(self.steps), "lr": self.lr, "betas": self.betas, "eps": self.eps,
                 "exp_avg": None if self.exp_avg is None else self.exp_avg.clone(),
                 "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.clone()}
 
     def load_state_dict(self, state: dict) -> None:
         self.t, self.lr, self.betas, self.eps = int(state["t"]), float(state["lr"]), tuple(state["betas"]), float(state["eps"])
         self.param_groups[0]["lr"] = self.lr
+        self.steps = [int(x) for x in state.get("steps", [])]
         dev = next(self.model.parameters()).device
         self.exp_avg = None if state["exp_avg"] is None else state["exp_avg"].to(dev).clone()
         self.exp_avg_sq = None if state["exp_avg_sq"] is None else state["exp_avg_sq"].to(dev).clone()
@@ -151,38 +225,40 @@ class LibraryAdam:
         offsets, live, total = model.bucket_layout()
         if self.exp_avg is None or self.exp_avg.numel() != total or self.exp_avg.device != flat_p.device:
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
-        self.t += 1
         b1, b2 = self.betas
-        step = float(self.t)
-        bias_correction1 = 1 - b1 ** step                    # torch/optim/adam.py (_multi_tensor_adam), python doubles
-        bias_correction2 = 1 - b2 ** step
         self.lr = float(self.param_groups[0]["lr"])          # honour a scheduler writing the group's lr, like torch's optimisers
-        neg_step_size = (self.lr / bias_correction1) * -1
-        bias_correction2_sqrt = bias_correction2 ** 0.5
-        scal = (1 - b1, b2, 1 - b2, bias_correction2_sqrt, self.eps, neg_step_size)
         stream = torch.cuda.current_stream(flat_p.device).cuda_stream
 
-        def launch(p_ptr, g_ptr, off, n):
+        def launch(p_ptr, g_ptr, off, n, step):
+            bias_correction1 = 1 - b1 ** float(step)         # torch/optim/adam.py (_multi_tensor_adam), python doubles
+            bias_correction2 = 1 - b2 ** float(step)
+            neg_step_size = (self.lr / bias_correction1) * -1
+            scal = (1 - b1, b2, 1 - b2, bias_correction2 ** 0.5, self.eps, neg_step_size)
             _lib.check(lib.drin_adam_step(p_ptr, g_ptr, self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off,
                                           n, *(C.c_float(x) for x in scal), stream))
 
         params = _param_list(model)
+        if len(self.steps) != len(params):                   # a state from before the per-parameter counts: everyone at t
+            self.steps = [self.t if (i < len(offsets) and offsets[i] < live) else 0 for i in range(len(params))]
         # the kernel writes the parameters behind PyTorch's back: bump their version counters (no launch), so that everything
         # keyed on them - the folded weights of the fused inference path, the per-entity cache, autograd's saved-tensor
         # checks - sees the update exactly as it sees torch.optim.Adam's
         torch.autograd.graph.increment_version(params)
         with_grad = [i for i, p in enumerate(params) if p.grad is not None]
+        for i in with_grad:
+            self.steps[i] += 1
+        self.t = max(self.steps) if self.steps else 0
         gflat = model.grad_bucket()
         live_set = [i for i, o in enumerate(offsets) if o < live]
-        if gflat is not None and with_grad == live_set:
-            launch(flat_p.data_ptr(), gflat.data_ptr(), 0, live)          # the whole live prefix, slot padding included (zeros)
+        if gflat is not None and with_grad == live_set and len({self.steps[i] for i in live_set}) == 1:
+            launch(flat_p.data_ptr(), gflat.data_ptr(), 0, live, self.steps[live_set[0]])   # the whole live prefix, slot padding included (zeros)
             self.one_launch_steps += 1
             return
-        for i in with_grad:                                               # irregular step: one launch per tensor
+        for i in with_grad:                                               # irregular step: one launch per tensor, its own step count
             p, g = params[i], params[i].grad
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = g.to(torch.float32).contiguous()
-            launch(p.data_ptr(), g.data_ptr(), offsets[i], p.numel())
+            launch(p.data_ptr(), g.data_ptr(), offsets[i], p.numel(), self.steps[i])
 
 
 def make_adam(model, lr: float, library: Optional[bool] = None, capturable: bool = False, fused: bool = False):
@@ -207,7 +283,7 @@ class _GatherScores(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        world = _world()
+        world = _world()                                     # (a process group of one rank gathers its own slice)
         parts = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(parts, x.contiguous())
         ctx.rows = x.shape[0]
@@ -300,7 +376,8 @@ class MELRunner:
     def __init__(self, cfg: DrinConfig, model: nn.Module, device, global_batch_loss: bool = False,
                  log: Optional[Callable[[str], None]] = None, entity_table=None, device_loss: Optional[bool] = None,
                  fused_adam: bool = False, library_adam: Optional[bool] = None, output_test_result: Optional[str] = None,
-                 profiling: bool = False, profile_dir: str = "log/profiler"):
+                 profiling: bool = False, profile_dir: str = "log/profiler", force_collectives: bool = False,
+                 overlap_allreduce: Optional[bool] = None):
         """`entity_table`: a device-resident `drin_amd.model.EntityTable`; the loaders then yield the 11-item
         table-form batches of `drin_amd.data.IndexedMELData` (candidate indices instead of gathered features).
         `device_loss`: loss + top-k counters through the library's `drin_triplet_topk` (default on a GPU; the
@@ -309,13 +386,18 @@ class MELRunner:
         `output_test_result`: a path - the per-sample dump of `train.py:16-17,40-43` (`args.output_test_result`): every
         test-split sample's score row and answer row, `"{index}:\t{scores}\n{answer}\n"` (rank r > 0 of a data-parallel
         run appends `.rank{r}` to the name and numbers its own shard's samples).
-        `profiling`: the switch of `train.py:64-70` (`args.profiling`), see `StepProfiler` (GPU only)."""
+        `profiling`: the switch of `train.py:64-70` (`args.profiling`), see `StepProfiler` (GPU only).
+        `force_collectives`: run the step's collectives (gradient all-reduce, score gather, metric sync) in a process
+        group of ONE rank too - what a one-GPU box can exercise of the N-GPU path.
+        `overlap_allreduce`: `GradBucket(overlap=True)` (default: for the HIP `Model` on a GPU whenever collectives run)."""
         self.cfg, self.model, self.device = cfg, model, torch.device(device)
         self.entity_table = entity_table
         self.fused_adam, self.library_adam = fused_adam, library_adam
         self.result_file = None
+        self._result_index = 0
         if output_test_result:
-            self.result_file = open(output_test_result + (f".rank{_rank()}" if _rank() > 0 else ""), "w")
+            self._result_path = output_test_result + (f".rank{_rank()}" if _rank() > 0 else "")
+            self.result_file = open(self._result_path, "w")
         self.loss = TripletLoss(cfg.triplet_margin)
         self.metrics = [TopkAccuracy(k, self.device) for k in cfg.metrics_topk]
         if device_loss and global_batch_loss:
@@ -323,7 +405,12 @@ class MELRunner:
         if device_loss is None:
             device_loss = self.device.type == "cuda" and not global_batch_loss
         self.device_loss = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk, self.device) if device_loss else None
-        self.bucket = GradBucket(list(model.parameters()))
+        self.force_collectives = force_collectives
+        if overlap_allreduce is None:
+            overlap_allreduce = (self.device.type == "cuda" and hasattr(model, "_layers_ready_hook") and _collectives(force_collectives)
+                                 and getattr(model, "grad_bucket_enabled", False))
+        self.bucket = GradBucket(list(model.parameters()), force=force_collectives, overlap=overlap_allreduce,
+                                 model=model if overlap_allreduce else None)
         self.global_batch_loss = global_batch_loss
         self.log = log
         if profiling and self.device.type != "cuda":
@@ -344,12 +431,15 @@ class MELRunner:
         else:
             y_hat = self.model(batch[:-1])
         if self.result_file is not None and split == 2:                # train.py:40-43
+            # (the reference numbers a sample `i + batch_idx * batch_size` with the LOADER's batch size: a running count
+            #  is that number whatever batch size the loaders were built with)
             for i, sample in enumerate(y_hat.detach().to("cpu").tolist()):
-                self.result_file.write(f"{i + batch_idx * self.cfg.batch_size}:\t{sample}\n{y[i]}\n")
+                self.result_file.write(f"{self._result_index + i}:\t{sample}\n{y[i]}\n")
+            self._result_index += y_hat.shape[0]
             self.result_file.flush()
         # (evaluation shards may differ in length by one mention across ranks - no padding, so that the metrics count every
         #  mention exactly once - hence no per-step collective there: the gathered loss is a training-step construct)
-        if self.global_batch_loss and _world() > 1 and self.model.training:
+        if self.global_batch_loss and _collectives(self.force_collectives) and self.model.training:
             world = _world()
             ys = [torch.empty_like(y) for _ in range(world)]
             dist.all_gather(ys, y.contiguous())
@@ -376,6 +466,11 @@ class MELRunner:
         if self.log and _rank() == 0 and self._epoch is not None:
             from datetime import datetime
             self.log(f"\n***** Epoch {self._epoch[0]}/{self._epoch[1]} - {('training', 'validating', 'testing')[split]} - {datetime.now()}")
+        if split == 2 and self.result_file is not None:               # on_test_epoch_start (train.py:92-95)
+            if self.result_file.closed:                                # a test pass after fit() closed the dump: continue it
+                self.result_file = open(self._result_path, "a")
+            self.result_file.write("==========  Test ==========\n")
+            self._result_index = 0
         training = optimizer is not None
         self.model.train(training)
         total, steps = torch.zeros((), dtype=torch.float64, device=self.device), 0   # summed on the device: no per-step read-back
@@ -396,13 +491,24 @@ class MELRunner:
         if training and self.profiler is not None:
             self.profiler.stop()                                       # on_train_epoch_end (train.py:84-85)
         for m in meters:
-            m.sync()
+            m.sync(force=self.force_collectives)
         mean_loss = float(total) / max(steps, 1)
-        if _world() > 1:
+        if _collectives(self.force_collectives):
             t = torch.tensor([mean_loss], device=self.device)
             dist.all_reduce(t)
             mean_loss = float(t) / _world()
         return StepLog(mean_loss, self._topk(split))
+
+    def close(self) -> None:
+        """End of `main()` (`train.py:145-146`): the test-result dump is closed."""
+        if self.result_file is not None and not self.result_file.closed:
+            self.result_file.close()
+        self.bucket.close()
+
+    def test(self, loader) -> StepLog:
+        """`trainer.test(model, datasets[2])` (`train.py:137-140,144`): one pass over the test split."""
+        self._epoch = self._epoch or (1, self.cfg.num_epoch)
+        return self.run_epoch(loader, 2, None)
 
     def fit(self, loaders, num_epoch: Optional[int] = None, test_epoch_interval: Optional[int] = None) -> History:
         """`main()` of `train.py:141-144`."""
@@ -438,6 +544,8 @@ class MELRunner:
             if self.log and _rank() == 0:
                 self.log(f"test after epoch {epoch}: loss {te.loss:.5f} top-k {te.topk}")
         hist.seconds = time.perf_counter() - t0
+        if self.result_file is not None:                               # train.py:145-146
+            self.result_file.close()
         return hist
 
 
@@ -454,7 +562,8 @@ def seed_everything(seed: int) -> None:
 
 def main(argv: Optional[Sequence[str]] = None) -> None:
     """python -m drin_amd.train --data DIR [--dataset wikidiverse|wikimel] [--epochs E] [--interval I] [--on-device]
-    [--precision bf16x3|f32] [--torch-adam] [--output-test-result PATH] [--profiling]; N GPUs: python -m torch.distributed.run --nproc-per-node N -m drin_amd.train ..."""
+    [--precision bf16x3|f32] [--torch-adam] [--output-test-result PATH] [--profiling] [--test-only] [--load-state PATH]
+    [--force-collectives]; N GPUs: python -m torch.distributed.run --nproc-per-node N -m drin_amd.train ..."""
     import argparse
     import os
 
@@ -477,6 +586,12 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap.add_argument("--profiling", action="store_true",
                     help="args.profiling (train.py:64-70): wait 1 / warmup 1 / active 3 steps x 2 cycles per fit through the library's "
                          "profiler, kernel class -> ms per step written to log/profiler/drin_profile_<cycle>.json")
+    ap.add_argument("--test-only", action="store_true",
+                    help="args.test_only (train.py:137-140, args.py:112): no fit, one pass over the test split with the freshly "
+                         "initialised (or --load-state'd) model")
+    ap.add_argument("--load-state", default=None, metavar="PATH", help="a torch-saved state_dict (the reference's keys) loaded before fit / test")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise a process group even for ONE rank and run the step's collectives in it (RCCL exercised on a one-GPU box)")
     ap.add_argument("--on-device", action="store_true",
                     help="every split (and, wikimel, the entity tables) resident on the GPU (create_device_splits, load_entity_table): "
                          "no host gather, no host-to-device copy in the step")
@@ -486,8 +601,11 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or a.force_collectives:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=int(os.environ.get("RANK", "0")), world_size=world)
     seed_everything(cfg.seed)
     table = None
     if a.on_device:
@@ -503,11 +621,21 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
             v = getattr(cfg, f.name)
             print(f.name, "'" + v + "'" if isinstance(v, str) else v, sep=" = ")
     model = Model(cfg, precision=a.precision).to(dev)
+    if a.load_state:
+        model.load_state_dict(torch.load(a.load_state, map_location=dev))
     runner = MELRunner(cfg, model, dev, a.global_batch_loss, log=print, entity_table=table,
                        library_adam=False if a.torch_adam else None, output_test_result=a.output_test_result,
-                       profiling=a.profiling)
-    runner.fit(loaders, a.epochs, a.interval)
-    if world > 1:
+                       profiling=a.profiling, force_collectives=a.force_collectives)
+    if a.test_only:                                                    # train.py:137-140
+        te = runner.test(loaders[2])
+        if _rank() == 0:
+            print(f"test: loss {te.loss:.5f} top-k {te.topk}")
+    else:
+        runner.fit(loaders, a.epochs, a.interval)
+        if _rank() == 0:
+            print("Training completed")                                # train.py:147
+    runner.close()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

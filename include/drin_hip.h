@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRIN_ABI_VERSION 2
+#define DRIN_ABI_VERSION 3
 #define DRIN_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -239,6 +239,17 @@ DRIN_API int drin_forward(const drin_config* cfg, const drin_batch* batch, const
 DRIN_API int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
                   void* workspace, size_t workspace_bytes, const float* grad_scores,
                   const drin_param_grads* grads, void* stream);
+
+/* drin_backward in two stages for a data-parallel caller (the reference runs one device, train.py:117-118,
+ * and has no counterpart).  `layers_ready_event`: a hipEvent_t the caller created, or NULL (= drin_backward).  The event
+ * is recorded on `stream` once every gradient of the GCN layers (the `layer[l]` tensors of `grads`) is complete; only
+ * the four vertex encoders' gradients (w_/b_ mention_text, entity_text, mention_image, entity_image) are written after
+ * it.  A caller whose gradient bucket keeps the two groups apart starts the all-reduce of the layers' part behind the
+ * event, under the vertex encoders' weight-gradient products.  The gradients are those of drin_backward BIT FOR BIT
+ * (every split reduction keeps its slices and their order; none of them uses atomics). */
+DRIN_API int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
+                  void* workspace, size_t workspace_bytes, const float* grad_scores,
+                  const drin_param_grads* grads, void* layers_ready_event, void* stream);
 
 /* ---- fused two-layer inference path ------------------------------------------------------------
  * Same result as drin_forward (fp32 re-association only) for the default geometry num_layers == 2,

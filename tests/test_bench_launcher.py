@@ -52,3 +52,14 @@ def test_world_size_mismatch_is_an_error():
 def test_a_failing_rank_fails_the_parent():
     r = _run("--gpus", "2", "--stub", "--steps", "1", "--warmup", "0", env={"DRIN_BENCH_STUB_FAIL_RANK": "1"})
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_force_collective_runs_the_allreduce_in_a_world_of_one():
+    """--force-collective at N = 1: a process group of one rank is initialised and the train step's flat-bucket all-reduce
+    runs in it (gloo here; RCCL on the GPU box: tests/test_gpu_round3.py)."""
+    r = _run("--stub", "--mode", "train", "--steps", "3", "--warmup", "1", "--force-collective")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["collectives_issued"] == 4
+    r = _run("--stub", "--mode", "train", "--steps", "3", "--warmup", "1")
+    assert json.loads(r.stdout.strip().splitlines()[-1])["collectives_issued"] == 0

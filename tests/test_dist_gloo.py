@@ -151,3 +151,95 @@ def test_grad_bucket_reduces_a_flat_bucket_in_place_and_packs_anything_else():
     params[1].grad = torch.ones(7)
     assert b._aliased_bucket([p for p in b.params if p.grad is not None]) is None
     assert b.nbytes() == 4 * (15 + 7)
+
+
+# ---- the gradient all-reduce in two pieces, the first one started inside backward --------------------
+def _flat_bucket_step(model, bucket, shard, overlap):
+    """One step's gradients laid out as the HIP backward leaves them - every .grad a view of the model's flat bucket - with
+    the staged hook called where `_DrinScore.backward` calls it (the layers' gradients final, the vertex encoders' not yet
+    all-reduced), then the step's `allreduce_mean()`."""
+    from drin_amd.metrics import TripletLoss
+    from drin_amd.model import _param_list
+    model.zero_grad(set_to_none=True)
+    TripletLoss(CFG.triplet_margin)(shard[-1], model(shard[:-1])).backward()
+    params = _param_list(model)
+    offsets, live, total = model.bucket_layout()
+    flat = torch.zeros(total)
+    for o, p in zip(offsets, params):
+        if p.grad is not None:
+            view = flat[o:o + p.numel()].view(p.shape)
+            view.copy_(p.grad)
+            p.grad = view
+    model._grad_flat = flat
+    if overlap:
+        model._layers_ready_hook(flat[:live], offsets[8], None)
+    bucket.allreduce_mean()
+    return flat[:live]
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        out = {}
+        for overlap in (False, True):
+            model = OracleModel(CFG)
+            model.load_state_dict(synth.make_state_dict(CFG, 8))
+            bucket = GradBucket(list(model.parameters()), overlap=overlap, model=model)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            for step in range(3):
+                batch = synth.make_batch(CFG, 8, 90 + step)
+                shard = [t[rank * 4:(rank + 1) * 4] for t in batch]
+                _flat_bucket_step(model, bucket, shard, overlap)
+                assert bucket.in_place
+                opt.step()
+            assert bucket.overlapped == (3 if overlap else 0) and bucket.collectives == (6 if overlap else 3)
+            bucket.close()
+            assert model._layers_ready_hook is None
+            out[overlap] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_piece_overlapped_allreduce_is_bit_identical_to_the_one_piece_path():
+    """Three optimiser steps on two ranks with the bucket all-reduced in one piece after backward, and with the GCN layers'
+    piece started from the staged-backward hook + the vertex encoders' piece after it: identical parameters, bit for bit,
+    on both ranks."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_overlap_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(2))
+    for k in r0[False]:
+        assert torch.equal(r0[False][k], r0[True][k]), f"two-piece all-reduce changed {k}"
+        assert torch.equal(r0[True][k], r1[True][k]), f"replicas diverged: {k}"
+
+
+def test_overlapped_bucket_refuses_gradients_that_left_the_bucket():
+    """A piece in flight on memory that is no longer the gradient (accumulation replaced the views) must raise, not
+    silently reduce the wrong bytes.  World of one rank, forced collectives."""
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = OracleModel(CFG)
+        model.load_state_dict(synth.make_state_dict(CFG, 8))
+        bucket = GradBucket(list(model.parameters()), force=True, overlap=True, model=model)
+        batch = synth.make_batch(CFG, 4, 3)
+        before = _flat_bucket_step(model, bucket, batch, True).clone()
+        assert bucket.overlapped == 1 and bucket.collectives == 2
+        assert torch.equal(before, model._grad_flat[:before.numel()])        # a world of one: the mean is the value itself
+        # now the hook fires but the gradients are replaced before the step's all-reduce
+        from drin_amd.model import _param_list
+        offsets, live, _ = model.bucket_layout()
+        model._layers_ready_hook(model._grad_flat[:live], offsets[8], None)
+        for p in _param_list(model):
+            if p.grad is not None:
+                p.grad = p.grad.clone()
+        with pytest.raises(RuntimeError, match="overlap=False"):
+            bucket.allreduce_mean()
+        plain = GradBucket(list(model.parameters()))                         # no force: a world of one does nothing
+        plain.allreduce_mean()
+        assert plain.collectives == 0
+    finally:
+        dist.destroy_process_group()

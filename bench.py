@@ -607,8 +607,10 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
                 graph=False, fused_adam=False, torch_loss=False, library_adam=True, force_collective=False):
     """One optimisation step of train.py:30-56 per "step": forward (intermediates kept), TripletLoss, backward
     through the HIP kernels, the RCCL all-reduce of the flat gradient bucket (world > 1, or a forced world of one), Adam.
-    With collectives the bucket goes in two pieces, the GCN layers' started inside backward (GradBucket(overlap=True));
-    `allreduce_exposed_ms` = what the step's stream still waits for, `allreduce_ms` = the one-piece collective after backward."""
+    With collectives the all-reduce and Adam run on a side stream under the next step's parameter-free head
+    (drin_amd.train.OverlappedStep; DRIN_OVERLAP selects another mode).  `allreduce_ms` = the one-piece collective when it
+    runs serially after backward (HIP events), `allreduce_exposed_ms` = the timed step minus the same step without any
+    collective: what the overlap leaves on the critical path."""
     from drin_amd import _lib
     from drin_amd.metrics import DeviceLossMetric
     from drin_amd.model import Model
@@ -643,18 +645,31 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
         loss_fn = TripletLoss(cfg.triplet_margin)
     opt = make_adam(model, cfg.learning_rate, library=library_adam and not graph and not fused_adam, capturable=graph, fused=fused_adam)
     import torch.distributed as dist
+    from drin_amd.train import OverlappedStep
     collectives = world > 1 or (force_collective and dist.is_available() and dist.is_initialized())
-    overlap = collectives and not graph and os.environ.get("DRIN_NO_OVERLAP") != "1"
+    # how the all-reduce leaves the critical path (drin_amd/train.py): "forward" - collective + Adam on a side stream under
+    # the next step's parameter-free head (default); "backward" - the GCN layers' piece started inside the staged backward
+    mode = os.environ.get("DRIN_OVERLAP", "forward") if (collectives and not graph) else "none"
+    if mode not in ("none", "forward", "backward", "both"):
+        raise SystemExit(f"DRIN_OVERLAP={mode!r}: none | forward | backward | both")
     plain_bucket = GradBucket(list(model.parameters()), force=force_collective)
-    bucket = GradBucket(list(model.parameters()), force=force_collective, overlap=True, model=model) if overlap else plain_bucket
+    staged = mode in ("backward", "both")
+    bucket = GradBucket(list(model.parameters()), force=force_collective, overlap=True, model=model) if staged else plain_bucket
+    pipe = OverlappedStep(model, bucket, opt) if mode in ("forward", "both") else None
     ar_events = []
 
-    def eager_step(record=False, use=None):
-        use = use or bucket
+    def eager_step(record=False, how="default"):
+        """how: "default" (the configured overlap), "serial" (one-piece collective after backward, then Adam), "none" (no collective)"""
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(y, model(batch if batch is not None else ib.gathered()))
         loss.backward()
-        if record and collectives:
+        if how == "default" and pipe is not None:
+            pipe.run()
+            return loss
+        use = bucket if how == "default" else plain_bucket
+        if how == "none":
+            pass
+        elif record and collectives:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             use.allreduce_mean()
@@ -685,21 +700,25 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
             return static_loss
 
     elapsed, per_rank, loss = ctx.timed(step, steps, warmup)
+    if pipe is not None:
+        pipe.finish()
+    serial_ms = none_ms = None
+    hook = model._layers_ready_hook
+    if collectives:
+        # the same step (a) with the one-piece collective after backward and Adam behind it, (b) without any collective:
+        # what the collective costs when nothing hides it, and what of it the configured overlap leaves exposed
+        model._layers_ready_hook = None
+        e_s, _pr, _l = ctx.timed(lambda: eager_step(how="serial"), steps, 5)
+        e_n, _pr, _l = ctx.timed(lambda: eager_step(how="none"), steps, 5)
+        serial_ms, none_ms = e_s / steps * 1e3, e_n / steps * 1e3
     _lib.profile_begin(1 << 16)
     for _ in range(steps):
-        eager_step(record=True)
+        eager_step(record=True, how="serial")
     prof = _lib.profile_end()
     ctx.sync()
-    exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
-    ar_ms = exposed_ms
-    if overlap:                                       # the same step with the one-piece collective after backward, for comparison
-        ar_events.clear()
-        model._layers_ready_hook = None
-        for _ in range(steps):
-            eager_step(record=True, use=plain_bucket)
-        ctx.sync()
-        ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
-        model._layers_ready_hook = bucket._layers_ready
+    model._layers_ready_hook = hook
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
+    exposed_ms = max(0.0, elapsed / steps * 1e3 - none_ms) if none_ms is not None else 0.0
     N = cfg.num_candidates_model
     ab = algorithmic_bytes(cfg, full[:14]) if full is not None else None
     roof = train_roofline(cfg, B, N, prof, steps, precision)
@@ -707,8 +726,11 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
     coll = None
     if collectives:
         coll = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_world_of_one": world == 1,
-                "pieces": 2 if overlap else 1, "in_place": bool(bucket.in_place), "collectives_issued": bucket.collectives + plain_bucket.collectives * (plain_bucket is not bucket),
-                "steps_overlapped": bucket.overlapped}
+                "overlap": mode, "pieces": 2 if staged else 1, "in_place": bool(plain_bucket.in_place or bucket.in_place),
+                "collectives_issued": bucket.collectives + plain_bucket.collectives * (plain_bucket is not bucket),
+                "steps_overlapped_under_next_forward": pipe.steps if pipe is not None else 0,
+                "steps_with_early_piece": bucket.overlapped,
+                "serial_ms_per_step": serial_ms, "no_collective_ms_per_step": none_ms}
     bucket.close()
     return {
         "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)" + (" [hipGraph replay]" if graph else ""),
@@ -755,12 +777,12 @@ def stub_worker(ctx, args):
         want = sum(range(1, ctx.world + 1)) / ctx.world
         assert all(torch.allclose(p.grad, torch.full_like(p, want)) for p in params), "stub all-reduce mean is wrong"
     if ctx.rank == 0:
-        print(json.dumps({"metric": "stub steps/sec (launcher plumbing only, no GPU work)", "stub": True,
+        emit({"metric": "stub steps/sec (launcher plumbing only, no GPU work)", "stub": True,
                           "value": args.steps * ctx.world / elapsed, "unit": "steps/s", "n_gpus": ctx.world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
                           "config": {"workload": f"stub {args.mode}"}, "collectives_issued": bucket.collectives,
-                          "rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}), flush=True)
+                          "rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]})
     ctx.finish()
 
 
@@ -851,10 +873,30 @@ def leg_guard(name, fn):
             torch.cuda.empty_cache()
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout: whatever else writes to file descriptor 1 - RCCL prints a version banner
+    there when its communicator comes up - is sent to stderr; `emit` writes the line to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def main(argv=None):
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_children(args))                     # before anything touches the GPU in this process
+    quiet_stdout()
     ctx = Ctx(args)
     if args.stub:
         return stub_worker(ctx, args)
@@ -873,7 +915,7 @@ def main(argv=None):
         if ctx.pg_error:
             line["collective_error"] = ctx.pg_error
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit(line)
         return ctx.finish()
 
     # WikiMEL: 4096 mentions = 413 696 pairs and 92 GB of resident inputs per step (of 288 GB): large steps
@@ -907,7 +949,7 @@ def main(argv=None):
                     "path": ("per-entity cache + layer 2" if args.entity_cache else "fused two-layer") + ", " + args.precision}
             if rank == 0:
                 line["parity"] = parity_of_timed_batch(cfg, sd, last, out, n_slices=2, width=1)
-                print(json.dumps(line), flush=True)
+                emit(line)
             return ctx.finish()
         batch = make_table_chunk(cfg, table, B, 100 + rank, dev, g)
     else:
@@ -1033,7 +1075,7 @@ def main(argv=None):
             line["legs"] = extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
-        print(json.dumps(line), flush=True)
+        emit(line)
     ctx.finish()
 
 

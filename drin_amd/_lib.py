@@ -82,6 +82,8 @@ EXPORTS = {
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_forward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                C.c_size_t, C.c_void_p, C.c_int, C.POINTER(DrinTraceC), C.c_void_p]),
+    "drin_forward_staged": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
+                                      C.c_size_t, C.c_void_p, C.c_int, C.POINTER(DrinTraceC), C.c_void_p, C.c_void_p]),
     "drin_backward": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                 C.c_size_t, C.c_void_p, C.POINTER(DrinParamGradsC), C.c_void_p]),
     "drin_backward_staged": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,

@@ -507,6 +507,12 @@ int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, 
 
 int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                  size_t workspace_bytes, float* scores, int keep_for_backward, const drin_trace* trace, void* stream) {
+  return drin_forward_staged(cfg, batch, params, workspace, workspace_bytes, scores, keep_for_backward, trace, nullptr, stream);
+}
+
+int drin_forward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
+                        size_t workspace_bytes, float* scores, int keep_for_backward, const drin_trace* trace,
+                        void* params_ready_event, void* stream) {
   RoctxRange range("drin_forward");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
@@ -551,6 +557,13 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
     DRIN_TRY(run_static_edges(cfg, batch, P, ws + L.edges[0], st));
   }
 
+  // Everything above - the pooling passes and the static edges - reads the batch alone; from here on the parameters are
+  // read.  drin_forward_staged: they are final once the caller's event has fired (the previous step's gradient all-reduce
+  // and optimiser update on another stream, which the parameter-free head above has just run under).
+  if (params_ready_event != nullptr) {
+    hipError_t we = hipStreamWaitEvent(st, (hipEvent_t)params_ready_event, 0);
+    if (we != hipSuccess) return hip_fail(we, "hipStreamWaitEvent(params_ready)");
+  }
   // VertexEncoder (model.py:26-46): four Linears
   float* vm0 = ws + L.vm[0];
   float* ve0 = ws + L.ve[0];
@@ -876,7 +889,10 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
   // fill and a partial tile per workgroup; together the workgroups walk ~4x longer slices.  Mention-sized products
   // (exact fp32) and the vector-edge ones (their operands are overwritten layer by layer) run where they arise.
   TnGroup dw_group;
-  F32GemmGroup dw_small;   // the mention-sized ones (exact fp32, atomics onto dW): one launch as well
+  F32GemmGroup dw_small;   // the mention-sized ones (exact fp32): one launch as well
+  // drin_backward_staged: how many entries of the three collections belong to the GCN layers (-1: still collecting them).
+  // An instalment flushed while the vertex encoders' products are being added takes every layer entry with it: 0 remain.
+  int layer_sums = -1, layer_small = -1, layer_group = -1;
   const bool defer_dw = x3 && !vec && tnp != nullptr;
   // (db: the bias gradient that goes with it = the column sums of dy; the group takes them from the rows it stages)
   auto dw_product = [&](const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, int64_t lddw, int64_t rows,
@@ -892,6 +908,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
       if (dw_group.n == TnGroup::MAX) {   // deeper than three layers: the group goes in instalments
         DRIN_TRY(launch_gemm_tn_group(dw_group, st, tnp, tnf));
         dw_group = TnGroup();
+        if (layer_group >= 0) layer_group = 0;
       }
       return dw_group.add(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red, x_index, db);
     }
@@ -902,6 +919,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
       if (dw_small.n == F32GemmGroup::MAX) {
         DRIN_TRY(launch_gemm_tn_f32_group(dw_small, st, smp, L.small_part_floats));
         dw_small = F32GemmGroup();
+        if (layer_small >= 0) layer_small = 0;
       }
       return dw_small.add_tn(dy, lddy, x, ldx, dw, lddw, rows, n_out, k_red);
     }
@@ -1021,7 +1039,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
   }
 
   // what is collected up to here belongs to the GCN layers, what follows to the vertex encoders (drin_backward_staged)
-  const int layer_sums = bias_sums.n, layer_small = dw_small.n, layer_group = dw_group.n;
+  layer_sums = bias_sums.n, layer_small = dw_small.n, layer_group = dw_group.n;
   // VertexEncoder (model.py:26-46): four Linears over the pooled inputs
   const float* g_mt = g_vm[0];
   const float* g_mi = g_vm[0] + BD;
@@ -1037,10 +1055,12 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
   // gradients - each store their slices, and ONE slice-sum launch adds them all to the gradients in a fixed order (two
   // products of one destination, dW_h's mention and entity rows, as two segments of one entry).
   // Staged (layers_ready_event): the same launches in two parts - first everything that lands in a GCN layer's gradients,
-  // then the event, then the vertex encoders' part.  Every product keeps the slices of the one-part launch (the whole
-  // group's target slice length goes to both parts; products of one destination are always in the same part), so the
-  // gradients are the same bit for bit; the scratch regions are reused in stream order.
-  const int64_t target = tn_group_target(dw_group, tnf);
+  // then the event, then the vertex encoders' part; the scratch regions are reused in stream order.  Each part deals the
+  // chip's workgroups over ITS products (handing both parts the whole group's slice length keeps every bit of the one-part
+  // launch, but leaves the chip half empty twice: measured 0.73 -> 0.95 ms of split-bf16 GEMM time per B = 64 step), so the
+  // pair-sized weight gradients of the staged pass differ from drin_backward's in the last bits - by the summation
+  // split only; each is reproducible.
+  const int64_t target = 0;
   auto flush = [&](int s0, int s1, int f0, int f1, int g0, int g1) -> int {
     ColsumBatch cs;
     for (int i = s0; i < s1; ++i) {

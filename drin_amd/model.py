@@ -443,8 +443,14 @@ class _DrinScore(torch.autograd.Function):
         ws = call.workspace(training)
         scores = torch.empty(call.B, call.N, dtype=torch.float32, device=call.device)
         stream = torch.cuda.current_stream(call.device).cuda_stream
-        _lib.check(lib.drin_forward(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), ws.data_ptr(), ws.numel(),
-                                    scores.data_ptr(), 1 if training else 0, None, stream))
+        ready = getattr(call, "params_ready", None)       # train.OverlappedStep: the previous update is still running on a side stream
+        if ready is not None:
+            # the pooling passes and static edges of THIS step run under it; the stream waits before the first weight is read
+            _lib.check(lib.drin_forward_staged(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), ws.data_ptr(), ws.numel(),
+                                               scores.data_ptr(), 1 if training else 0, None, ready.cuda_event, stream))
+        else:
+            _lib.check(lib.drin_forward(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), ws.data_ptr(), ws.numel(),
+                                        scores.data_ptr(), 1 if training else 0, None, stream))
         ctx.call, ctx.ws, ctx.pc, ctx.params = call, ws, pc, params
         return scores
 
@@ -516,6 +522,7 @@ class Model(nn.Module):
         self._grad_flat: Optional[torch.Tensor] = None
         self._bucket_in_flight = False                       # handed out by a backward pass that is still running
         self._layers_ready_hook = None                       # set by train.GradBucket(overlap=True): see _DrinScore.backward
+        self._params_ready = None                            # set by train.OverlappedStep: event behind an update still in flight
         self._param_flat: Optional[torch.Tensor] = None
         self._layout = None
         self.register_load_state_dict_post_hook(_invalidate_after_load)
@@ -681,8 +688,22 @@ class Model(nn.Module):
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         return self._score(call, self._prepared, training, *params)
 
+    def wait_for_parameters(self) -> None:
+        """Make the current stream wait for an optimiser update `train.OverlappedStep` left running on its side stream (no-op
+        otherwise).  Every path that reads the parameters calls it - or, the layer-by-layer forward, hands the event to
+        `drin_forward_staged` so that its parameter-free head runs under the update."""
+        ev, self._params_ready = self._params_ready, None
+        if ev is not None:
+            torch.cuda.current_stream(next(self.parameters()).device).wait_event(ev)
+
     def _score(self, call: _Call, prepared, training: bool, *params):
         call.owner = self
+        ev = self._params_ready
+        if ev is not None:
+            if training or prepared is None:                 # the layer-by-layer entry point: staged
+                call.params_ready, self._params_ready = ev, None
+            else:
+                self.wait_for_parameters()
         return _DrinScore.apply(call, prepared, training, *params)
 
     def _indexed_training_call(self, batch: "IndexedBatch", planes: bool) -> Optional[_Call]:
@@ -710,6 +731,7 @@ class Model(nn.Module):
         lib = _lib.load()
         if call.B == 0:
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
+        self.wait_for_parameters()
         det = tuple(p.detach().contiguous() for p in params)
         pc = _lib.DrinParamsC()
         _fill_params(pc, det, call.per_layer)
@@ -727,6 +749,7 @@ class Model(nn.Module):
     def forward_traced(self, batch: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Scores plus every stage's vertices and edges (tests / debugging)."""
         lib = _lib.load()
+        self.wait_for_parameters()
         call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if self.precision == _lib.PREC_BF16 else self.precision)
         params = tuple(p.detach().contiguous() for p in _param_list(self))
         pc = _lib.DrinParamsC()

@@ -169,6 +169,52 @@ class GradBucket:
         torch._foreach_copy_([p.grad.reshape(-1) for p in live], list(self.flat.split([p.numel() for p in live])))
 
 
+class OverlappedStep:
+    """`bucket.allreduce_mean(); optimizer.step()` of step t on a SIDE stream, under the parameter-free head of step t + 1's
+    forward (SURVEY.md 8e asks for no more than "overlap optional"; this is the part that costs nothing).  A WikiMEL step
+    opens with 0.2 ms of pooling and static-edge kernels that read the batch alone (`ghmfc.py:54-60,245-249`,
+    `model.py:41-45,60-94`); 26.8 MB of all-reduce over xGMI at 8 GPUs is 0.15-0.36 ms.  So after
+    `loss.backward()` the step's stream records an event and goes on to the next batch; the side stream waits for it, runs the
+    collective and the one-launch Adam, and records `model._params_ready`; `drin_forward_staged` makes the step's stream wait
+    for THAT right before its first weight-reading launch.  Same kernels, same arithmetic, same bits as the serial loop
+    (`tests/test_gpu_round3.py`, `tests/test_dist_gloo.py`).
+
+    Whoever reads the parameters outside `model(...)` - evaluation code on another stream, `state_dict()` - calls `finish()`
+    first (`MELRunner` does at the end of every training epoch).  Host tensors / no GPU: runs inline."""
+
+    def __init__(self, model, bucket: GradBucket, optimizer):
+        self.model, self.bucket, self.optimizer = model, bucket, optimizer
+        self._comm: Optional[torch.cuda.Stream] = None
+        self.steps = 0
+
+    def run(self) -> None:
+        """call right after `loss.backward()`"""
+        p0 = next(self.model.parameters())
+        self.steps += 1
+        if not p0.is_cuda or not hasattr(self.model, "_params_ready"):
+            self.bucket.allreduce_mean()
+            self.optimizer.step()
+            return
+        main = torch.cuda.current_stream(p0.device)
+        if self._comm is None or self._comm.device != p0.device:
+            self._comm = torch.cuda.Stream(device=p0.device)
+        self.model.wait_for_parameters()                   # (an update nobody consumed: keep the updates ordered)
+        done = torch.cuda.Event()
+        done.record(main)                                  # the backward pass, and with it the gradient bucket, is complete
+        self._comm.wait_event(done)
+        with torch.cuda.stream(self._comm):
+            self.bucket.allreduce_mean()
+            self.optimizer.step()
+            ready = torch.cuda.Event()
+            ready.record(self._comm)
+        self.model._params_ready = ready
+
+    def finish(self) -> None:
+        """the current stream waits for the update in flight (if any)"""
+        if hasattr(self.model, "wait_for_parameters"):
+            self.model.wait_for_parameters()
+
+
 class LibraryAdam:
     """`torch.optim.Adam(model.parameters(), lr)` of `train.py:55-56` (torch defaults) for a `drin_amd.model.Model`, as ONE
     launch of `drin_adam_step` over the model's flat parameter / gradient / moment buckets instead of torch's nine
@@ -389,7 +435,10 @@ class MELRunner:
         `profiling`: the switch of `train.py:64-70` (`args.profiling`), see `StepProfiler` (GPU only).
         `force_collectives`: run the step's collectives (gradient all-reduce, score gather, metric sync) in a process
         group of ONE rank too - what a one-GPU box can exercise of the N-GPU path.
-        `overlap_allreduce`: `GradBucket(overlap=True)` (default: for the HIP `Model` on a GPU whenever collectives run)."""
+        `overlap_allreduce`: how the gradient all-reduce leaves the critical path when collectives run with the HIP `Model`
+        on a GPU - "forward" (default then): `OverlappedStep`, collective + Adam on a side stream under the next step's
+        parameter-free head; "backward": `GradBucket(overlap=True)`, the GCN layers' piece started inside the staged
+        backward; "both"; False / "none": serial."""
         self.cfg, self.model, self.device = cfg, model, torch.device(device)
         self.entity_table = entity_table
         self.fused_adam, self.library_adam = fused_adam, library_adam
@@ -406,11 +455,19 @@ class MELRunner:
             device_loss = self.device.type == "cuda" and not global_batch_loss
         self.device_loss = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk, self.device) if device_loss else None
         self.force_collectives = force_collectives
+        can = (self.device.type == "cuda" and hasattr(model, "_layers_ready_hook") and getattr(model, "grad_bucket_enabled", False))
         if overlap_allreduce is None:
-            overlap_allreduce = (self.device.type == "cuda" and hasattr(model, "_layers_ready_hook") and _collectives(force_collectives)
-                                 and getattr(model, "grad_bucket_enabled", False))
-        self.bucket = GradBucket(list(model.parameters()), force=force_collectives, overlap=overlap_allreduce,
-                                 model=model if overlap_allreduce else None)
+            overlap_allreduce = "forward" if (can and _collectives(force_collectives)) else "none"
+        mode = {True: "backward", False: "none"}.get(overlap_allreduce, overlap_allreduce)
+        if mode not in ("none", "forward", "backward", "both"):
+            raise ValueError(f"overlap_allreduce={overlap_allreduce!r}")
+        if mode != "none" and not can:
+            raise ValueError("overlap_allreduce needs the HIP Model (grad_bucket=True) on a GPU")
+        self.overlap_mode = mode
+        staged_bwd = mode in ("backward", "both")
+        self.bucket = GradBucket(list(model.parameters()), force=force_collectives, overlap=staged_bwd,
+                                 model=model if staged_bwd else None)
+        self._pipe = None
         self.global_batch_loss = global_batch_loss
         self.log = log
         if profiling and self.device.type != "cuda":
@@ -479,8 +536,13 @@ class MELRunner:
                 optimizer.zero_grad(set_to_none=True)
                 loss = self.forward_step(batch, split, batch_idx)
                 loss.backward()
-                self.bucket.allreduce_mean()
-                optimizer.step()
+                if self.overlap_mode in ("forward", "both"):
+                    if self._pipe is None or self._pipe.optimizer is not optimizer:
+                        self._pipe = OverlappedStep(self.model, self.bucket, optimizer)
+                    self._pipe.run()                                   # collective + Adam on the side stream; the next forward waits
+                else:
+                    self.bucket.allreduce_mean()
+                    optimizer.step()
                 if self.profiler is not None:
                     self.profiler.step()                               # on_train_batch_end (train.py:105-109)
             else:
@@ -488,6 +550,8 @@ class MELRunner:
                     loss = self.forward_step(batch, split, batch_idx)
             total += loss.detach()
             steps += 1
+        if self._pipe is not None:
+            self._pipe.finish()                                        # the last update lands before anyone else reads the weights
         if training and self.profiler is not None:
             self.profiler.stop()                                       # on_train_epoch_end (train.py:84-85)
         for m in meters:

@@ -233,6 +233,16 @@ DRIN_API int drin_forward(const drin_config* cfg, const drin_batch* batch, const
                  void* workspace, size_t workspace_bytes, float* scores, int keep_for_backward,
                  const drin_trace* trace, void* stream);
 
+/* drin_forward for a training loop that runs the previous step's gradient all-reduce and optimiser update on ANOTHER
+ * stream (the reference runs one device, train.py:117-118, and has no counterpart).  `params_ready_event`: a
+ * hipEvent_t recorded on that stream behind the update, or NULL (= drin_forward).  The parameter-free head of the pass - the
+ * pooling kernels and the static edges (ghmfc.py:54-60,245-249; model.py:41-45,60-94), which read the batch alone: 0.2 of
+ * the 1.35 ms of a WikiMEL step at batch 64 - is enqueued first; `stream` then waits for the event (hipStreamWaitEvent)
+ * before the first launch that reads `params`.  Same kernels, same results as drin_forward. */
+DRIN_API int drin_forward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
+                 void* workspace, size_t workspace_bytes, float* scores, int keep_for_backward,
+                 const drin_trace* trace, void* params_ready_event, void* stream);
+
 /* Backward of drin_forward: given grad_scores[B, N], accumulates parameter gradients into `grads`
  * (loss.backward() of train.py:33-34 through model.py:164-209).  Inputs carry no gradient in the
  * reference (precomputed features), so none is produced. */
@@ -245,8 +255,10 @@ DRIN_API int drin_backward(const drin_config* cfg, const drin_batch* batch, cons
  * is recorded on `stream` once every gradient of the GCN layers (the `layer[l]` tensors of `grads`) is complete; only
  * the four vertex encoders' gradients (w_/b_ mention_text, entity_text, mention_image, entity_image) are written after
  * it.  A caller whose gradient bucket keeps the two groups apart starts the all-reduce of the layers' part behind the
- * event, under the vertex encoders' weight-gradient products.  The gradients are those of drin_backward BIT FOR BIT
- * (every split reduction keeps its slices and their order; none of them uses atomics). */
+ * event, under the vertex encoders' weight-gradient products.  The two parts deal the chip's workgroups separately, so the
+ * pair-sized weight gradients differ from drin_backward's in the last bits (another split of the same sums; no atomics:
+ * each entry point reproduces its own bits run after run) and the pass costs two part-filled launches more - measure
+ * before preferring it to drin_forward_staged, which hides the collective without touching the backward pass. */
 DRIN_API int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
                   void* workspace, size_t workspace_bytes, const float* grad_scores,
                   const drin_param_grads* grads, void* layers_ready_event, void* stream);

@@ -154,7 +154,7 @@ def test_grad_bucket_reduces_a_flat_bucket_in_place_and_packs_anything_else():
 
 
 # ---- the gradient all-reduce in two pieces, the first one started inside backward --------------------
-def _flat_bucket_step(model, bucket, shard, overlap):
+def _flat_bucket_step(model, bucket, shard, overlap, reduce=True):
     """One step's gradients laid out as the HIP backward leaves them - every .grad a view of the model's flat bucket - with
     the staged hook called where `_DrinScore.backward` calls it (the layers' gradients final, the vertex encoders' not yet
     all-reduced), then the step's `allreduce_mean()`."""
@@ -173,7 +173,8 @@ def _flat_bucket_step(model, bucket, shard, overlap):
     model._grad_flat = flat
     if overlap:
         model._layers_ready_hook(flat[:live], offsets[8], None)
-    bucket.allreduce_mean()
+    if reduce:
+        bucket.allreduce_mean()
     return flat[:live]
 
 
@@ -182,19 +183,24 @@ def _overlap_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     try:
+        from drin_amd.train import OverlappedStep
         out = {}
-        for overlap in (False, True):
+        for overlap in (False, True, "pipe"):
             model = OracleModel(CFG)
             model.load_state_dict(synth.make_state_dict(CFG, 8))
-            bucket = GradBucket(list(model.parameters()), overlap=overlap, model=model)
+            bucket = GradBucket(list(model.parameters()), overlap=overlap is True, model=model)
             opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            pipe = OverlappedStep(model, bucket, opt) if overlap == "pipe" else None   # host tensors: runs inline
             for step in range(3):
                 batch = synth.make_batch(CFG, 8, 90 + step)
                 shard = [t[rank * 4:(rank + 1) * 4] for t in batch]
-                _flat_bucket_step(model, bucket, shard, overlap)
+                _flat_bucket_step(model, bucket, shard, overlap is True, reduce=pipe is None)
+                if pipe is not None:
+                    pipe.run()
+                else:
+                    opt.step()
                 assert bucket.in_place
-                opt.step()
-            assert bucket.overlapped == (3 if overlap else 0) and bucket.collectives == (6 if overlap else 3)
+            assert bucket.overlapped == (3 if overlap is True else 0) and bucket.collectives == (6 if overlap is True else 3)
             bucket.close()
             assert model._layers_ready_hook is None
             out[overlap] = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -212,6 +218,7 @@ def test_two_piece_overlapped_allreduce_is_bit_identical_to_the_one_piece_path()
         r0, r1 = (torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(2))
     for k in r0[False]:
         assert torch.equal(r0[False][k], r0[True][k]), f"two-piece all-reduce changed {k}"
+        assert torch.equal(r0[False][k], r0["pipe"][k]), f"OverlappedStep changed {k}"
         assert torch.equal(r0[True][k], r1[True][k]), f"replicas diverged: {k}"
 
 

@@ -452,6 +452,8 @@ def test_train_cli_runs_end_to_end(tmp_path, dataset, monkeypatch):
         assert rep["steps"] == 1 and rep["kernel_ms_per_step"]["optim"] > 0 and rep["launches_per_step"]["optim"] == 1
         assert sum(rep["launches_per_step"].values()) >= 30 and sum(ln.startswith("profile cycle 0") for ln in lines) == 2
     rows = open(dump).read().splitlines()
+    assert rows.count("==========  Test ==========") == 2          # on_test_epoch_start (train.py:92-95), once per test pass
+    rows = [r for r in rows if r != "==========  Test =========="]
     import re
     assert sum(bool(re.match(r"^\d+:\t\[", r)) for r in rows) == 2 * 8   # two test passes x 8 mentions (the answer rows' repr may wrap)
     assert rows[0].startswith("0:\t[") and len(eval(rows[0].split(":\t", 1)[1])) == cfg.num_candidates_model

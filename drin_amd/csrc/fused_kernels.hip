@@ -105,9 +105,11 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       const Row<DV> cls = load_row_stream<DV>(base, lane, D4);
       Row<DV> acc = zero_row<DV>();
       int t = 1;
-      if constexpr (sizeof(FT) == 2) {
+      if constexpr (sizeof(FT) == 2 && (EXACT || DV == 1)) {
         // bf16 rows are half the bytes: twice as many of them in flight keeps the same bytes in flight per wave
-        // (the pass is bound by per-CU memory latency, not by instruction issue); same left-to-right sum
+        // (the pass is bound by per-CU memory latency, not by instruction issue); same left-to-right sum.
+        // (Not in the guarded-column instantiation of the wide rows: with the column guards live, eight rows in flight
+        //  spilled 26 VGPRs to scratch - tests/test_host.py::test_no_kernel_uses_scratch; four rows fit, same sum order.)
         for (; t + 8 <= stop; t += 8) {
           Row<DV> r[8];
 #pragma unroll

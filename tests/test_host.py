@@ -283,3 +283,21 @@ def test_step_profiler_follows_the_reference_schedule(tmp_path, monkeypatch):
         short.step()
     short.stop()                                        # the epoch ended after one timed step
     assert short.reports[0]["steps"] == 1 and not short.open
+
+
+def test_no_kernel_uses_scratch():
+    """no kernel of the gfx950 code objects may spill to scratch memory (`.private_segment_fixed_size` /
+    `.vgpr_spill_count` of the AMDGPU metadata notes; round 2 shipped `k_entity_stream<3, 8, tokens, guarded, bf16>` with 26
+    spilled VGPRs).  Reads the objects `python -m drin_amd.build` leaves under csrc/build - no GPU."""
+    from drin_amd import build, resources
+    build.build(verbose=False)
+    rows = resources.kernel_resources()
+    names = " ".join(k["name"] for k in rows)
+    for must in ("k_entity_stream", "k_gemm_bf16x3", "k_gemm_x3_planes", "k_gemm_tn_bf16x3", "k_gemm_f32", "k_pair_layer1", "k_pair_final",
+                 "k_cached_pairs", "k_slice_sum", "k_layernorm_gelu_bwd"):
+        assert must in names, f"{must} not found in the code objects"
+    assert len(rows) >= 90
+    bad = [(k["name"], k.get("private_segment_fixed_size", 0), k.get("vgpr_spill_count", 0)) for k in rows
+           if k.get("private_segment_fixed_size", 0) or k.get("vgpr_spill_count", 0)]
+    assert not bad, f"kernels with scratch / spilled VGPRs: {bad}"
+    assert all(k.get("vgpr_count", 0) <= 256 for k in rows)

@@ -72,9 +72,8 @@ class DrinConfig:
         # the reference takes getattr(torch.nn.functional, name) (model.py:117-118): any name.  Built: see include/drin_hip.h
         if self.gcn_vertex_activation not in ("gelu", "relu", "tanh", "silu", "sigmoid"):
             raise NotImplementedError(f"gcn_vertex_activation {self.gcn_vertex_activation!r}: built are gelu, relu, tanh, silu, sigmoid")
-        if self.gcn_edge_activation not in ("sigmoid", "tanh", "relu"):
-            raise NotImplementedError(f"gcn_edge_activation {self.gcn_edge_activation!r}: built are sigmoid, tanh, relu "
-                                      "(the backward takes the derivative from the stored edge value)")
+        if self.gcn_edge_activation not in ("sigmoid", "tanh", "relu", "gelu", "silu"):
+            raise NotImplementedError(f"gcn_edge_activation {self.gcn_edge_activation!r}: built are sigmoid, tanh, relu, gelu, silu")
         if self.gcn_embed_dim != self.bert_embed_dim:
             raise ValueError("gcn_embed_dim must equal bert_embed_dim (args.py:38-39 force the output dims)")
         if len(self.gcn_edge_enabled) != 4:

@@ -145,10 +145,10 @@ int validate_config(const drin_config* c) {
     set_error("config: vertex_activation %d is not a drin_activation", c->vertex_activation);
     return DRIN_E_UNSUPPORTED;
   }
-  if (c->edge_activation != DRIN_ACT_DEFAULT && c->edge_activation != DRIN_ACT_SIGMOID && c->edge_activation != DRIN_ACT_RELU &&
-      c->edge_activation != DRIN_ACT_TANH) {
-    set_error("config: edge_activation %d - built are sigmoid, tanh and relu (the backward takes the derivative from the stored "
-              "edge value, which gelu / silu do not offer)", c->edge_activation);
+  // (sigmoid, tanh, relu: the backward takes the derivative from the stored edge; gelu, silu: the forward keeps the
+  //  pre-activation for it, Layout::edge_z)
+  if (c->edge_activation < DRIN_ACT_DEFAULT || c->edge_activation > DRIN_ACT_SILU) {
+    set_error("config: edge_activation %d is not a drin_activation", c->edge_activation);
     return DRIN_E_UNSUPPORTED;
   }
   if (c->precision != DRIN_PREC_F32 && c->precision != DRIN_PREC_BF16X3 && c->precision != DRIN_PREC_BF16X3_ALL &&
@@ -617,6 +617,8 @@ int drin_forward_staged(const drin_config* cfg, const drin_batch* batch, const d
 
   bool all_enabled = true;
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
+  // gelu / silu edges (model.py:118 takes any F.* name): their derivative needs the pre-activation, kept when training
+  const bool keep_z = L.training && (act_e == DRIN_ACT_GELU || act_e == DRIN_ACT_SILU);
 
   for (int l = 0; l < nl; ++l) {
     const drin_layer_params& W = params->layer[l];
@@ -687,12 +689,12 @@ int drin_forward_staged(const drin_config* cfg, const drin_batch* batch, const d
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, H, 2 * M, H, D, false, prec, st));
       DRIN_TRY(launch_edge_pre_vec(fu, fv, e, pre, B, N, D, st));
       DRIN_TRY(launch_gemm_nt(pre, D, W.w_m, D, W.b_m, e_next, D, 4 * M, D, D, false, prec, st));
-      DRIN_TRY(launch_sigmoid_inplace(e_next, 4 * M * D, st, act_e));
+      DRIN_TRY(launch_sigmoid_inplace(e_next, 4 * M * D, st, act_e, keep_z ? ws + L.edge_z[l] : nullptr));
     } else if (live_edges) {
       float* fu = ws + L.fu[l];
       float* fv = ws + L.fv[l];
       DRIN_TRY(launch_gemm_nt(et, D, W.w_v, D, W.b_v, fv, D, 2 * M, D, D, false, prec, st, tl, tlf, wp(L.wp_v[l])));   // fu: with W_h above
-      DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st, act_e));
+      DRIN_TRY(launch_edge_update4(fu, fv, e, e_next, B, N, D, st, act_e, keep_z ? ws + L.edge_z[l] : nullptr));
     } else if (!cfg->dynamic_edges) {
       hipError_t err = hipMemcpyAsync(e_next, e, 4 * ES * sizeof(float), hipMemcpyDeviceToDevice, st);
       if (err != hipSuccess) return hip_fail(err, "hipMemcpyAsync(static edges)");
@@ -845,6 +847,9 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
   for (int k = 0; k < 4; ++k) all_enabled = all_enabled && cfg->edge_enabled[k] == 1.0f;
   float* const tnp = L.tn_part_floats ? ws + L.tn_part : nullptr;  // partial tiles of the split-bf16 dW products
   const size_t tnf = L.tn_part_floats;
+  // gelu / silu edges: the derivative is taken at the pre-activation the forward kept (Layout::edge_z)
+  const bool from_z = act_e == DRIN_ACT_GELU || act_e == DRIN_ACT_SILU;
+  const int act_eb = from_z ? (act_e | 0x100) : act_e;   // device_utils.h: kActFromPre
   float* const smp = ws + L.small_part;     // slices of the mention-sized exact-fp32 dW products
   float* const csp = ws + L.colsum_part;    // partial rows of the bias column sums
   // dX (+)= dY W.  Pair-sized products in split-bf16 precision run on the NT kernel against W^T, transposed into
@@ -973,7 +978,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
     if (edge_update && vec) {
       // (d, vector edges) e' = sigmoid(W_m(cat(W_u(u), W_v(v)) + e) + b_m)  (model.py:150-152,133)
       const int H = D / 2;
-      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st, act_e));  // dz
+      DRIN_TRY(launch_sigmoid_bwd(g_e[cur], from_z ? ws + L.edge_z[l] : ws + L.edges[l + 1], dpre, 4 * (int64_t)ES, st, act_eb));  // dz
       if (G.w_m) DRIN_TRY(launch_gemm_tn(dpre, D, ws + L.pre[l], D, G.w_m, D, 4 * (int64_t)M, D, D, prec, st, tnp, tnf));
       DRIN_TRY(launch_colsum(dpre, G.b_m, 4 * (int64_t)M, D, st, csp, L.colsum_part_floats));
       DRIN_TRY(gemm_nn(dpre, D, W.w_m, g_e[cur], D, 4 * (int64_t)M, D, D, false));  // d(cat + e)
@@ -989,7 +994,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
       const float* fv = ws + L.fv[l];
       const float inv_d = 1.0f / (float)D;
       // dpre = g e' (1 - e');  dfv_t = (dpre_tt fu_t + dpre_it fu_i) / D ; dfv_i = (dpre_ti fu_t + dpre_ii fu_i) / D: one pass
-      DRIN_TRY(launch_edge_update_bwd(g_e[cur], ws + L.edges[l + 1], fu, dpre, dfv, B, N, D, inv_d, st, act_e));
+      DRIN_TRY(launch_edge_update_bwd(g_e[cur], from_z ? ws + L.edge_z[l] : ws + L.edges[l + 1], fu, dpre, dfv, B, N, D, inv_d, st, act_eb));
       // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
       if (B <= 65535) {
         DRIN_TRY(launch_mention_reduce2(dpre, fv, fv + MD, nullptr, nullptr, dfu, dfu + BD, B, N, D, inv_d, st));

@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) k_sigmoid_bwd(const float* __restrict__ g
                                                      float* __restrict__ dpre, int64_t n, int act) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    dpre[i] = g[i] * act_grad_from_output(act, e_new[i]);
+    dpre[i] = g[i] * edge_act_grad(act, e_new[i]);
   }
 }
 
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float e = e_new[k * pairs + p];
-    d[k] = g[k * pairs + p] * act_grad_from_output(act, e);
+    d[k] = g[k * pairs + p] * edge_act_grad(act, e);
   }
   if (lane < 4) dpre[(int64_t)lane * pairs + p] = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
   const float* ft = fu + b * (int64_t)D4 * 4;

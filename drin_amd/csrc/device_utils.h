@@ -135,6 +135,13 @@ __device__ __forceinline__ float act_grad_from_output(int id, float y) {
   }
 }
 
+// The edge update's backward: `act` carries kActFromPre when the buffer it reads holds the PRE-activation z (kept by the
+// forward for gelu / silu edges, model.py:118 takes any F.* name), else the buffer is the stored edge e' = act(z).
+constexpr int kActFromPre = 0x100;
+__device__ __forceinline__ float edge_act_grad(int act, float v) {
+  return (act & kActFromPre) ? act_grad(act & 0xff, v) : act_grad_from_output(act, v);
+}
+
 // nn.CosineSimilarity as torch>=2 evaluates it: each norm clamped at eps separately.
 __device__ __forceinline__ float cosine_from_sums(float xy, float xx, float yy, float eps) {
   return xy / (fmaxf(sqrtf(xx), eps) * fmaxf(sqrtf(yy), eps));

@@ -311,7 +311,7 @@ int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, i
 // order is fixed, so the results do not depend on the launch geometry.
 __global__ void __launch_bounds__(256) k_edge_update4(const float* __restrict__ fu, const float* __restrict__ fv,
                                                       const float* __restrict__ e, float* __restrict__ out,
-                                                      int64_t pairs, int B, int N, int D4, int act) {
+                                                      int64_t pairs, int B, int N, int D4, int act, float* __restrict__ z_out) {
   int64_t p, b;
   if (!wave_pair(pairs, N, p, b)) return;
   const int lane = threadIdx.x & 63;
@@ -334,15 +334,19 @@ __global__ void __launch_bounds__(256) k_edge_update4(const float* __restrict__ 
   s_ii = wave_sum(s_ii);
   if (lane == 0) {
     const float d = (float)(D4 * 4);
-    out[p] = act_apply(act, s_tt / d + e[p]);
-    out[pairs + p] = act_apply(act, s_ti / d + e[pairs + p]);
-    out[2 * pairs + p] = act_apply(act, s_it / d + e[2 * pairs + p]);
-    out[3 * pairs + p] = act_apply(act, s_ii / d + e[3 * pairs + p]);
+    const float z0 = s_tt / d + e[p], z1 = s_ti / d + e[pairs + p], z2 = s_it / d + e[2 * pairs + p], z3 = s_ii / d + e[3 * pairs + p];
+    out[p] = act_apply(act, z0);
+    out[pairs + p] = act_apply(act, z1);
+    out[2 * pairs + p] = act_apply(act, z2);
+    out[3 * pairs + p] = act_apply(act, z3);
+    if (z_out != nullptr) {  // an activation whose derivative cannot be taken from its output (gelu, silu): backward reads z
+      z_out[p] = z0, z_out[pairs + p] = z1, z_out[2 * pairs + p] = z2, z_out[3 * pairs + p] = z3;
+    }
   }
 }
 
 int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
-                        hipStream_t st, int act) {
+                        hipStream_t st, int act, float* z_out) {
   const int64_t pairs = (int64_t)B * N;
   if (pairs <= 0) return DRIN_OK;
   if (D % 4) {
@@ -350,7 +354,7 @@ int launch_edge_update4(const float* fu, const float* fv, const float* e, float*
     return DRIN_E_SHAPE;
   }
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_edge_update4, pair_grid(B, N), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4, act);
+  hipLaunchKernelGGL(k_edge_update4, pair_grid(B, N), dim3(256), 0, st, fu, fv, e, out, pairs, B, N, D / 4, act, z_out);
   DRIN_CHECK_LAUNCH("k_edge_update4");
   return DRIN_OK;
 }

@@ -266,8 +266,9 @@ int launch_layernorm_gelu2(const float* h, float* y, float* mean, float* rstd, i
                            float* mean2, float* rstd2, int64_t rows2, const float* gamma, const float* beta, int D, float eps,
                            hipStream_t st, int act = DRIN_ACT_GELU);
 // model.py:148-153 + :133: out[b,n] = sigmoid(mean_d(fu[b,:] fv[b,n,:]) + e[b,n])
+// (z_out: optional [4][B*N], the pre-activations - kept for backward when the activation has no derivative-from-output)
 int launch_edge_update4(const float* fu, const float* fv, const float* e, float* out, int B, int N, int D,
-                        hipStream_t st, int act = DRIN_ACT_SIGMOID);
+                        hipStream_t st, int act = DRIN_ACT_SIGMOID, float* z_out = nullptr);
 
 // ---- backward row kernels (backward_kernels.hip) ------------------------------------------------
 // d cos(x[b], y[p]) : dx [B, D], dy [B*N, D]; scratch3 holds 3 * B*N floats
@@ -302,6 +303,7 @@ struct ColsumBatch {
 // (scratch: sum over the entries of by * C floats <= 8 * kColsumMaxSlices * C; defer as for launch_gemm_tn_group)
 int launch_colsum_batch(const ColsumBatch& b, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer = nullptr);
 // sigmoid backward of the scalar edge update + both entity-side gradients dfv_t, dfv_i in one pass (see the kernel)
+// (act | kActFromPre (device_utils.h: 0x100): e_new holds the pre-activation instead of the stored edge; also launch_sigmoid_bwd)
 int launch_edge_update_bwd(const float* g, const float* e_new, const float* fu, float* dpre, float* dfv, int B, int N, int D,
                            float scale, hipStream_t st, int act = DRIN_ACT_SIGMOID);
 // dpre = g * e' * (1 - e')
@@ -329,7 +331,7 @@ int launch_entity_aggregate_vec(const float* e1, const float* m1, const float* e
                                 float* out, int B, int N, int D, hipStream_t st);
 int launch_edge_pre_vec(const float* fu, const float* fv, const float* e, float* pre, int B, int N, int D,
                         hipStream_t st);
-int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st, int act = DRIN_ACT_SIGMOID);
+int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st, int act = DRIN_ACT_SIGMOID, float* z_out = nullptr);
 int launch_edge_pre_vec_bwd(const float* dpre, float* dfu, float* dfv, int B, int N, int D, hipStream_t st);
 int launch_entity_side_bwd_vec(const float* dA_mt, const float* dA_mi, const float* dA_et, const float* dA_ei,
                                const float* mt, const float* mi, const float* et, const float* ei, const float* e,

@@ -40,6 +40,7 @@ struct Layout {
   size_t fv[DRIN_MAX_LAYERS] = {};          // [2][M][D]  W_v(et), W_v(ei)
   size_t edges_scalar = 0;                  // [4][M]     scalar static edges before model.py:202 expands them (vector edges)
   size_t pre[DRIN_MAX_LAYERS] = {};         // [4][M][D]  W_m input cat(fu, fv) + e (vector edges)
+  size_t edge_z[DRIN_MAX_LAYERS] = {};      // [4][M](x D) pre-activation of the edge update, kept for backward with gelu / silu edges
   size_t splitk = 0, splitk_floats = 0;     // split-K partials of the mention-sized exact-fp32 products (small batches only)
   size_t tn_part = 0, tn_part_floats = 0;   // [slices][N][K] partial tiles of the split-bf16 weight-gradient products
   size_t small_part = 0, small_part_floats = 0;     // slices of the mention-sized exact-fp32 weight-gradient products (launch_gemm_tn_f32_group)
@@ -92,6 +93,7 @@ struct Layout {
       for (int l = 0; l < nl; ++l) {
         masked[l] = take(4 * M * EW);
         pre[l] = take(c.vector_edges ? 4 * M * D : 0);
+        edge_z[l] = take((c.edge_activation == DRIN_ACT_GELU || c.edge_activation == DRIN_ACT_SILU) && c.dynamic_edges ? 4 * M * EW : 0);
         agg_m[l] = take(2 * B * D);
         agg_e[l] = take(2 * M * D);
         h_m[l] = take(2 * B * D);

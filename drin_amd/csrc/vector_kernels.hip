@@ -135,17 +135,18 @@ int launch_edge_pre_vec(const float* fu, const float* fv, const float* e, float*
 }
 
 // x = sigmoid(x) in place
-__global__ void __launch_bounds__(256) k_sigmoid_inplace(float* __restrict__ x, int64_t n4, int act) {
+__global__ void __launch_bounds__(256) k_sigmoid_inplace(float* __restrict__ x, int64_t n4, int act, float* __restrict__ z_out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const float4 v = ld4(x + i * 4);
+  if (z_out != nullptr) st4(z_out + i * 4, v);   // the pre-activation, for activations without a derivative-from-output
   st4(x + i * 4, make_float4(act_apply(act, v.x), act_apply(act, v.y), act_apply(act, v.z), act_apply(act, v.w)));
 }
 
-int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st, int act) {
+int launch_sigmoid_inplace(float* x, int64_t n, hipStream_t st, int act, float* z_out) {
   if (n <= 0) return DRIN_OK;
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_sigmoid_inplace, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, x, n / 4, act);
+  hipLaunchKernelGGL(k_sigmoid_inplace, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, x, n / 4, act, z_out);
   DRIN_CHECK_LAUNCH("k_sigmoid_inplace");
   return DRIN_OK;
 }

@@ -31,6 +31,10 @@ CASES = {
     #  reference's own fp32 autograd is only good to ~1e-3 there; the backward of this activation is covered against the
     #  oracle by the random-geometry sweep)
     "tiny_wd_sigmoid_vertex": (DrinConfig(gcn_vertex_activation="sigmoid", num_gcn_layers=3, **TINY), 2, 17, 8, True, False),
+    # edge activations without a derivative-from-output (the backward keeps the pre-activation for them)
+    "tiny_wd_gelu_edge": (DrinConfig(gcn_edge_activation="gelu", num_gcn_layers=3, **TINY), 3, 18, 8, True, True),
+    "tiny_wm_silu_edge_vector": (DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6,
+                                            gcn_edge_activation="silu", gcn_edge_feature="vector", **TINY), 3, 19, 8, True, True),
     "tiny_wm_n37": (DrinConfig(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=9, **TINY), 4, 9, 8, True, False),
 }
 

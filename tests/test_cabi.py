@@ -144,7 +144,12 @@ def test_activation_ids_are_validated_on_host():
     c.vertex_activation = _lib.ACTIVATIONS["relu"]
     assert lib.drin_workspace_bytes(C.byref(c), 1) > 0
     assert lib.drin_fused_supported(C.byref(c)) == _lib.OK                # the folded paths take the built activations too
-    c.edge_activation = _lib.ACTIVATIONS["silu"]                          # no derivative-from-output: not built for edges
+    plain = lib.drin_workspace_bytes(C.byref(c), 1)
+    c.edge_activation = _lib.ACTIVATIONS["silu"]                          # no derivative-from-output: the forward keeps the pre-activation
+    kept = lib.drin_workspace_bytes(C.byref(c), 1)
+    assert kept >= plain + 4 * 4 * c.batch * c.num_candidates             # one [4][B N] fp32 per layer that updates its edges
+    assert lib.drin_workspace_bytes(C.byref(c), 0) == lib.drin_workspace_bytes(C.byref(c), 0)
+    c.edge_activation = 17
     assert lib.drin_workspace_bytes(C.byref(c), 1) == 0 and b"edge_activation" in lib.drin_last_error()
     c.edge_activation, c.vertex_activation = 0, 17
     assert lib.drin_workspace_bytes(C.byref(c), 1) == 0

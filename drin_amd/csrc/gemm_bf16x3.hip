@@ -18,6 +18,8 @@
 //     the number of workgroups, not the tile efficiency, decides the time.
 // LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled per row quad so that every
 // ds_read_b128 lane group lands on 16 distinct bank quads (for LDS-DMA the swizzle goes on the source).
+#include <stdlib.h>
+
 #include "device_utils.h"
 #include "internal.h"
 
@@ -55,7 +57,8 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
 template <int ROWS, int THREADS>
 struct Stager {
   static constexpr int RPP = THREADS / 8;  // rows per pass
-  static constexpr int PASSES = ROWS / RPP;
+  static constexpr int PASSES = (ROWS + RPP - 1) / RPP;   // (a last, partly used pass: its surplus rows are loaded clamped and not stored)
+  static constexpr bool RAGGED = (ROWS % RPP) != 0;
   const float* p[PASSES];
   float4 v[PASSES];
 
@@ -65,7 +68,7 @@ struct Stager {
     const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-      int64_t row = row0 + r + RPP * i;
+      int64_t row = row0 + (RAGGED && r + RPP * i >= ROWS ? ROWS - 1 : r + RPP * i);
       row = row < rows ? row : rows - 1;
       if (index != nullptr) row = index[row];
       p[i] = src + row * ld + c4 * 4;
@@ -81,6 +84,7 @@ struct Stager {
     const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
+      if (RAGGED && r + RPP * i >= ROWS) continue;
       bf16x4 hi, lo;
       split4(v[i], hi, lo);
       const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
@@ -373,6 +377,221 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
   return DRIN_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Stream-K form of the same product for problems whose tiles do not fill the chip in whole rounds (the B = 64 training
+// step: 6 464 / 12 928 rows x 768 columns are 0.6 / 1.2 rounds of 128 x 256 tiles on 256 CUs; as 64 x 128 tiles they fill it
+// but run at the L2 -> LDS bandwidth such a small tile needs: SQ counters 0.30 of the cycles with an MFMA executing, 0.51 of
+// the wave time parked - profiles/r3_mfma_pmc.json).  The work is the sequence of (tile, K-block) units, tile-major; the
+// launch has exactly as many workgroups as the chip keeps resident and workgroup w walks units [w U / G, (w + 1) U / G):
+// every CU gets the same number of K-blocks whatever the tile count.  A tile that lies inside one workgroup's range is
+// stored by it as usual; a tile cut by a range boundary has EVERY one of its segments stored raw to the scratch
+// (slot 2 w for a segment that starts inside the tile, 2 w + 1 for one that starts at its first K-block) and k_sk_fixup adds
+// the segments in workgroup order, with the bias: no atomics, the same bits every run.
+template <int BM, int BN, int WM, int WN, bool W_PLANES>
+__global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
+    k_gemm_bf16x3_sk(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
+                     const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
+                     int64_t ldc, int64_t M, int N, int K, int accumulate, unsigned col_tiles, unsigned tiles,
+                     float* __restrict__ partial, const int64_t* __restrict__ a_index) {
+  using G = Cfg<BM, BN, WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned nkb = (unsigned)(K / BK);
+  const uint64_t U = (uint64_t)tiles * nkb;
+  // XCD-contiguous ranges: consecutive tiles (column index fastest) share their A rows through one L2
+  unsigned w = blockIdx.x;
+  {
+    const unsigned total = gridDim.x, xcd = w & 7, k = w >> 3, q = total >> 3, rem = total & 7;
+    w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  }
+  uint64_t u = (uint64_t)w * U / gridDim.x;
+  const uint64_t u_end = (uint64_t)(w + 1) * U / gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 15, c = lane >> 4;
+
+  while (u < u_end) {
+    const unsigned t = (unsigned)(u / nkb);
+    const int kb0 = (int)(u - (uint64_t)t * nkb);
+    const int len = (int)((uint64_t)(nkb - kb0) < u_end - u ? (uint64_t)(nkb - kb0) : u_end - u);
+    const int kb1 = kb0 + len;
+    u += len;
+    const int n0 = (int)(t % col_tiles) * BN;
+    const int64_t m0 = (int64_t)(t / col_tiles) * BM;
+
+    f32x4 acc[G::MI][G::NI];
+#pragma unroll
+    for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < G::NI; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
+
+    Stager<BM, G::THREADS> sa;
+    Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;
+    PlaneDma<BN, WM * WN> dma;
+    sa.init(A, lda, m0, M, a_index);
+    if (W_PLANES)
+      dma.init(w_hi, w_lo, ldw, n0, N);
+    else
+      sb.init(W, ldw, n0, N);
+    sa.load(kb0 * BK);
+    if (W_PLANES)
+      dma.issue(smem + 2 * G::A_PLANE, kb0);
+    else
+      sb.load(kb0 * BK);
+    sa.store(smem, smem + G::A_PLANE);
+    if (!W_PLANES) sb.store(smem + 2 * G::A_PLANE, smem + 2 * G::A_PLANE + G::B_PLANE);
+    if (len > 1) {
+      sa.load((kb0 + 1) * BK);
+      if (!W_PLANES) sb.load((kb0 + 1) * BK);
+    }
+    __syncthreads();
+
+    bf16x8 bh[G::NI], bl[G::NI];
+    auto load_b = [&](const char* buf) {
+#pragma unroll
+      for (int j = 0; j < G::NI; ++j) {
+        const int off = swz(wn * (BN / WN) + j * 16 + r, c);
+        bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + off);
+        bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
+      }
+    };
+    auto row_tiles = [&](const char* buf, int i0, int i1) {
+#pragma unroll
+      for (int i = 0; i < G::MI; ++i) {
+        if (i < i0 || i >= i1) continue;
+        const int off = swz(wm * (BM / WM) + i * 16 + r, c);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
+#pragma unroll
+        for (int j = 0; j < G::NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+        }
+      }
+    };
+    for (int kb = kb0; kb < kb1; ++kb) {  // the pipeline of k_gemm_bf16x3
+      const int cur = (kb - kb0) & 1;
+      const char* buf = smem + cur * G::BUF_BYTES;
+      char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
+      const bool more = kb + 1 < kb1;
+      if (W_PLANES && more) dma.issue(nb + 2 * G::A_PLANE, kb + 1);
+      load_b(buf);
+      row_tiles(buf, 0, G::MI / 2);
+      if (more) {
+        sa.store(nb, nb + G::A_PLANE);
+        if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
+        if (kb + 2 < kb1) {
+          sa.load((kb + 2) * BK);
+          if (!W_PLANES) sb.load((kb + 2) * BK);
+        }
+      }
+      row_tiles(buf, G::MI / 2, G::MI);
+      __syncthreads();
+    }
+
+    if (kb0 != 0 || kb1 != (int)nkb) {  // a segment of a cut tile: raw accumulators, row-major [BM][BN]
+      float* part = partial + ((size_t)2 * w + (kb0 == 0 ? 1 : 0)) * (size_t)(BM * BN);
+#pragma unroll
+      for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NI; ++j)
+          st4(part + (wm * (BM / WM) + i * 16 + r) * BN + wn * (BN / WN) + j * 16 + c * 4,
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < G::MI; ++i) {
+      const int64_t row = m0 + wm * (BM / WM) + i * 16 + r;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < G::NI; ++j) {
+        const int col = n0 + wn * (BN / WN) + j * 16 + c * 4;
+        if (col >= N) continue;   // N % 4 == 0: a group of four columns is inside or outside as a whole
+        float* dst = C + row * ldc + col;
+        float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (bias != nullptr) o = o + ld4(bias + col);
+        if (accumulate) o = o + ld4(dst);
+        st4(dst, o);
+      }
+    }
+  }
+}
+
+// C[cut tile] (+)= bias + its segments, in workgroup order.  grid (BM * BN / 1024, tiles), 256 threads, a float4 each.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) k_sk_fixup(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                  float* __restrict__ C, int64_t ldc, int64_t M, int N, unsigned col_tiles,
+                                                  unsigned tiles, unsigned nkb, unsigned G, int accumulate) {
+  const unsigned t = blockIdx.y;
+  const uint64_t U = (uint64_t)tiles * nkb, first = (uint64_t)t * nkb, last = first + nkb - 1;
+  const unsigned w_first = (unsigned)(((first + 1) * G - 1) / U), w_last = (unsigned)(((last + 1) * G - 1) / U);
+  if (w_first == w_last) return;   // the tile lay inside one workgroup's range and was stored by it
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int row = e / (BN / 4), c4 = e - row * (BN / 4);
+  const int64_t m = (int64_t)(t / col_tiles) * BM + row;
+  const int col = (int)(t % col_tiles) * BN + c4 * 4;
+  if (row >= BM || m >= M || col >= N) return;
+  float4 s = bias != nullptr ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t off = (size_t)row * BN + (size_t)c4 * 4;
+  for (unsigned w = w_first; w <= w_last; ++w) {
+    const uint64_t start = (uint64_t)w * U / G;
+    s = s + ld4(partial + ((size_t)2 * w + (start <= first ? 1 : 0)) * (size_t)(BM * BN) + off);
+  }
+  float* dst = C + m * ldc + col;
+  if (accumulate) s = s + ld4(dst);
+  st4(dst, s);
+}
+
+template <int BM, int BN, int WM, int WN, bool W_PLANES>
+static int launch_sk(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
+                     const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate,
+                     float* scratch, size_t scratch_floats, const int64_t* a_index, bool* done) {
+  using G = Cfg<BM, BN, WM, WN>;
+  *done = false;
+  const int64_t mt = cdiv(M, BM), nt = cdiv(N, BN);
+  const int64_t tiles = mt * nt, nkb = K / BK;
+  if (tiles > ((int64_t)1 << 24) || scratch == nullptr || (N % 4) || (ldy % 4) || !aligned16(y) || !aligned16(scratch)) return DRIN_OK;
+  auto kern = k_gemm_bf16x3_sk<BM, BN, WM, WN, W_PLANES>;
+  static DynLdsOptIn opt_in;
+  DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), G::LDS_BYTES, "hipFuncSetAttribute(gemm_bf16x3_sk)"));
+  // as many workgroups as the chip keeps resident (occupancy x CUs, asked once per device)
+  static std::atomic<int> resident[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  int g = resident[dev & 63].load(std::memory_order_relaxed);
+  if (g == 0) {
+    int per_cu = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, G::THREADS, G::LDS_BYTES);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(gemm_bf16x3_sk)");
+    g = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
+    resident[dev & 63].store(g, std::memory_order_relaxed);
+  }
+  const int64_t units = tiles * nkb;
+  int64_t groups = g;
+  if (groups * 4 > units) groups = units / 4;           // at least four K-blocks per workgroup
+  if (groups < 1) groups = 1;
+  while (groups > 1 && (size_t)2 * groups * BM * BN > scratch_floats) --groups;
+  if ((size_t)2 * groups * BM * BN > scratch_floats) return DRIN_OK;
+  {
+    KernelTimer timer(DRIN_KC_GEMM_X3, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
+                       (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, (unsigned)tiles, scratch,
+                       a_index);
+    DRIN_CHECK_LAUNCH("k_gemm_bf16x3_sk");
+    if (groups > 1) {
+      hipLaunchKernelGGL((k_sk_fixup<BM, BN>), dim3(BM * BN / 1024, (unsigned)tiles), dim3(256), 0, st, scratch, bias, y, ldy, M, N,
+                         (unsigned)nt, (unsigned)tiles, (unsigned)nkb, (unsigned)groups, accumulate ? 1 : 0);
+      DRIN_CHECK_LAUNCH("k_sk_fixup");
+    }
+  }
+  *done = true;
+  return DRIN_OK;
+}
+
 }  // namespace x3
 
 int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int N, unsigned col_tiles, unsigned full,
@@ -416,6 +635,49 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
     return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
   }
   if (tail != nullptr && !aligned16(tail)) tail = nullptr;
+  // Mid-sized products (a few thousand to a few ten thousand rows: the training step at the reference's batch): 64 x 128 tiles
+  // fill the chip but run at the L2 -> LDS bandwidth so small a tile needs (SQ counters: an MFMA executing in 0.30 of the
+  // cycles, waves parked 0.51 of their time - profiles/r3_mfma_pmc.json).  Where a BM x 256 tile of eight waves comes to at
+  // least three quarters of a whole number of rounds of the chip's 256 CUs, it is taken instead - BM in {96, 128, 160, 192},
+  // the one with the least rounds x rows: 6 464 rows -> 96 (204 tiles), 12 928 -> 160 (243), 25 856 -> 160 (486).  Same
+  // box, the B = 64 step's split-bf16 GEMM time 0.730 -> 0.679 ms, B = 128 1.360 -> 1.249 (profiles/r3_tile_shapes_ab.txt).
+  // Measured there and NOT adopted: the same tiles at a fixed BM for every product (0.726 - 0.855 ms), and three stream-K
+  // forms (k_gemm_bf16x3_sk, kept behind DRIN_SK for the record: every CU gets the same number of K-blocks, but below one
+  // round every tile is cut and takes the scratch + fix-up path: 64 x 128 0.859, 128 x 256 0.781, 256 x 256 0.955 ms).
+  {
+    static const char* sk = getenv("DRIN_SK");
+    const bool mid = !big && M >= 2048;
+    const char* mode = sk != nullptr ? sk : "auto";
+    bool done = false;
+    if (mode[0] == '6' && mid) {
+      DRIN_TRY(planes ? (x3::launch_sk<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done))
+                      : (x3::launch_sk<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done)));
+    } else if (mode[0] == '1' && mid) {
+      DRIN_TRY(planes ? (x3::launch_sk<128, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done))
+                      : (x3::launch_sk<128, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done)));
+    } else if (mode[0] == '2' && (mid || big)) {
+      DRIN_TRY(planes ? (x3::launch_sk<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done))
+                      : (x3::launch_sk<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done)));
+    }
+    if (done) return DRIN_OK;
+    if ((mode[0] == 'a' || mode[0] == 't') && mid && planes) {
+      int best = 0;
+      int64_t cost = 0;
+      for (int cand : {192, 160, 128, 96}) {
+        const int64_t tiles = cdiv(M, cand) * cdiv(N, 256), rounds = cdiv(tiles, x3::kCUs);
+        const bool filled = mode[0] == 't' || 4 * tiles >= 3 * rounds * (int64_t)x3::kCUs;
+        if (filled && (best == 0 || rounds * cand <= cost)) cost = rounds * cand, best = cand;
+      }
+      if (mode[0] == 't' && mode[1] != 0) best = atoi(mode + 1);   // probe: a fixed BM
+      switch (best) {
+        case 96: return x3::launch<96, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+        case 128: return x3::launch<128, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+        case 160: return x3::launch<160, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+        case 192: return x3::launch<192, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+        default: break;   // no tall tile fills its rounds: the 64 x 128 tiles below
+      }
+    }
+  }
   if (big)
     return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
                   : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);

@@ -43,7 +43,8 @@ from drin_amd.config import DrinConfig, wikimel_config  # noqa: E402
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
-TRAFFIC_FILE = os.path.join("profiles", "r2_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r3_hbm_traffic.json")
+MFMA_PMC_FILE = os.path.join("profiles", "r3_mfma_pmc.json")
 FEAT_SLOTS = (0, 4, 5, 7, 9, 10)  # the six feature tensors of the 14-sequence
 
 
@@ -245,6 +246,21 @@ def measured_traffic(kernel_prefix, section, matches):
     return None
 
 
+def measured_mfma_busy(section, family):
+    """Fraction of the kernel family's SIMD-cycles with a matrix instruction executing, from the committed SQ counter pass of
+    this configuration (tools/pmc_mfma.sh -> tools/collect_mfma_pmc.py: SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)) -
+    replayed, NOT re-measured in this run; None when there is no pass for the configuration."""
+    path = os.path.join(REPO, MFMA_PMC_FILE)
+    if not (section and os.path.exists(path)):
+        return None, None
+    try:
+        sec = json.load(open(path))["sections"][section]
+        v = sec["families"][family]["mfma_busy"]
+        return v, (f"{MFMA_PMC_FILE} [{section}].families.{family}: rocprofv3 --pmc SQ pass of `{sec['command']}`, replayed - not re-measured in this run")
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
 KERNEL_NAMES = {"stream": "k_entity_stream", "gemm_planes": "k_gemm_x3_planes", "gemm_x3": "k_gemm_bf16x3", "gemm": "k_gemm_f32",
                 "gcn": "row kernels (k_pair_layer1, k_pair_final, ...)", "pool": "pooling kernels", "edge": "edge kernels"}
 
@@ -301,6 +317,10 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
             passes = 1 if precision == "bf16" else 3
             roof["executed_bf16_tflops"] = passes * achieved
             roof["executed_frac"] = passes * achieved / peak
+            section = None
+            if precision == "bf16x3" and features == "f32" and fused and not cached:
+                section = {("wikimel", 4096): "wikimel_b4096", ("wikidiverse", 16384): "wikidiverse_b16384"}.get((workload, B))
+            roof["mfma_busy"], roof["mfma_busy_source"] = measured_mfma_busy(section, {"gemm_x3": "k_gemm_bf16x3", "gemm_planes": "k_gemm_x3_planes"}.get(dom, ""))
     return roof, ab, stream_bytes_pair, flops_pair
 
 
@@ -588,6 +608,8 @@ def train_roofline(cfg, B, N, prof, steps, precision):
            "flops_per_pair": fwd + bwd}
     if x3:
         out["executed_bf16_tflops"], out["executed_frac"] = 3 * tf, 3 * tf / peak
+        section = {64: "train_b64", 512: "train_b512"}.get(B) if (precision == "bf16x3" and cfg.token_level_entities) else None
+        out["mfma_busy"], out["mfma_busy_source"] = measured_mfma_busy(section, "split_bf16_family")
     return out
 
 

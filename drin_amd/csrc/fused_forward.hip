@@ -258,7 +258,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   // The image rows are read in place by their contraction (fp32, split on the fly): writing 8 KB/pair of
   // planes from the stream kernel costs it more (measured twice on one box: +1.0 ms at B = 4096) than the LDS-DMA
   // kernel gains on that GEMM (-0.35 ms).  Only the table form, which has to gather the rows anyway, writes them.
-  const bool xi_planes = planes && indexed;
+  static const char* xi_env = getenv("DRIN_XI_PLANES");   // probe switch: image rows as planes in the gathered form too
+  const bool xi_planes = planes && (indexed || (xi_env != nullptr && xi_env[0] == '1' && cfg->feature_dtype == DRIN_FEAT_F32));
   if (b->entity_text_cls) {
     set_error("drin_forward_prepared: entity_text_cls (text pooled ahead of time) is a form of the training entry points");
     return DRIN_E_UNSUPPORTED;

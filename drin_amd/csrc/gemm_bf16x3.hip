@@ -678,6 +678,12 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
       }
     }
   }
+  {  // big products on weight planes: the four-phase pipeline of gemm_x3_planes.hip (DRIN_P4=0: the kernel below, for A/Bs)
+    static const char* p4 = getenv("DRIN_P4");
+    if (big && planes && !one_pass && a_index == nullptr && !(p4 != nullptr && p4[0] == '0') && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) &&
+        (bias == nullptr || aligned16(bias)))
+      return launch_gemm_nt_bf16x3_p4(x, ldx, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
+  }
   if (big)
     return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
                   : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);

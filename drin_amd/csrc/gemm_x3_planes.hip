@@ -9,6 +9,8 @@
 // LDS buffers of four planes (128 KiB).  LDS rows are 64 B; LDS-DMA writes linearly (wave base + lane *
 // 16), so the XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied to the
 // SOURCE address: the lane that fills physical chunk c of row r fetches logical chunk c ^ f(r).
+#include <stdlib.h>
+
 #include "device_utils.h"
 #include "internal.h"
 
@@ -280,6 +282,468 @@ __global__ void __launch_bounds__(THREADS, 2)
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same product on a finer pipeline ("four phases per K-block", after the 8-phase bf16 template of
+// cdna_hip_programming.md 5).  What it changes against k_gemm_x3_planes:
+//  * the K-block's 64 KiB arrive as FOUR units of 16 KiB - (operand, 128-row half), both planes - one unit issued per
+//    phase, and the LDS-DMA stays in flight ACROSS the barriers: a counted s_waitcnt vmcnt(4) (two units outstanding) and
+//    raw s_barrier instead of __syncthreads(), whose vmcnt(0) drains every DMA at every K-block;
+//  * a wave's 128 x 64 output is two 64-row strips x two 32-column strips, one from each half, so that output quadrant
+//    (qi, qj) needs exactly unit A[qi] and unit B[qj]; the quadrants run 00, 01, 11, 10 - each shares an operand with its
+//    predecessor, whose fragments stay in registers (12 + 4 + 8 + 4 fragment reads per K-block);
+//  * a phase is { fragment reads, DMA issue, counted wait | barrier | 24 MFMAs | barrier } and the two halves of the
+//    workgroup (waves 0 - 3, 4 - 7: one wave of each per SIMD) run ONE BARRIER APART, so that on every SIMD one wave
+//    issues MFMAs while the other reads LDS - no second fragment set, 176 accumulator + fragment registers.
+//   unit      issued in phase   first read in phase        (g = 4 t + q counts phases; the unit belongs to K-block t + 1)
+//   A0(t+1)   4 t               4 t + 4
+//   B0(t+1)   4 t + 1           4 t + 4 (and 4 t + 7)
+//   B1(t+1)   4 t + 2           4 t + 5
+//   A1(t+1)   4 t + 3           4 t + 6
+// Before the first barrier of phase g every wave has waited for all but its two newest units (vmcnt(4): two DMA
+// instructions per unit per wave), which retires what phase g + 1 reads first; the delayed half waits one barrier later, and
+// the second barrier of the phase still lies between its wait and anybody's read.  A slot is re-filled two or more phases
+// after its last read, whose lgkmcnt(0) precedes the MFMAs of that phase.
+namespace p4 {
+
+constexpr int UNIT_BYTES = 2 * 128 * 64;       // two planes x 128 rows x 64 B
+constexpr int BUF = 4 * UNIT_BYTES;            // A0, A1, B0, B1
+constexpr int LDS = 2 * BUF;
+
+struct Src {
+  const char* ptr[4][2];   // [unit][piece]: this lane's 16 source bytes of K-block 0 (rows past the end clamped)
+};
+
+// unit u: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  Wave w fills pieces 2 w and 2 w + 1 of the unit's 16 (plane w >> 2, rows 32 (w & 3) ..)
+template <int U>
+__device__ __forceinline__ void issue_unit(const Src& s, char* buf, int kb) {
+  const int wave = threadIdx.x >> 6;
+  char* dst = buf + U * UNIT_BYTES + (wave >> 2) * (128 * 64) + (wave & 3) * 2048;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_global_load_lds((gptr_t)(s.ptr[U][i] + (int64_t)kb * (BK * 2)), (lptr_t)(dst + i * 1024), 16, 0, 0);
+}
+
+}  // namespace p4
+
+__global__ void __launch_bounds__(THREADS, 2)
+    k_gemm_x3_planes_p4(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
+                        const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
+                        const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, int nx,
+                        unsigned full, int ksplit, float* __restrict__ tail) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tx, kpart;
+  int64_t ty;
+  unsigned tail_slot;
+  tile_of_block(tx, ty, nx, full, ksplit, kpart, tail_slot);   // ids >= full: K-slices of the tail tiles (as in k_gemm_x3_planes)
+  const int64_t m0 = ty * BM;
+  const int n0 = tx * BN;
+  int64_t k0 = 0;
+  if (blockIdx.x >= full) {
+    K /= ksplit;
+    k0 = (int64_t)kpart * K;
+  }
+  const int nkb = K / BK;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, c = lane >> 4;
+
+  p4::Src src;
+  {
+    const int f = (0x78 >> (((lane >> 4) & 3) << 1)) & 3;
+    const int chunk = (lane & 3) ^ f;
+    const bool lo = wave >= 4;
+    const char* ap = reinterpret_cast<const char*>((lo ? a_lo : a_hi) + k0) + chunk * 16;
+    const char* bp = reinterpret_cast<const char*>((lo ? b_lo : b_hi) + k0) + chunk * 16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool is_b = u >= 2;
+        int64_t g = (is_b ? (int64_t)n0 : m0) + (u & 1) * 128 + (wave & 3) * 32 + 16 * i + (lane >> 2);
+        const int64_t lim = is_b ? (int64_t)N : M;
+        g = g < lim ? g : lim - 1;
+        src.ptr[u][i] = (is_b ? bp : ap) + g * (is_b ? ldb : lda) * 2;
+      }
+  }
+
+  f32x4 acc[2][2][4][2];   // [row half][column half][row tile][column tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[a][b][i][j][v] = 0.f;
+
+  bf16x8 ah[4], al[4], bh[2], bl[2];
+  auto read_a = [&](const char* buf, int half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* p = buf + half * p4::UNIT_BYTES + swz16(wm * 64 + i * 16 + r, c);
+      ah[i] = *reinterpret_cast<const bf16x8*>(p);
+      al[i] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
+    }
+  };
+  auto read_b = [&](const char* buf, int half) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* p = buf + (2 + half) * p4::UNIT_BYTES + swz16(wn * 32 + j * 16 + r, c);
+      bh[j] = *reinterpret_cast<const bf16x8*>(p);
+      bl[j] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
+    }
+  };
+  auto mma = [&](f32x4 (&cc)[4][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the counted wait that precedes the first barrier of a phase
+  auto wait_units = [&](bool issued) {
+    if (issued) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
+  // prologue: K-block 0 whole, landed and published to everybody
+  p4::issue_unit<0>(src, smem, 0);
+  p4::issue_unit<2>(src, smem, 0);
+  p4::issue_unit<3>(src, smem, 0);
+  p4::issue_unit<1>(src, smem, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+  if (wm == 1) barrier();   // the second half of the workgroup runs one barrier behind the first from here on
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const char* buf = smem + (kb & 1) * p4::BUF;
+    char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
+    const bool next = kb + 1 < nkb;
+    // phase 0: quadrant 00
+    read_a(buf, 0);
+    read_b(buf, 0);
+    if (next) p4::issue_unit<0>(src, nbuf, kb + 1);
+    wait_units(next);
+    barrier();
+    mma(acc[0][0]);
+    barrier();
+    // phase 1: quadrant 01 (A0 fragments stay)
+    read_b(buf, 1);
+    if (next) p4::issue_unit<2>(src, nbuf, kb + 1);
+    wait_units(next);
+    barrier();
+    mma(acc[0][1]);
+    barrier();
+    // phase 2: quadrant 11 (B1 fragments stay)
+    read_a(buf, 1);
+    if (next) p4::issue_unit<3>(src, nbuf, kb + 1);
+    wait_units(next);
+    barrier();
+    mma(acc[1][1]);
+    barrier();
+    // phase 3: quadrant 10 (A1 fragments stay)
+    read_b(buf, 0);
+    if (next) p4::issue_unit<1>(src, nbuf, kb + 1);
+    wait_units(next);
+    barrier();
+    mma(acc[1][0]);
+    barrier();
+  }
+  if (wm == 0) barrier();   // pairs with the delayed half's last barrier
+
+  if (kpart > 0) {  // raw accumulators of a tail slice: [slot][256][256], folded into C by the tail-add launch
+    float* part = tail + (size_t)tail_slot * (BM * BN);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            st4(part + (a * 128 + wm * 64 + i * 16 + r) * BN + b * 128 + wn * 32 + j * 16 + c * 4,
+                make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]));
+    return;
+  }
+  float4 bv[2][2];   // the bias of this lane's four column groups, fetched once (a load per store would serialise the stores)
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + b * 128 + wn * 32 + j * 16 + c * 4;
+      bv[b][j] = (bias != nullptr && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = m0 + a * 128 + wm * 64 + i * 16 + r;
+      if (row >= M) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + b * 128 + wn * 32 + j * 16 + c * 4;
+          if (col >= N) continue;   // N % 4 == 0 (checked by the launcher)
+          st4(C + row * ldc + col, make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]) + bv[b][j]);
+        }
+    }
+}
+
+
+// The four-phase pipeline for an fp32 A operand (the image rows of the folded path, the activations of the big training
+// products): the B units stream by LDS-DMA as above; an A unit (128 rows x 32 k of fp32 = 16 KiB) is fetched into registers
+// - two 16-byte loads per thread, issued where the DMA of that unit would be, by inline asm so that the only wait is
+// the counted one - and, in the phase whose wait retires it, split into bf16 (hi, lo) and written to the unit's two planes
+// (once per workgroup: 24 vector instructions per thread per unit, in the half of the phase in which the other wave group
+// holds the matrix pipes).  Two loads per unit per wave like two DMA instructions: the vmcnt arithmetic is unchanged.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_store(f32x4v v, char* hi_plane, int off) {
+  bf16x4p h, l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = (__bf16)v[k];
+    l[k] = (__bf16)(v[k] - (float)h[k]);
+  }
+  *reinterpret_cast<bf16x4p*>(hi_plane + off) = h;
+  *reinterpret_cast<bf16x4p*>(hi_plane + 128 * 64 + off) = l;
+}
+
+__global__ void __launch_bounds__(THREADS, 2)
+    k_gemm_bf16x3_p4(const float* __restrict__ A, int64_t lda, const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo,
+                     int64_t ldb, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+                     int accumulate, int nx, unsigned full, int ksplit, float* __restrict__ tail) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tx, kpart;
+  int64_t ty;
+  unsigned tail_slot;
+  tile_of_block(tx, ty, nx, full, ksplit, kpart, tail_slot);
+  const int64_t m0 = ty * BM;
+  const int n0 = tx * BN;
+  if (blockIdx.x >= full) {  // a K-slice of a tail tile
+    K /= ksplit;
+    const int64_t k0 = (int64_t)kpart * K;
+    A += k0;
+    b_hi += k0;
+    b_lo += k0;
+  }
+  const int nkb = K / BK;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, c = lane >> 4;
+
+  // B: DMA sources as in k_gemm_x3_planes_p4 (units 2, 3); A: this thread's float4 #(tid & 7) of rows (tid >> 3) + 64 i of a half
+  p4::Src src;
+  const float* arow[2][2];   // [half][i]
+  int a_off[2];              // LDS offset of the 8-byte piece inside an A unit's hi plane
+  {
+    const int f = (0x78 >> (((lane >> 4) & 3) << 1)) & 3;
+    const int chunk = (lane & 3) ^ f;
+    const char* bp = reinterpret_cast<const char*>(wave >= 4 ? b_lo : b_hi) + chunk * 16;
+#pragma unroll
+    for (int u = 2; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int64_t g = (int64_t)n0 + (u & 1) * 128 + (wave & 3) * 32 + 16 * i + (lane >> 2);
+        g = g < N ? g : (int64_t)N - 1;
+        src.ptr[u][i] = bp + g * ldb * 2;
+      }
+    src.ptr[0][0] = src.ptr[0][1] = src.ptr[1][0] = src.ptr[1][1] = nullptr;
+    const int c4 = threadIdx.x & 7, row = threadIdx.x >> 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int64_t g = m0 + h * 128 + row + 64 * i;
+        g = g < M ? g : M - 1;
+        arow[h][i] = A + g * lda + c4 * 4;
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_off[i] = swz16(row + 64 * i, c4 >> 1) + ((c4 & 1) << 3);
+  }
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[a][b][i][j][v] = 0.f;
+
+  bf16x8 ah[4], al[4], bh[2], bl[2];
+  auto read_a = [&](const char* buf, int half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* p = buf + half * p4::UNIT_BYTES + swz16(wm * 64 + i * 16 + r, c);
+      ah[i] = *reinterpret_cast<const bf16x8*>(p);
+      al[i] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
+    }
+  };
+  auto read_b = [&](const char* buf, int half) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* p = buf + (2 + half) * p4::UNIT_BYTES + swz16(wn * 32 + j * 16 + r, c);
+      bh[j] = *reinterpret_cast<const bf16x8*>(p);
+      bl[j] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
+    }
+  };
+  auto mma = [&](f32x4 (&cc)[4][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // A unit `half` of K-block kb into registers: two loads the compiler does not track (the counted waits below are the only ones)
+  auto load_a = [&](int half, int kb, f32x4v& v0, f32x4v& v1) {
+    const float* p0 = arow[half][0] + (int64_t)kb * BK;
+    const float* p1 = arow[half][1] + (int64_t)kb * BK;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v1) : "v"(p1) : "memory");
+  };
+  // The counted wait of a phase: every unit but this wave's two newest has landed.  The registers of the A unit it retires
+  // are named by an EMPTY statement behind it: whatever copies the compiler wants for their consumers come after the wait.
+  auto wait4 = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
+  auto landed = [&](f32x4v& v0, f32x4v& v1) { asm volatile("" : "+v"(v0), "+v"(v1) : : "memory"); };
+  auto store_a = [&](char* buf, int half, f32x4v v0, f32x4v v1) {
+    split_store(v0, buf + half * p4::UNIT_BYTES, a_off[0]);
+    split_store(v1, buf + half * p4::UNIT_BYTES, a_off[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the writes are in LDS before the barrier that publishes them
+  };
+
+  f32x4v a0v0, a0v1, a1v0, a1v1;   // the A0 / A1 unit in flight
+  // prologue: K-block 0 - A0 converted and published, A1 landed in registers (phase 1 converts it), B0 and B1 by DMA
+  load_a(0, 0, a0v0, a0v1);
+  p4::issue_unit<2>(src, smem, 0);
+  p4::issue_unit<3>(src, smem, 0);
+  load_a(1, 0, a1v0, a1v1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  landed(a0v0, a0v1);
+  landed(a1v0, a1v1);
+  store_a(smem, 0, a0v0, a0v1);
+  barrier();
+  if (wm == 1) barrier();
+
+  // Every K-block issues the units of block min(kb + 1, last): the last one fetches itself again into the idle buffer, so
+  // that all blocks are the same straight-line code with the same counted waits (one block's worth of L2 reads per tile
+  // more: 4 % at K = 768).
+  for (int kb = 0; kb < nkb; ++kb) {
+    char* buf = smem + (kb & 1) * p4::BUF;
+    char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
+    const int kn = kb + 1 < nkb ? kb + 1 : kb;
+    // phase 0: quadrant 00; A0(kn) leaves for the registers
+    read_a(buf, 0);
+    read_b(buf, 0);
+    load_a(0, kn, a0v0, a0v1);
+    wait4();
+    barrier();
+    mma(acc[0][0]);
+    barrier();
+    // phase 1: quadrant 01; B0(kn) leaves; A1(kb) has landed: split and publish it
+    read_b(buf, 1);
+    p4::issue_unit<2>(src, nbuf, kn);
+    wait4();
+    landed(a1v0, a1v1);
+    store_a(buf, 1, a1v0, a1v1);
+    barrier();
+    mma(acc[0][1]);
+    barrier();
+    // phase 2: quadrant 11; B1(kn) leaves
+    read_a(buf, 1);
+    p4::issue_unit<3>(src, nbuf, kn);
+    wait4();
+    barrier();
+    mma(acc[1][1]);
+    barrier();
+    // phase 3: quadrant 10; A1(kn) leaves; A0(kn) has landed: split and publish it
+    read_b(buf, 0);
+    load_a(1, kn, a1v0, a1v1);
+    wait4();
+    landed(a0v0, a0v1);
+    store_a(nbuf, 0, a0v0, a0v1);
+    barrier();
+    mma(acc[1][0]);
+    barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant units of the last block
+  if (wm == 0) barrier();
+
+  if (kpart > 0) {
+    float* part = tail + (size_t)tail_slot * (BM * BN);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            st4(part + (a * 128 + wm * 64 + i * 16 + r) * BN + b * 128 + wn * 32 + j * 16 + c * 4,
+                make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]));
+    return;
+  }
+  float4 bv[2][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + b * 128 + wn * 32 + j * 16 + c * 4;
+      bv[b][j] = (bias != nullptr && col < N) ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = m0 + a * 128 + wm * 64 + i * 16 + r;
+      if (row >= M) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + b * 128 + wn * 32 + j * 16 + c * 4;
+          if (col >= N) continue;
+          float* dst = C + row * ldc + col;
+          float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]) + bv[b][j];
+          if (accumulate) o = o + ld4(dst);
+          st4(dst, o);
+        }
+    }
+}
+
 // fp32 -> (hi, lo) bf16 planes, 4 values per thread
 __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ x, __bf16* __restrict__ hi,
                                                       __bf16* __restrict__ lo, int64_t n4) {
@@ -395,6 +859,50 @@ int launch_transpose_split_batch(const SplitBatch& b, int rows, int cols, hipStr
   return DRIN_OK;
 }
 
+// The partly filled last round of 256 x 256 tiles as K-slices over the idle CUs (both split-bf16 NT kernel families)
+static void tail_split_256(int64_t tiles, int nkb, const float* tail, size_t tail_floats, unsigned* full, int* ksplit) {
+  *full = (unsigned)tiles;
+  *ksplit = 1;
+  if (tail == nullptr || !aligned16(tail) || tiles > 16 * 256) return;
+  const unsigned frac = (unsigned)(tiles % 256);
+  for (int s = 4; s >= 2 && frac > 0; --s)
+    if ((unsigned)s * frac <= 256 && nkb % s == 0 && nkb / s >= 4 && (size_t)frac * (s - 1) * (x3p::BM * x3p::BN) <= tail_floats) {
+      *ksplit = s;
+      *full = (unsigned)tiles - frac;
+      return;
+    }
+}
+
+// The four-phase pipeline on an fp32 A operand against pre-split weight planes (256 x 256 tiles; DRIN_E_UNSUPPORTED outside
+// its contract: the caller keeps its other kernel).  tail: optional scratch for the tail split, as launch_gemm_nt_bf16x3.
+int launch_gemm_nt_bf16x3_p4(const float* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw, const float* bias,
+                             float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate, float* tail,
+                             size_t tail_floats) {
+  if (M <= 0 || N <= 0) return DRIN_OK;
+  if (K <= 0 || (K % x3p::BK) || (ldx % 4) || (ldw % 8) || (N % 4) || (ldy % 4) || !aligned16(x) || !aligned16(w_hi) || !aligned16(w_lo) ||
+      !aligned16(y) || (bias != nullptr && !aligned16(bias))) {
+    set_error("gemm_bf16x3_p4: shape / alignment outside the kernel's contract");
+    return DRIN_E_UNSUPPORTED;
+  }
+  const int nx = (int)cdiv(N, x3p::BN);
+  const int64_t tiles = cdiv(M, x3p::BM) * nx;
+  if (tiles > ((int64_t)1 << 28)) return DRIN_E_UNSUPPORTED;
+  unsigned full;
+  int ksplit;
+  tail_split_256(tiles, K / x3p::BK, tail, tail_floats, &full, &ksplit);
+  const unsigned items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
+  static DynLdsOptIn opt;
+  DRIN_TRY(ensure_dynamic_lds(opt, reinterpret_cast<const void*>(x3p::k_gemm_bf16x3_p4), x3p::p4::LDS, "hipFuncSetAttribute(gemm_bf16x3_p4)"));
+  {
+    KernelTimer timer(DRIN_KC_GEMM_X3, st);
+    hipLaunchKernelGGL(x3p::k_gemm_bf16x3_p4, dim3(items), dim3(x3p::THREADS), x3p::p4::LDS, st, x, ldx, (const __bf16*)w_hi,
+                       (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, nx, full, ksplit, tail);
+    DRIN_CHECK_LAUNCH("k_gemm_bf16x3_p4");
+  }
+  if (ksplit > 1) DRIN_TRY(launch_tail_add_256(tail, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
+  return DRIN_OK;
+}
+
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
                           hipStream_t st, float* splitk, size_t splitk_floats) {
@@ -448,6 +956,23 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
         full = (unsigned)tiles - frac;
         break;
       }
+  }
+  {  // the full split product (both lo planes) on whole tiles + tail slices: the four-phase pipeline (DRIN_P4=0: the previous kernel, for A/Bs)
+    static const char* p4 = getenv("DRIN_P4");
+    if (!(p4 != nullptr && p4[0] == '0') && a_lo_plane && b_lo_plane && splits == 1 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) &&
+        (bias == nullptr || aligned16(bias))) {
+      static DynLdsOptIn opt;
+      DRIN_TRY(ensure_dynamic_lds(opt, reinterpret_cast<const void*>(x3p::k_gemm_x3_planes_p4), x3p::p4::LDS, "hipFuncSetAttribute(gemm_x3_planes_p4)"));
+      const unsigned p4_items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
+      {
+        KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
+        hipLaunchKernelGGL(x3p::k_gemm_x3_planes_p4, dim3(p4_items), dim3(x3p::THREADS), x3p::p4::LDS, st, (const __bf16*)a_hi,
+                           (const __bf16*)a_lo, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K, nx, full, ksplit, splitk);
+        DRIN_CHECK_LAUNCH("k_gemm_x3_planes_p4");
+      }
+      if (ksplit > 1) DRIN_TRY(launch_tail_add_256(splitk, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
+      return DRIN_OK;
+    }
   }
   const unsigned items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
   dim3 grid(items, 1, (unsigned)splits);

@@ -181,6 +181,10 @@ int64_t tn_group_target(const TnGroup& g, size_t scratch_floats);
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
                           hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
+// the four-phase pipeline (gemm_x3_planes.hip) on an fp32 x against pre-split weight planes: whole 256 x 256 tiles
+int launch_gemm_nt_bf16x3_p4(const float* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw, const float* bias,
+                             float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate, float* tail = nullptr,
+                             size_t tail_floats = 0);
 // y[tail tile] += its ksplit - 1 partial 256 x 256 tiles, in order (tail split of the two split-bf16 NT kernels)
 int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int N, unsigned col_tiles, unsigned full,
                         unsigned tail_tiles, int ksplit, hipStream_t st);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates the judged evidence under gpurun_out/round/ (copy the summaries into profiles/ afterwards):
 #   kernel-trace stats + the bench line of the same command (default workload), the full default bench line (all legs),
-#   PMC traffic passes (their own runs), cached-table and training-step kernel stats.
+#   PMC traffic passes (their own runs), cached-table and training-step kernel stats; the SQ / MFMA counter passes are
+#   tools/pmc_mfma.sh (separate call: it writes gpurun_out/pmc_mfma/).
 # rocprofv3: program directly after `--`, counters in their own passes.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

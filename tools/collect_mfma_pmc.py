@@ -69,7 +69,7 @@ def reduce_dir(d):
         out[k] = e
     fam = {}
     for name in ("k_gemm_bf16x3", "k_gemm_x3_planes", "k_gemm_tn_bf16x3"):
-        ks = [k for k in out if k.startswith(name + "<") or k == name]
+        ks = [k for k in out if k.startswith(name)]   # every form of the family: <tile shapes>, _p4 (four-phase pipeline), _sk
         b = sum(out[k]["sum"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k in ks)
         s = sum(out[k]["sum"].get("SQ_BUSY_CYCLES", 0.0) for k in ks)
         if s:

@@ -25,7 +25,12 @@ python3 tools/collect_pmc.py $O/pmc_fetch_tab $O/pmc_write_tab $O/hbm_traffic.js
 echo "[profile_round] table cache done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 > $O/train64_bench_under_rocprof.json 2> $O/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train512 -- python3 bench.py --mode train --batch 512 --steps 20 --warmup 30 > $O/train512_bench_under_rocprof.json 2> $O/train512.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_rccl -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 --force-collective > $O/train64_rccl_world1_bench_under_rocprof.json 2> $O/train_rccl.err
 echo "[profile_round] training done"
 python3 bench.py --workload table --entity-cache --mentions 1000000 --chunk 4096 > $O/config5_1M_stream.json 2> $O/config5.err
 echo "[profile_round] config 5 full stream done"
+for i in 1 2; do python3 bench.py > $O/wm_bench_$i.json 2>> $O/wm_bench.err; done
+echo "[profile_round] two more default lines done"
+bash tools/pmc_mfma.sh r3 > $O/pmc_mfma.log 2>&1 && cp gpurun_out/pmc_mfma/r3_mfma_pmc.json gpurun_out/pmc_mfma/summary.txt $O/
+echo "[profile_round] SQ / MFMA counter passes done"
 ls $O

@@ -306,6 +306,22 @@ __global__ void __launch_bounds__(THREADS, 2)
 // after its last read, whose lgkmcnt(0) precedes the MFMAs of that phase.
 namespace p4 {
 
+#ifndef DRIN_P4_TERM_MAJOR
+#define DRIN_P4_TERM_MAJOR 1
+#endif
+constexpr bool kTermMajor = DRIN_P4_TERM_MAJOR != 0;
+#ifndef DRIN_P4_DMA_PLACE
+#define DRIN_P4_DMA_PLACE 0
+#endif
+constexpr int kDmaPlace = DRIN_P4_DMA_PLACE;
+// the counted wait before a phase's first barrier (two DMA / load instructions per unit per wave)
+__device__ __forceinline__ void wait_units() {
+  if (kDmaPlace == 0) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
+}
 constexpr int UNIT_BYTES = 2 * 128 * 64;       // two planes x 128 rows x 64 B
 constexpr int BUF = 4 * UNIT_BYTES;            // A0, A1, B0, B1
 constexpr int LDS = 2 * BUF;
@@ -396,16 +412,34 @@ __global__ void __launch_bounds__(THREADS, 2)
       bl[j] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
     }
   };
-  auto mma = [&](f32x4 (&cc)[4][2]) {
+  auto mma = [&](f32x4 (&cc)[4][2], auto&& mid) {
     __builtin_amdgcn_s_setprio(1);
+    // term-major over the quadrant's eight tiles: an accumulator's next MFMA is eight issues away (same order of the three
+    // terms per accumulator as everywhere: hi lo, lo hi, hi hi - same bits)
+    if (p4::kTermMajor) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+      mid();
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -414,15 +448,6 @@ __global__ void __launch_bounds__(THREADS, 2)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  // the counted wait that precedes the first barrier of a phase
-  auto wait_units = [&](bool issued) {
-    if (issued) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  };
-
   // prologue: K-block 0 whole, landed and published to everybody
   p4::issue_unit<0>(src, smem, 0);
   p4::issue_unit<2>(src, smem, 0);
@@ -432,40 +457,38 @@ __global__ void __launch_bounds__(THREADS, 2)
   barrier();
   if (wm == 1) barrier();   // the second half of the workgroup runs one barrier behind the first from here on
 
+  // Every K-block issues the units of block min(kb + 1, last): the last one fetches itself again into the idle buffer, so that
+  // all blocks are the same straight-line code with the same counted wait (one block's worth of L2 reads per tile more).
+  // Where in the phase the unit's two DMA instructions go (p4::kDmaPlace): an LDS-DMA costs its wave 100-185 cycles of issue
+  // among LDS reads and ~60 among MFMAs (MI355X_MICROARCH.md), and the reading half of a phase must not outlast the other wave
+  // group's 24 MFMAs.  0: with the fragment reads; 1: behind the first barrier, before the MFMAs; 2: between the first and the
+  // second third of the MFMAs.  The unit a phase's wait must retire was issued two phases earlier: with the phase's own issue
+  // in front of the wait (0) two newer units are outstanding - vmcnt(4) - with it behind the barrier (1, 2) one - vmcnt(2).
+  auto none = [] {};
+#define DRIN_P4_PHASE(READS, UNIT, ACC)                                  \
+  {                                                                      \
+    READS;                                                               \
+    if (p4::kDmaPlace == 0) p4::issue_unit<UNIT>(src, nbuf, kn);         \
+    p4::wait_units();                                                    \
+    barrier();                                                           \
+    if (p4::kDmaPlace == 1) p4::issue_unit<UNIT>(src, nbuf, kn);         \
+    if (p4::kDmaPlace == 2)                                              \
+      mma(ACC, [&] { p4::issue_unit<UNIT>(src, nbuf, kn); });            \
+    else                                                                 \
+      mma(ACC, none);                                                    \
+    barrier();                                                           \
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     const char* buf = smem + (kb & 1) * p4::BUF;
     char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
-    const bool next = kb + 1 < nkb;
-    // phase 0: quadrant 00
-    read_a(buf, 0);
-    read_b(buf, 0);
-    if (next) p4::issue_unit<0>(src, nbuf, kb + 1);
-    wait_units(next);
-    barrier();
-    mma(acc[0][0]);
-    barrier();
-    // phase 1: quadrant 01 (A0 fragments stay)
-    read_b(buf, 1);
-    if (next) p4::issue_unit<2>(src, nbuf, kb + 1);
-    wait_units(next);
-    barrier();
-    mma(acc[0][1]);
-    barrier();
-    // phase 2: quadrant 11 (B1 fragments stay)
-    read_a(buf, 1);
-    if (next) p4::issue_unit<3>(src, nbuf, kb + 1);
-    wait_units(next);
-    barrier();
-    mma(acc[1][1]);
-    barrier();
-    // phase 3: quadrant 10 (A1 fragments stay)
-    read_b(buf, 0);
-    if (next) p4::issue_unit<1>(src, nbuf, kb + 1);
-    wait_units(next);
-    barrier();
-    mma(acc[1][0]);
-    barrier();
+    const int kn = kb + 1 < nkb ? kb + 1 : kb;
+    DRIN_P4_PHASE((read_a(buf, 0), read_b(buf, 0)), 0, acc[0][0])   // quadrant 00
+    DRIN_P4_PHASE(read_b(buf, 1), 2, acc[0][1])                      // quadrant 01 (A0 fragments stay)
+    DRIN_P4_PHASE(read_a(buf, 1), 3, acc[1][1])                      // quadrant 11 (B1 fragments stay)
+    DRIN_P4_PHASE(read_b(buf, 0), 1, acc[1][0])                      // quadrant 10 (A1 fragments stay)
   }
+#undef DRIN_P4_PHASE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant units of the last block
   if (wm == 0) barrier();   // pairs with the delayed half's last barrier
 
   if (kpart > 0) {  // raw accumulators of a tail slice: [slot][256][256], folded into C by the tail-add launch
@@ -519,11 +542,19 @@ typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_store(f32x4v v, char* hi_plane, int off) {
   bf16x4p h, l;
+#ifdef DRIN_P4_ABLATE_CVT   // timing ablation only (plain-bf16 results): a third of the split arithmetic, the same two LDS writes
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = (__bf16)v[k];
+    l[k] = (__bf16)0.0f;
+  }
+#else
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     h[k] = (__bf16)v[k];
     l[k] = (__bf16)(v[k] - (float)h[k]);
   }
+#endif
   *reinterpret_cast<bf16x4p*>(hi_plane + off) = h;
   *reinterpret_cast<bf16x4p*>(hi_plane + 128 * 64 + off) = l;
 }
@@ -610,16 +641,34 @@ __global__ void __launch_bounds__(THREADS, 2)
       bl[j] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
     }
   };
-  auto mma = [&](f32x4 (&cc)[4][2]) {
+  auto mma = [&](f32x4 (&cc)[4][2], auto&& mid) {
     __builtin_amdgcn_s_setprio(1);
+    // term-major over the quadrant's eight tiles: an accumulator's next MFMA is eight issues away (same order of the three
+    // terms per accumulator as everywhere: hi lo, lo hi, hi hi - same bits)
+    if (p4::kTermMajor) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+      mid();
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], cc[i][j], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -637,7 +686,7 @@ __global__ void __launch_bounds__(THREADS, 2)
   };
   // The counted wait of a phase: every unit but this wave's two newest has landed.  The registers of the A unit it retires
   // are named by an EMPTY statement behind it: whatever copies the compiler wants for their consumers come after the wait.
-  auto wait4 = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
+  auto wait4 = [&]() { p4::wait_units(); };
   auto landed = [&](f32x4v& v0, f32x4v& v1) { asm volatile("" : "+v"(v0), "+v"(v1) : : "memory"); };
   auto store_a = [&](char* buf, int half, f32x4v v0, f32x4v v1) {
     split_store(v0, buf + half * p4::UNIT_BYTES, a_off[0]);
@@ -665,38 +714,44 @@ __global__ void __launch_bounds__(THREADS, 2)
     char* buf = smem + (kb & 1) * p4::BUF;
     char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
     const int kn = kb + 1 < nkb ? kb + 1 : kb;
+    auto none = [] {};
+    // (p4::kDmaPlace: where the phase's two loads / DMA instructions go - see k_gemm_x3_planes_p4)
     // phase 0: quadrant 00; A0(kn) leaves for the registers
     read_a(buf, 0);
     read_b(buf, 0);
-    load_a(0, kn, a0v0, a0v1);
+    if (p4::kDmaPlace == 0) load_a(0, kn, a0v0, a0v1);
     wait4();
     barrier();
-    mma(acc[0][0]);
+    if (p4::kDmaPlace == 1) load_a(0, kn, a0v0, a0v1);
+    if (p4::kDmaPlace == 2) mma(acc[0][0], [&] { load_a(0, kn, a0v0, a0v1); }); else mma(acc[0][0], none);
     barrier();
     // phase 1: quadrant 01; B0(kn) leaves; A1(kb) has landed: split and publish it
     read_b(buf, 1);
-    p4::issue_unit<2>(src, nbuf, kn);
+    if (p4::kDmaPlace == 0) p4::issue_unit<2>(src, nbuf, kn);
     wait4();
     landed(a1v0, a1v1);
     store_a(buf, 1, a1v0, a1v1);
     barrier();
-    mma(acc[0][1]);
+    if (p4::kDmaPlace == 1) p4::issue_unit<2>(src, nbuf, kn);
+    if (p4::kDmaPlace == 2) mma(acc[0][1], [&] { p4::issue_unit<2>(src, nbuf, kn); }); else mma(acc[0][1], none);
     barrier();
     // phase 2: quadrant 11; B1(kn) leaves
     read_a(buf, 1);
-    p4::issue_unit<3>(src, nbuf, kn);
+    if (p4::kDmaPlace == 0) p4::issue_unit<3>(src, nbuf, kn);
     wait4();
     barrier();
-    mma(acc[1][1]);
+    if (p4::kDmaPlace == 1) p4::issue_unit<3>(src, nbuf, kn);
+    if (p4::kDmaPlace == 2) mma(acc[1][1], [&] { p4::issue_unit<3>(src, nbuf, kn); }); else mma(acc[1][1], none);
     barrier();
     // phase 3: quadrant 10; A1(kn) leaves; A0(kn) has landed: split and publish it
     read_b(buf, 0);
-    load_a(1, kn, a1v0, a1v1);
+    if (p4::kDmaPlace == 0) load_a(1, kn, a1v0, a1v1);
     wait4();
     landed(a0v0, a0v1);
     store_a(nbuf, 0, a0v0, a0v1);
     barrier();
-    mma(acc[1][0]);
+    if (p4::kDmaPlace == 1) load_a(1, kn, a1v0, a1v1);
+    if (p4::kDmaPlace == 2) mma(acc[1][0], [&] { load_a(1, kn, a1v0, a1v1); }); else mma(acc[1][0], none);
     barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant units of the last block

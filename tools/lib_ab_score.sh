@@ -1,0 +1,25 @@
+#!/bin/bash
+# Same-box A/B of two builds of the library (current vs drin_amd/libdrin_hip_prev.so through DRIN_LIB_PATH) on the scoring side:
+# the planes GEMM alone, the headline (4 alternating runs), WikiDiverse, training at 512.
+O=gpurun_out/lib_ab_score
+rm -rf $O; mkdir -p $O
+PREV=$PWD/drin_amd/libdrin_hip_prev.so
+for i in 1 2; do
+  python tools/gemm_bench.py 103424 2>&1 | grep "^planes" | sed "s/^/new  /" >> $O/gemm.txt
+  DRIN_LIB_PATH=$PREV python tools/gemm_bench.py 103424 2>&1 | grep "^planes" | sed "s/^/prev /" >> $O/gemm.txt
+done
+cat $O/gemm.txt
+for i in 1 2 3 4; do
+  python bench.py --legs none --no-cpu-baseline --steps 10 > $O/score_new_$i.json 2>> $O/err.log
+  DRIN_LIB_PATH=$PREV python bench.py --legs none --no-cpu-baseline --steps 10 > $O/score_prev_$i.json 2>> $O/err.log
+done
+python bench.py --workload wikidiverse --legs none --no-cpu-baseline --steps 10 > $O/wd_new.json 2>> $O/err.log
+DRIN_LIB_PATH=$PREV python bench.py --workload wikidiverse --legs none --no-cpu-baseline --steps 10 > $O/wd_prev.json 2>> $O/err.log
+python bench.py --mode train --batch 512 > $O/t512_new.json 2>> $O/err.log
+DRIN_LIB_PATH=$PREV python bench.py --mode train --batch 512 > $O/t512_prev.json 2>> $O/err.log
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/lib_ab_score/*.json")):
+    l = json.load(open(f))
+    print(f.split("/")[-1], round(l["ms_per_step"], 3), round(l["value"] / 1e6, 2), {k: round(v, 3) for k, v in l["kernel_ms_per_step"].items() if v})
+PY

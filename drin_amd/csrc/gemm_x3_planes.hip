@@ -314,6 +314,10 @@ constexpr bool kTermMajor = DRIN_P4_TERM_MAJOR != 0;
 #define DRIN_P4_DMA_PLACE 0
 #endif
 constexpr int kDmaPlace = DRIN_P4_DMA_PLACE;
+#ifndef DRIN_P4_REBALANCE
+#define DRIN_P4_REBALANCE 1
+#endif
+constexpr bool kRebalance = DRIN_P4_REBALANCE != 0 && kDmaPlace == 0;   // the fp32-A kernel's phase schedule (see there)
 // the counted wait before a phase's first barrier (two DMA / load instructions per unit per wave)
 __device__ __forceinline__ void wait_units() {
   if (kDmaPlace == 0) {
@@ -710,6 +714,76 @@ __global__ void __launch_bounds__(THREADS, 2)
   // Every K-block issues the units of block min(kb + 1, last): the last one fetches itself again into the idle buffer, so
   // that all blocks are the same straight-line code with the same counted waits (one block's worth of L2 reads per tile
   // more: 4 % at K = 768).
+  if (p4::kRebalance) {
+    // The phases' reading halves evened out (an LDS-DMA costs its wave ~150 cycles of issue among LDS reads, a register load
+    // ~40, a unit's split ~250 with its two writes: with the DMA of B0 and the split of A1 in one phase that phase's reading
+    // half lasted ~600 cycles against the 384 of the other group's MFMAs).  DMA in the phases that read most fragments, loads
+    // and splits in the others; the B0 fragments stay in registers from quadrant 00 to quadrant 10, so B0's slot is free for
+    // the next block's DMA four phases after its only read:
+    //   phase 0 (00): read A0 B0 | DMA  B0(kn)        phase 1 (01): read B1 | load A0(kn) | split A1(kb)
+    //   phase 2 (11): read A1    | DMA  B1(kn)        phase 3 (10): -       | load A1(kn) | split A0(kn)
+    // Issue order B0', A0', B1', A1': vmcnt(4) before a phase's barrier retires the unit issued two phases earlier - A1(kb)
+    // for phase 1's split, A0(kn) for phase 3's, B0(kn) / B1(kn) one or more phases before their first read.
+    bf16x8 b0h[2], b0l[2];
+    auto mma_b = [&](f32x4 (&cc)[4][2], const bf16x8 (&fh)[2], const bf16x8 (&fl)[2]) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], al[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[j], ah[i], cc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], ah[i], cc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    for (int kb = 0; kb < nkb; ++kb) {
+      char* buf = smem + (kb & 1) * p4::BUF;
+      char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
+      const int kn = kb + 1 < nkb ? kb + 1 : kb;
+      // phase 0: quadrant 00
+      read_a(buf, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* p = buf + 2 * p4::UNIT_BYTES + swz16(wn * 32 + j * 16 + r, c);
+        b0h[j] = *reinterpret_cast<const bf16x8*>(p);
+        b0l[j] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
+      }
+      p4::issue_unit<2>(src, nbuf, kn);
+      wait4();
+      barrier();
+      mma_b(acc[0][0], b0h, b0l);
+      barrier();
+      // phase 1: quadrant 01
+      read_b(buf, 1);
+      load_a(0, kn, a0v0, a0v1);
+      wait4();
+      landed(a1v0, a1v1);
+      store_a(buf, 1, a1v0, a1v1);
+      barrier();
+      mma_b(acc[0][1], bh, bl);
+      barrier();
+      // phase 2: quadrant 11
+      read_a(buf, 1);
+      p4::issue_unit<3>(src, nbuf, kn);
+      wait4();
+      barrier();
+      mma_b(acc[1][1], bh, bl);
+      barrier();
+      // phase 3: quadrant 10
+      load_a(1, kn, a1v0, a1v1);
+      wait4();
+      landed(a0v0, a0v1);
+      store_a(nbuf, 0, a0v0, a0v1);
+      barrier();
+      mma_b(acc[1][0], b0h, b0l);
+      barrier();
+    }
+  } else
   for (int kb = 0; kb < nkb; ++kb) {
     char* buf = smem + (kb & 1) * p4::BUF;
     char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;

@@ -1,14 +1,11 @@
 #!/bin/bash
-# Same-box A/B of two builds of the library (current vs drin_amd/libdrin_hip_prev.so through DRIN_LIB_PATH) on the scoring side:
-# the planes GEMM alone, the headline (4 alternating runs), WikiDiverse, training at 512.
+# Same-box A/B of two builds of the library (current vs drin_amd/libdrin_hip_prev.so through DRIN_LIB_PATH): parity tests on the current
+# build, then the headline (4 alternating runs), WikiDiverse, training at 512.
 O=gpurun_out/lib_ab_score
 rm -rf $O; mkdir -p $O
 PREV=$PWD/drin_amd/libdrin_hip_prev.so
-for i in 1 2; do
-  python tools/gemm_bench.py 103424 2>&1 | grep "^planes" | sed "s/^/new  /" >> $O/gemm.txt
-  DRIN_LIB_PATH=$PREV python tools/gemm_bench.py 103424 2>&1 | grep "^planes" | sed "s/^/prev /" >> $O/gemm.txt
-done
-cat $O/gemm.txt
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q -m gpu > $O/tests.log 2>&1
+echo "tests (current build): $(tail -1 $O/tests.log)"
 for i in 1 2 3 4; do
   python bench.py --legs none --no-cpu-baseline --steps 10 > $O/score_new_$i.json 2>> $O/err.log
   DRIN_LIB_PATH=$PREV python bench.py --legs none --no-cpu-baseline --steps 10 > $O/score_prev_$i.json 2>> $O/err.log

@@ -134,6 +134,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: the DRIN HIP path has no fallback. Build it with `python -m drin_amd.build`."
         )
+    # The library works on PyTorch's device pointers and streams, so it must run on the HIP runtime PyTorch runs on: torch
+    # ships its own libamdhip64 and the library needs "libamdhip64.so.7" - whichever is in the process first serves both.
+    # Loaded before torch, the library pulls /opt/rocm's copy in, torch then brings its own, and the library's calls fail
+    # with "no ROCm-capable device is detected" (seen: __graft_entry__.build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a torch-free caller (examples/score_c_abi.cpp has no Python at all): the system runtime alone
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -462,3 +462,62 @@ def test_overlapped_allreduce_through_the_hip_model_is_bit_identical_on_two_rank
             assert torch.equal(r0[mode][k], r1[mode][k]), f"replicas diverged ({mode}): {k}"
     w0 = synth.make_state_dict(wikimel_config(max_entity_attr_token_len=8), 8)["gcn_layers.0.w_h.weight"]
     assert not torch.equal(r0["forward"]["gcn_layers.0.w_h.weight"], w0)
+
+
+def test_overlapped_step_with_a_split_training_batch(monkeypatch):
+    """`OverlappedStep` + a training batch above `MAX_CALL_MENTIONS` (several scoring calls per forward): the first call takes
+    the pending update's event, the others find none; two steps end with the serial loop's parameters bit for bit."""
+    from drin_amd.train import OverlappedStep
+    cfg = DrinConfig(**TINY)
+    monkeypatch.setattr(Model, "MAX_CALL_MENTIONS", 5)
+    finals = []
+    for overlapped in (False, True):
+        model, batch, _ = _setup(cfg, 12, seed=11)
+        opt = make_adam(model, 1e-2)
+        bucket = GradBucket(list(model.parameters()))
+        pipe = OverlappedStep(model, bucket, opt) if overlapped else None
+        for _step in range(3):
+            opt.zero_grad(set_to_none=True)
+            _loss(model, batch, cfg).backward()
+            if pipe is not None:
+                pipe.run()
+                assert model._params_ready is not None
+            else:
+                opt.step()
+        if pipe is not None:
+            pipe.finish()
+            assert model._params_ready is None
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+def test_train_cli_test_only(tmp_path, monkeypatch):
+    """`args.test_only` (train.py:137-140): `python -m drin_amd.train --test-only --load-state PATH` makes one pass over the test
+    split with the loaded weights and writes the per-sample dump; no training epoch runs."""
+    from drin_amd import train as T
+    from drin_amd.data import write_synthetic_dataset
+    cfg = DrinConfig(batch_size=4, num_epoch=2, test_epoch_interval=1, **TINY)
+    write_synthetic_dataset(cfg, str(tmp_path), sizes=(8, 4, 6), seed=3)
+    state = str(tmp_path / "weights.pt")
+    sd = synth.make_state_dict(cfg, 8)
+    torch.save(sd, state)
+    dump = str(tmp_path / "test-result.txt")
+    monkeypatch.setattr(T, "DrinConfig", lambda **kw: cfg)
+    lines = []
+    monkeypatch.setattr("builtins.print", lambda *a, **k: lines.append(" ".join(map(str, a))))
+    T.main(["--data", str(tmp_path), "--test-only", "--load-state", state, "--output-test-result", dump])
+    assert sum(ln.startswith("test: loss") for ln in lines) == 1 and not any(ln.startswith("epoch ") for ln in lines)
+    assert not any("Training completed" in ln for ln in lines)
+    rows = open(dump).read().splitlines()
+    assert rows[0] == "==========  Test ==========" and sum(r.split(":\t")[0].isdigit() for r in rows[1:]) == 6
+    # the scores in the dump are those of the loaded weights
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    from drin_amd.data import create_datasets
+    batch = next(iter(create_datasets(cfg, str(tmp_path))[2]))
+    with torch.no_grad():
+        want = model([t.to(DEV) for t in batch[:-1]])[0].tolist()
+    got = eval(rows[1].split(":\t", 1)[1])
+    assert max(abs(a - b) for a, b in zip(got, want)) <= 1e-6

@@ -17,13 +17,23 @@
 // 5.5 MFLOP - plus ONE streaming pass over the entity bytes (k_entity_stream) and two row kernels.
 // The folded matrices depend only on the weights: drin_prepare computes them once per weight version
 // into a caller-owned buffer.
+#include <hip/hip_ext.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "fused.h"
 #include "internal.h"
 #include "layout.h"
 
 namespace drin {
+
+// side-by-side phases (below): off until measured; DRIN_PIPE / drin_set_pipeline choose
+constexpr int kPipeDefaultStreamCus = 0, kPipeDefaultChunkPairs = 51712;
 
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
@@ -146,13 +156,6 @@ size_t drin_prepared_bytes(const drin_config* cfg) {
   return P.total * sizeof(float);
 }
 
-size_t drin_fused_workspace_bytes(const drin_config* cfg) {
-  if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
-  FusedLayout L;
-  L.build(*cfg);
-  return L.total * sizeof(float);
-}
-
 int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepared, size_t prepared_bytes,
                  void* stream) {
   RoctxRange range("drin_prepare");
@@ -221,25 +224,20 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
   return DRIN_OK;
 }
 
-int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
-                          void* workspace, size_t workspace_bytes, float* scores, void* stream) {
-  RoctxRange range("drin_forward_prepared");
-  DRIN_TRY(validate_config(cfg));
-  DRIN_TRY(fused_supported(cfg));
-  if (!b || !params || !prepared || !workspace || !scores) {
-    set_error("drin_forward_prepared: NULL argument");
-    return DRIN_E_NULL;
-  }
+}  // extern "C"
+
+namespace drin {
+
+// The call in two halves.  kPhaseStream: everything up to and including the one pass over the entity bytes (HBM-bound);
+// kPhaseContract: the contractions and row kernels behind it (MFMA-bound).  Together: the whole forward on one stream.
+enum { kPhaseStream = 1, kPhaseContract = 2, kPhaseAll = 3 };
+
+static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
+                                   void* workspace, float* scores, hipStream_t st, const int phases) {
   FusedLayout L;
   L.build(*cfg);
-  if (workspace_bytes < L.total * sizeof(float) || !aligned16(workspace)) {
-    set_error("drin_forward_prepared: workspace has %zu bytes (needs %zu) or is not 16-byte aligned", workspace_bytes,
-              L.total * sizeof(float));
-    return DRIN_E_WORKSPACE;
-  }
   Prepared P;
   P.build(*cfg);
-  hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const float* pb = (const float*)prepared;
   const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
@@ -330,6 +328,11 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
     return DRIN_OK;
   };
   const size_t DD = (size_t)D * D, DR = (size_t)D * R;
+  float* vm0 = ws + L.vm0;
+  float* hmfu = ws + L.hmfu;
+  // pooled entity text stored as bf16 is exact in its hi plane: no lo plane, two MFMAs per tile pair
+  const bool xt_exact = bf16_feat && !tokens;
+  if (phases & kPhaseStream) {
   // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears
   if (bf16_feat) {
     DRIN_TRY(launch_span_mean_bf16(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
@@ -340,13 +343,11 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
                               cfg->mention_tokens, D, st));
     DRIN_TRY(launch_axis_mean(b->mention_image, ws + L.mimg, B, cfg->image_regions, R, st));
   }
-  float* vm0 = ws + L.vm0;
   // mention-sized contractions take the configured precision too: launch_gemm_nt keeps problems of fewer
   // than 1024 rows on the fp32 kernel (latency-bound), larger ones (WikiDiverse batches) go split-bf16
   DRIN_TRY(lin_pair({ws + L.span_mean, D, params->w_mention_text, D, P.p_wmt, DD, params->b_mention_text, vm0, D, B, D, D},
                     {ws + L.mimg, R, params->w_mention_image, R, P.p_wmi, DR, params->b_mention_image, vm0 + (size_t)B * D, D, B, D, R}));
   // (2) [hm | fu] = [mt0; mi0] [W_h1; W_u1]^T + [0; b_u1], then q = fu [W_v1 W_et | W_v1 W_ei]
-  float* hmfu = ws + L.hmfu;
   DRIN_TRY(lin(vm0, D, pb + P.wcat1, D, P.p_wcat1, 2 * DD, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D));
   if (dyn)
     DRIN_TRY(lin(hmfu + D, 2 * D, pb + P.ecat, D, P.p_ecat, DD + DR, nullptr, ws + L.q, D + R, 2 * (int64_t)B, D + R, D));
@@ -372,8 +373,6 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   sa.k_t = pb + P.k_t;
   sa.k_i = pb + P.k_i;
   sa.xt_out = planes ? nullptr : ws + L.xt;
-  // pooled entity text stored as bf16 is exact in its hi plane: no lo plane, two MFMAs per tile pair
-  const bool xt_exact = bf16_feat && !tokens;
   if (planes) {
     sa.xt_hi = xt_hi;
     sa.xt_lo = (xt_exact || one_pass) ? nullptr : xt_hi + MD;
@@ -406,6 +405,8 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   DRIN_TRY(launch_entity_stream(sa, st));
   if (L.chunks > 1)
     DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
+  }
+  if (!(phases & kPhaseContract)) return DRIN_OK;
   // (4) layer-1 mention vertices: T = S_text W_et^T + S_img W_ei^T, then the W_h input, W_h, LN, GELU
   DRIN_TRY(lin_pair({ws + L.s_text, D, params->w_entity_text, D, P.p_wet, DD, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D},
                     {ws + L.s_img, R, params->w_entity_image, R, P.p_wei, DR, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R}));
@@ -497,6 +498,235 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
   fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;
   return launch_pair_final(fa, st);
+}
+
+// ---- the two phases side by side on disjoint CU sets ------------------------------------------------------------------
+// k_entity_stream is HBM-bound, the contractions MFMA-bound; on the same CUs they do not overlap (the GEMM's tile loads queue
+// behind the stream kernel's ~100 KB per CU in flight), on DISJOINT CU sets they do, and a pass over 3 KB rows needs far
+// fewer than 256 CUs to keep HBM busy (tools/probes/partition_probe.hip: 96 CUs 4.6 TB/s, 128 CUs 5.6, 160 CUs 6.2 = what
+// all 256 reach).  A large batch is therefore cut into chunks of mentions; chunk c + 1's stream phase runs on the first
+// `stream_cus` CUs while chunk c's contraction phase runs on the others (two streams created with
+// hipExtStreamCreateWithCUMask, forked from and joined to the caller's stream by events).  Each chunk has its own workspace,
+// so no buffer is shared between chunks in flight.  A mention's score depends on its chunk's size only through the tile /
+// split-K choices of the mention-sized products (all inside the parity bar, and a deterministic function of the batch size).
+struct PipePlan {
+  int chunks = 1, chunk_mentions = 0, stream_cus = 0;
+};
+
+static std::atomic<int> g_pipe_stream_cus{-1}, g_pipe_chunk_pairs{-1};   // -1: environment / default
+
+static PipePlan pipe_plan(const drin_config& c) {
+  PipePlan p;
+  p.chunk_mentions = c.batch;
+  int cus = g_pipe_stream_cus.load(std::memory_order_relaxed);
+  int chunk_pairs = g_pipe_chunk_pairs.load(std::memory_order_relaxed);
+  if (cus < 0 || chunk_pairs < 0) {
+    // DRIN_PIPE = "off" | "<stream CUs>" | "<stream CUs>:<pairs per chunk>"
+    static const char* env = getenv("DRIN_PIPE");
+    int e_cus = kPipeDefaultStreamCus, e_pairs = kPipeDefaultChunkPairs;
+    if (env != nullptr && env[0] != 0) {
+      if (env[0] == 'o') e_cus = 0;
+      else {
+        e_cus = atoi(env);
+        const char* colon = strchr(env, ':');
+        if (colon) e_pairs = atoi(colon + 1);
+      }
+    }
+    if (cus < 0) cus = e_cus;
+    if (chunk_pairs < 0) chunk_pairs = e_pairs;
+  }
+  const bool planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL) && c.embed_dim % 32 == 0 &&
+                      c.image_dim % 32 == 0;
+  if (cus <= 0 || cus >= 256 || chunk_pairs < 4096 || !planes) return p;
+  int per = (int)std::max<int64_t>(1, chunk_pairs / c.num_candidates);
+  if (per >= 256) per -= per % 256;   // whole 256-row tiles of the mention-sized products
+  const int n = (int)cdiv(c.batch, per);
+  if (n < 4) return p;                // fill and drain of a short pipeline cost what the overlap buys
+  p.chunks = n;
+  p.chunk_mentions = per;
+  p.stream_cus = cus;
+  return p;
+}
+
+struct PipeStreams {
+  hipStream_t a = nullptr, b = nullptr;
+  hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
+  std::vector<hipEvent_t> done;
+  int cus = 0;
+};
+static std::mutex g_pipe_mutex;
+static PipeStreams g_pipe[16][2];   // per device: the configured split, and one spare for a second setting (probes)
+
+static int pipe_streams(int stream_cus, int chunks, PipeStreams** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(g_pipe_mutex);
+  PipeStreams* ps = nullptr;
+  for (PipeStreams& q : g_pipe[dev & 15])
+    if (q.cus == stream_cus || q.cus == 0) {
+      ps = &q;
+      break;
+    }
+  if (!ps) {  // a third setting in one process: rebuild the spare
+    ps = &g_pipe[dev & 15][1];
+    (void)hipStreamSynchronize(ps->a);
+    (void)hipStreamSynchronize(ps->b);
+    (void)hipStreamDestroy(ps->a);
+    (void)hipStreamDestroy(ps->b);
+    ps->a = ps->b = nullptr;
+    ps->cus = 0;
+  }
+  if (ps->cus == 0) {
+    int total = 0;
+    hipError_t e = hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
+    if (total > 256 || stream_cus >= total) {
+      set_error("pipelined forward: %d stream CUs of %d", stream_cus, total);
+      return DRIN_E_UNSUPPORTED;
+    }
+    // mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs): a prefix of the bits
+    // is spread evenly over the eight XCDs and their L2s
+    uint32_t ma[8] = {0}, mb[8] = {0};
+    for (int c = 0; c < total; ++c) (c < stream_cus ? ma : mb)[c / 32] |= 1u << (c % 32);
+    e = hipExtStreamCreateWithCUMask(&ps->a, 8, ma);
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ps->b, 8, mb);
+    if (e != hipSuccess) return hip_fail(e, "hipExtStreamCreateWithCUMask");
+    for (hipEvent_t* ev : {&ps->fork, &ps->join_a, &ps->join_b})
+      if (*ev == nullptr && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
+        return hip_fail(e, "hipEventCreate(pipeline)");
+    ps->cus = stream_cus;
+  }
+  while ((int)ps->done.size() < chunks) {
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate(pipeline)");
+    ps->done.push_back(ev);
+  }
+  *out = ps;
+  return DRIN_OK;
+}
+
+// mentions [m0, m0 + count) of a batch
+static drin_batch slice_batch(const drin_config& c, const drin_batch& b, int64_t m0) {
+  const size_t es = c.feature_dtype == DRIN_FEAT_BF16 ? 2 : 4;
+  auto feat = [&](const float* p, int64_t elems) -> const float* {
+    return p ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (size_t)elems * es) : nullptr;
+  };
+  auto inner = [](int v) { return (int64_t)(v > 1 ? v : 1); };
+  const int64_t N = c.num_candidates, D = c.embed_dim, R = c.image_dim, T = c.entity_tokens;
+  drin_batch s = b;
+  s.mention_text = feat(b.mention_text, m0 * c.mention_tokens * D);
+  s.mention_start = b.mention_start ? b.mention_start + m0 : nullptr;
+  s.mention_end = b.mention_end ? b.mention_end + m0 : nullptr;
+  s.mention_image = feat(b.mention_image, m0 * c.image_regions * R);
+  s.mention_object = feat(b.mention_object, m0 * c.mention_objects * inner(c.mention_object_inner) * R);
+  s.mention_object_score = b.mention_object_score ? b.mention_object_score + m0 * c.mention_objects : nullptr;
+  s.miet_similarity = b.miet_similarity ? b.miet_similarity + m0 * N : nullptr;
+  s.mtei_similarity = b.mtei_similarity ? b.mtei_similarity + m0 * N : nullptr;
+  if (b.entity_index) {   // the entity tensors are tables: only the index moves
+    s.entity_index = b.entity_index + m0 * N;
+    return s;
+  }
+  s.entity_text = feat(b.entity_text, T > 0 ? m0 * N * T * D : m0 * N * D);
+  s.entity_text_mask = (b.entity_text_mask && T > 0) ? b.entity_text_mask + m0 * N * T : b.entity_text_mask;
+  s.entity_image = feat(b.entity_image, m0 * N * inner(c.entity_image_inner) * R);
+  s.entity_object = feat(b.entity_object, m0 * N * c.entity_objects * inner(c.entity_object_inner) * R);
+  s.entity_object_score = b.entity_object_score ? b.entity_object_score + m0 * N * c.entity_objects : nullptr;
+  return s;
+}
+
+static size_t chunk_workspace_floats(const drin_config& c, const PipePlan& plan) {
+  drin_config cc = c;
+  cc.batch = plan.chunk_mentions;
+  FusedLayout L;
+  L.build(cc);
+  return L.total;
+}
+
+static int forward_prepared_pipelined(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
+                                      void* workspace, float* scores, hipStream_t st, const PipePlan& plan) {
+  PipeStreams* ps = nullptr;
+  DRIN_TRY(pipe_streams(plan.stream_cus, plan.chunks, &ps));
+  const size_t chunk_floats = chunk_workspace_floats(*cfg, plan);
+  hipError_t e = hipEventRecord(ps->fork, st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ps->a, ps->fork, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ps->b, ps->fork, 0);
+  if (e != hipSuccess) return hip_fail(e, "pipeline fork");
+  int rc = DRIN_OK;
+  for (int c = 0; c < plan.chunks && rc == DRIN_OK; ++c) {
+    const int64_t m0 = (int64_t)c * plan.chunk_mentions;
+    drin_config cc = *cfg;
+    cc.batch = (int)std::min<int64_t>(plan.chunk_mentions, cfg->batch - m0);
+    const drin_batch sb = slice_batch(*cfg, *b, m0);
+    float* ws = (float*)workspace + (size_t)c * chunk_floats;
+    float* sc = scores + m0 * cfg->num_candidates;
+    rc = forward_prepared_phases(&cc, &sb, params, prepared, ws, sc, ps->a, kPhaseStream);
+    if (rc != DRIN_OK) break;
+    e = hipEventRecord(ps->done[c], ps->a);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ps->b, ps->done[c], 0);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "pipeline hand-over");
+      break;
+    }
+    rc = forward_prepared_phases(&cc, &sb, params, prepared, ws, sc, ps->b, kPhaseContract);
+  }
+  // join in every case: the caller's stream never runs ahead of work already queued on the side streams
+  e = hipEventRecord(ps->join_a, ps->a);
+  if (e == hipSuccess) e = hipEventRecord(ps->join_b, ps->b);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, ps->join_a, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, ps->join_b, 0);
+  if (e != hipSuccess && rc == DRIN_OK) rc = hip_fail(e, "pipeline join");
+  return rc;
+}
+
+}  // namespace drin
+
+extern "C" {
+
+int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs) {
+  if (stream_cus >= 256) {
+    set_error("drin_set_pipeline: stream_cus=%d (0 = one stream, -1 = default, else < 256)", stream_cus);
+    return DRIN_E_SHAPE;
+  }
+  g_pipe_stream_cus.store(stream_cus < 0 ? -1 : stream_cus);
+  g_pipe_chunk_pairs.store(chunk_pairs < 0 ? -1 : chunk_pairs);
+  return DRIN_OK;
+}
+
+size_t drin_fused_workspace_bytes(const drin_config* cfg) {
+  if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
+  const PipePlan plan = pipe_plan(*cfg);
+  if (plan.chunks > 1) return (size_t)plan.chunks * chunk_workspace_floats(*cfg, plan) * sizeof(float);
+  FusedLayout L;
+  L.build(*cfg);
+  return L.total * sizeof(float);
+}
+
+int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
+                          void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  RoctxRange range("drin_forward_prepared");
+  DRIN_TRY(validate_config(cfg));
+  DRIN_TRY(fused_supported(cfg));
+  if (!b || !params || !prepared || !workspace || !scores) {
+    set_error("drin_forward_prepared: NULL argument");
+    return DRIN_E_NULL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  PipePlan plan = pipe_plan(*cfg);
+  if (plan.chunks > 1) {   // a stream being captured into a graph stays on the one-stream schedule
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) plan = PipePlan();
+  }
+  FusedLayout L;
+  L.build(*cfg);
+  const size_t need = plan.chunks > 1 ? (size_t)plan.chunks * chunk_workspace_floats(*cfg, plan) : L.total;
+  if (workspace_bytes < need * sizeof(float) || !aligned16(workspace)) {
+    set_error("drin_forward_prepared: workspace has %zu bytes (needs %zu) or is not 16-byte aligned", workspace_bytes,
+              need * sizeof(float));
+    return DRIN_E_WORKSPACE;
+  }
+  if (plan.chunks > 1) return forward_prepared_pipelined(cfg, b, params, prepared, workspace, scores, st, plan);
+  return forward_prepared_phases(cfg, b, params, prepared, workspace, scores, st, kPhaseAll);
 }
 
 }  // extern "C"

@@ -278,6 +278,14 @@ DRIN_API int drin_prepare(const drin_config* cfg, const drin_params* params, voi
 DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
                                    const void* prepared, void* workspace, size_t workspace_bytes, float* scores,
                                    void* stream);
+/* Large batches in the split-bf16 precision: drin_forward_prepared cuts the batch into chunks of mentions and runs chunk
+ * c + 1's pass over the entity bytes (HBM-bound) on `stream_cus` of the CUs while chunk c's contractions (MFMA-bound) run on
+ * the others - two internal streams created with hipExtStreamCreateWithCUMask, forked from and joined to `stream` by
+ * events, so the call keeps its stream-ordered contract.  stream_cus: 0 = everything on `stream` itself, -1 = the built-in
+ * default (also: environment DRIN_PIPE = "off" | "<cus>" | "<cus>:<pairs per chunk>"); chunk_pairs: (mention, candidate)
+ * pairs per chunk, -1 = default.  Process-wide; drin_fused_workspace_bytes answers for the setting in force, so change it
+ * between calls, not between the size query and its call.  No reference counterpart (the reference runs one stream). */
+DRIN_API int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs);
 
 /* ---- per-entity precompute cache for table-form inference ---------------------- *
  * With frozen weights, what the first GCN layer takes from an entity (its rows of the entity_* tables,

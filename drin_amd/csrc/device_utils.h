@@ -29,6 +29,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// v = hi + lo with hi = bf16(v), lo = bf16(v - hi), both rounded to nearest-even (the operand planes of the split-bf16
+// products).  Written on PAIRS: one packed conversion gives both hi's, two bit operations widen them again, a packed
+// subtract and one packed conversion give both lo's - five vector instructions per pair.  Element by element the same
+// arithmetic compiled to eight per pair for half of the pairs (each hi converted once alone and once packed); same bits.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t w = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - w, bf16x2_t));
+}
+__device__ __forceinline__ void split_bf16x4(float4 v, bf16x4_t& hi, bf16x4_t& lo) {
+  uint2 h, l;
+  split_bf16_pair(v.x, v.y, h.x, l.x);
+  split_bf16_pair(v.z, v.w, h.y, l.y);
+  hi = __builtin_bit_cast(bf16x4_t, h);
+  lo = __builtin_bit_cast(bf16x4_t, l);
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 // once-read streaming loads (entity rows of k_entity_stream): non-temporal cache policy
 #ifdef DRIN_NO_NT_LOADS

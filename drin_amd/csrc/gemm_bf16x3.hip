@@ -40,16 +40,7 @@ constexpr unsigned kCUs = 256;  // MI355X: the tail split below only changes how
 __device__ __forceinline__ int swz_f(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 __device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ swz_f(row)) << 4); }
 
-__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
-  hi[0] = (__bf16)v.x;
-  hi[1] = (__bf16)v.y;
-  hi[2] = (__bf16)v.z;
-  hi[3] = (__bf16)v.w;
-  lo[0] = (__bf16)(v.x - (float)hi[0]);
-  lo[1] = (__bf16)(v.y - (float)hi[1]);
-  lo[2] = (__bf16)(v.z - (float)hi[2]);
-  lo[3] = (__bf16)(v.w - (float)hi[3]);
-}
+__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) { split_bf16x4(v, hi, lo); }
 
 // ROWS x 32 floats staged by THREADS threads: thread t loads float4 #(t & 7) of rows (t >> 3) + (THREADS/8) i.
 // Loads are unconditional (no exec-masked branches in the K loop): rows past the end are clamped to the

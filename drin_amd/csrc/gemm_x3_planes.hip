@@ -553,11 +553,7 @@ __device__ __forceinline__ void split_store(f32x4v v, char* hi_plane, int off) {
     l[k] = (__bf16)0.0f;
   }
 #else
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    h[k] = (__bf16)v[k];
-    l[k] = (__bf16)(v[k] - (float)h[k]);
-  }
+  split_bf16x4(make_float4(v[0], v[1], v[2], v[3]), h, l);
 #endif
   *reinterpret_cast<bf16x4p*>(hi_plane + off) = h;
   *reinterpret_cast<bf16x4p*>(hi_plane + 128 * 64 + off) = l;
@@ -881,14 +877,7 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
   const float4 v = ld4(x + i * 4);
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   bf16x4 h, l;
-  h[0] = (__bf16)v.x;
-  h[1] = (__bf16)v.y;
-  h[2] = (__bf16)v.z;
-  h[3] = (__bf16)v.w;
-  l[0] = (__bf16)(v.x - (float)h[0]);
-  l[1] = (__bf16)(v.y - (float)h[1]);
-  l[2] = (__bf16)(v.z - (float)h[2]);
-  l[3] = (__bf16)(v.w - (float)h[3]);
+  split_bf16x4(v, h, l);
   *reinterpret_cast<bf16x4*>(hi + i * 4) = h;
   *reinterpret_cast<bf16x4*>(lo + i * 4) = l;
 }
@@ -905,9 +894,7 @@ __global__ void __launch_bounds__(256) k_split_planes_batch(const SplitBatch b) 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const float4 v = ld4(x + i * 4);
     bf16x4 h, l;
-    h[0] = (__bf16)v.x, h[1] = (__bf16)v.y, h[2] = (__bf16)v.z, h[3] = (__bf16)v.w;
-    l[0] = (__bf16)(v.x - (float)h[0]), l[1] = (__bf16)(v.y - (float)h[1]);
-    l[2] = (__bf16)(v.z - (float)h[2]), l[3] = (__bf16)(v.w - (float)h[3]);
+    split_bf16x4(v, h, l);
     *reinterpret_cast<bf16x4*>(hi + i * 4) = h;
     *reinterpret_cast<bf16x4*>(lo + i * 4) = l;
   }

@@ -560,15 +560,19 @@ static PipeStreams g_pipe[16][2];   // per device: the configured split, and one
 static int pipe_streams(int stream_cus, int chunks, PipeStreams** out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev < 0 || dev >= 16) {
+    set_error("pipelined forward: device %d outside the 16 per-device stream slots", dev);
+    return DRIN_E_UNSUPPORTED;
+  }
   std::lock_guard<std::mutex> lock(g_pipe_mutex);
   PipeStreams* ps = nullptr;
-  for (PipeStreams& q : g_pipe[dev & 15])
+  for (PipeStreams& q : g_pipe[dev])
     if (q.cus == stream_cus || q.cus == 0) {
       ps = &q;
       break;
     }
   if (!ps) {  // a third setting in one process: rebuild the spare
-    ps = &g_pipe[dev & 15][1];
+    ps = &g_pipe[dev][1];
     (void)hipStreamSynchronize(ps->a);
     (void)hipStreamSynchronize(ps->b);
     (void)hipStreamDestroy(ps->a);

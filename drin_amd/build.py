@@ -66,6 +66,15 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True, asan_h
     if debug:
         flags += ["-g", "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     hdr_t = _newest_header()
+    # objects compiled with other flags (DRIN_EXTRA_FLAGS probes, --debug) are stale whatever their timestamps say
+    stamp = os.path.join(obj_dir, "flags.txt")
+    want = " ".join([hipcc] + flags)
+    try:
+        same_flags = open(stamp).read() == want
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True
     jobs = []
     objs = []
     for src in SOURCES:
@@ -86,6 +95,8 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True, asan_h
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    with open(stamp, "w") as f:
+        f.write(want)
     lib = ASAN_LIB if asan_host else LIB
     if jobs or not os.path.exists(lib):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + (SAN_FLAGS[:2] + ["-shared-libsan"] if asan_host else []) + objs)

@@ -254,18 +254,28 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     const char* buf = smem + cur * G::BUF_BYTES;
     char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
     const bool more = kb + 1 < nkb;
+#ifndef DRIN_ABLATE_NO_LOADS   // timing ablations only (wrong results): the K-loop without its global traffic / without its MFMAs
     if (W_PLANES && more) dma.template issue<!ONE_PASS>(nb + 2 * G::A_PLANE, kb + 1);
+#endif
     load_b(buf);
+#ifndef DRIN_ABLATE_NO_MFMA
     row_tiles(buf, 0, G::MI / 2);
+#endif
     if (more) {
       sa.template store<!ONE_PASS>(nb, nb + G::A_PLANE);
       if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
+#ifndef DRIN_ABLATE_NO_LOADS
       if (kb + 2 < nkb) {
         sa.load((kb + 2) * BK);
         if (!W_PLANES) sb.load((kb + 2) * BK);
       }
+#endif
     }
+#ifndef DRIN_ABLATE_NO_MFMA
     row_tiles(buf, G::MI / 2, G::MI);
+#else
+    row_tiles(buf, 0, 1);
+#endif
     __syncthreads();  // also drains the LDS-DMA of this iteration (vmcnt(0))
   }
 

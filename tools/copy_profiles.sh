@@ -1,0 +1,25 @@
+#!/bin/bash
+# Copies what tools/profile_round.sh left under gpurun_out/round/ into the tracked profiles/ names of a round:
+#   tools/copy_profiles.sh r3
+set -e
+R=${1:?round tag, e.g. r3}
+O=gpurun_out/round
+P=profiles
+stats() { ls -t $O/$1/*/*_kernel_stats.csv | head -1; }
+cp "$(stats wm)" $P/${R}_wikimel_b4096_kernel_stats.csv
+cp "$(stats tab)" $P/${R}_table_cache_b4096_kernel_stats.csv
+cp "$(stats train)" $P/${R}_train_b64_kernel_stats.csv
+cp "$(stats train512)" $P/${R}_train_b512_kernel_stats.csv
+cp "$(stats train_rccl)" $P/${R}_train_b64_rccl_world1_kernel_stats.csv
+cp $O/wm_bench_under_rocprof.json $P/${R}_wikimel_b4096_bench_under_rocprof.json
+cp $O/table_cache_bench_under_rocprof.json $P/${R}_table_cache_b4096_bench_under_rocprof.json
+cp $O/train64_bench_under_rocprof.json $P/${R}_train_b64_bench_under_rocprof.json
+cp $O/train512_bench_under_rocprof.json $P/${R}_train_b512_bench_under_rocprof.json
+cp $O/train64_rccl_world1_bench_under_rocprof.json $P/${R}_train_b64_rccl_world1_bench_under_rocprof.json
+cp $O/config5_1M_stream.json $P/${R}_config5_1M_mentions_streamed.json
+cp $O/hbm_traffic.json $P/${R}_hbm_traffic.json
+cp $O/r3_mfma_pmc.json $P/${R}_mfma_pmc.json
+cp $O/summary.txt $P/${R}_mfma_pmc_summary.txt
+# the default line three times (one JSON line each)
+cat $O/wm_bench.json $O/wm_bench_1.json $O/wm_bench_2.json > $P/${R}_wikimel_b4096_bench_all_legs.json
+ls -la $P | grep ${R}_ | wc -l

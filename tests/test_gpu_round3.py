@@ -567,3 +567,23 @@ def test_pipelined_forward_equals_the_one_stream_schedule(layout):
     finally:
         _lib.check(lib.drin_set_pipeline(-1, -1))
     assert lib.drin_set_pipeline(256, -1) != _lib.OK
+
+
+def test_four_phase_gemm_with_a_single_k_block():
+    """D = R = 32: every pair-sized contraction of the fused path is ONE 32-wide K-block (the four-phase kernels' prologue,
+    one block that re-fetches itself, epilogue) with 32 output columns of a 256-column tile; 80 000 pair rows = 313 tiles,
+    ragged last row tile.  Slices against the oracle, mention independence."""
+    cfg = DrinConfig(num_candidates_data=3, bert_embed_dim=32, gcn_embed_dim=32, resnet_embed_dim=32,
+                     max_mention_sentence_len=12, resnet_num_region=5)
+    sd = synth.make_state_dict(cfg, 8)
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    B = 20_011
+    batch = synth.make_device_batch(cfg, B, 9, DEV)[:14]
+    with torch.no_grad():
+        out = model(batch)
+        assert out.shape == (B, 4) and torch.isfinite(out).all()
+        for rows in (slice(0, 6), slice(B - 5, B), slice(10_000, 10_006)):
+            ref = O.forward(sd, [t[rows].cpu() for t in batch])
+            assert (out[rows].cpu() - ref).abs().max().item() <= 1e-5
+            assert (out[rows] - model([t[rows] for t in batch])).abs().max().item() <= 5e-6

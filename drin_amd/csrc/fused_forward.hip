@@ -440,6 +440,19 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
     DRIN_TRY(launch_gemm_nt(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, false, prec, st));
   }
+  // The two pair kernels open every workgroup with 18-24 KB of mention-side vectors into LDS and close it with a reduction over
+  // its waves: with thousands of mentions in the call a workgroup takes up to 128 candidates of its mention (WikiMEL: all 101)
+  // instead of the stream kernel's 16 - row kernels 1.385 -> 1.27 ms at 4096 mentions, same box; small batches keep the 16,
+  // which is where their parallelism comes from (64 mentions: 0.55 ms against 0.63).  The mention sums of layer 2 are then
+  // added in another grouping: scores of one mention in a small and in a large call differ by fp32 re-association, as
+  // they do through the tile choices of the mention-sized products.  DRIN_PAIR_CHUNK = candidates per workgroup (probes).
+  int pair_chunks = B >= 2048 ? (int)cdiv(N, 128) : L.chunks;
+  {
+    static const char* pc_env = getenv("DRIN_PAIR_CHUNK");
+    const int per = pc_env ? atoi(pc_env) : 0;
+    if (per >= 16) pair_chunks = (int)cdiv(N, per);
+  }
+  pair_chunks = std::max(1, std::min(L.chunks, pair_chunks));
   // (6) layer-1 entity vertices + layer-2 mention aggregates
   PairArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -462,12 +475,12 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   pa.B = B;
   pa.N = N;
   pa.D4 = D / 4;
-  pa.chunks = L.chunks;
+  pa.chunks = pair_chunks;
   pa.ln_eps = cfg->layer_norm_eps;
   pa.act_v = vertex_act(cfg);
   DRIN_TRY(launch_pair_layer1(pa, st));
   // (7) layer-2 mention-text vertex
-  DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, L.chunks, st));
+  DRIN_TRY(launch_mention_input2(ws + L.s2_part, vm1, ws + L.agg2, B, D, N, pair_chunks, st));
   DRIN_TRY(lin(ws + L.agg2, D, L2.w_h, D, P.p_wh2, DD, L2.b_h, ws + L.mt2, D, B, D, D));
   DRIN_TRY(launch_layernorm_gelu(ws + L.mt2, L2.ln_weight, L2.ln_bias, ws + L.mt2, nullptr, nullptr, B, D, cfg->layer_norm_eps, st,
                                  vertex_act(cfg)));
@@ -493,7 +506,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   fa.B = B;
   fa.N = N;
   fa.D4 = D / 4;
-  fa.chunks = L.chunks;
+  fa.chunks = pair_chunks;
   fa.ln_eps = cfg->layer_norm_eps;
   fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;

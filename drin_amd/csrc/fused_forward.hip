@@ -41,9 +41,19 @@ struct FusedLayout {  // workspace offsets in floats
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
-    // a workgroup owns 16 consecutive candidates of one mention (4 per wave).  The chunking depends on N
-    // only - never on the batch size - so a mention scores bit-identically in any batch.
-    chunks = (int)((N + 15) / 16);
+    // a workgroup owns 16 consecutive candidates of one mention (4 per wave) - or, from 2 048 mentions up, where the mentions
+    // alone fill the chip eight times over, up to 128 of them (WikiMEL: the whole list): one prologue of mention-side vectors
+    // and one cross-wave reduction per mention instead of seven, no partial sums to write and reduce (same box, three
+    // alternating runs: k_reduce_stream_partials' 0.15 ms gone, the stream kernel itself unchanged, step -0.19 ms;
+    // profiles/r3_stream_chunk_ab.txt).  The grouping of the per-mention sums therefore depends on the size of the call: a
+    // mention's scores in a small and in a large call differ by fp32 re-association (as through the tile choices of the
+    // mention-sized products), within one call size they are the same bits every run.
+    chunks = (int)(B >= 2048 ? (N + 127) / 128 : (N + 15) / 16);
+    {
+      static const char* sc_env = getenv("DRIN_STREAM_CHUNK");   // probe: candidates per workgroup of the stream kernel
+      const int per = sc_env ? atoi(sc_env) : 0;
+      if (per >= 16) chunks = (int)((N + per - 1) / per);
+    }
     size_t off = 0;
     auto take = [&off](size_t n) {
       const size_t o = off;
@@ -440,19 +450,15 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
     DRIN_TRY(launch_gemm_nt(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, false, prec, st));
   }
-  // The two pair kernels open every workgroup with 18-24 KB of mention-side vectors into LDS and close it with a reduction over
-  // its waves: with thousands of mentions in the call a workgroup takes up to 128 candidates of its mention (WikiMEL: all 101)
-  // instead of the stream kernel's 16 - row kernels 1.385 -> 1.27 ms at 4096 mentions, same box; small batches keep the 16,
-  // which is where their parallelism comes from (64 mentions: 0.55 ms against 0.63).  The mention sums of layer 2 are then
-  // added in another grouping: scores of one mention in a small and in a large call differ by fp32 re-association, as
-  // they do through the tile choices of the mention-sized products.  DRIN_PAIR_CHUNK = candidates per workgroup (probes).
-  int pair_chunks = B >= 2048 ? (int)cdiv(N, 128) : L.chunks;
+  // The two pair kernels walk the same candidate chunks as the stream kernel (FusedLayout::chunks: whole mentions from 2 048
+  // mentions up - their share of that change: row kernels 1.385 -> 1.27 ms at 4 096 mentions; 64 mentions with whole-mention
+  // workgroups 0.55 -> 0.63 ms, which is why small calls keep 16 candidates).  DRIN_PAIR_CHUNK = candidates per workgroup (probes).
+  int pair_chunks = L.chunks;
   {
     static const char* pc_env = getenv("DRIN_PAIR_CHUNK");
     const int per = pc_env ? atoi(pc_env) : 0;
-    if (per >= 16) pair_chunks = (int)cdiv(N, per);
+    if (per >= 16) pair_chunks = std::max(1, std::min(L.chunks, (int)cdiv(N, per)));
   }
-  pair_chunks = std::max(1, std::min(L.chunks, pair_chunks));
   // (6) layer-1 entity vertices + layer-2 mention aggregates
   PairArgs pa;
   memset(&pa, 0, sizeof(pa));

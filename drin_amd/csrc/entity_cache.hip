@@ -23,6 +23,8 @@
 // whenever they change, so it serves inference / evaluation with frozen weights - never training.
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "fused.h"
 #include "internal.h"
 #include "layout.h"
@@ -310,12 +312,22 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
                                                          l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
     accumulate2(acc + 2 * D, n_tt, et1, n_ti, ei1);
   };
-  {  // a chunk is one group of at most 16 candidates (chunks = ceil(N / 16))
-    const int n0 = n_begin + wave;
+  // a chunk is a whole number of groups of 16 candidates (the last one ragged); the indices of the next group are requested
+  // at the top of the current one and its first row during the current one's last step
+  // (EXACT widths only: the guarded instantiations have no registers left for the look-ahead and keep ONE group per workgroup)
+  for (int g = n_begin; g < n_end; g += 16) {
+    const bool more = EXACT && g + 16 < n_end;
+    int64_t nxt[4] = {0, 0, 0, 0}, nxt_v[4];
+    if (more) request_indices(nxt_v, g + 16);
+    const int n0 = g + wave;
     step(ra, rb, n0, ent[0], ent[1]);
     step(rb, ra, n0 + 4, ent[1], ent[2]);
     step(ra, rb, n0 + 8, ent[2], ent[3]);
-    step(rb, ra, n0 + 12, ent[3], 0);
+    if (more) uniform_indices(nxt, nxt_v);
+    step(rb, ra, n0 + 12, ent[3], nxt[0]);
+    if (!EXACT) break;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ent[k] = nxt[k];
   }
 
   // ---- fixed-order cross-wave reduction, one partial per (mention, chunk) --------------------------------
@@ -369,14 +381,32 @@ __global__ void __launch_bounds__(256) k_mention_layer1_cached(const float* __re
   out[((int64_t)B + b) * D + d] = (ai + s2 * wt + s3 * wi) * inv_n + hm[((int64_t)B + b) * ldhm + d] + bh;
 }
 
+// Same box, config 5 (1001 candidates), ms per call at 16 / 64 / 128 candidates per workgroup: 64 mentions 0.72 / 0.70 / 0.72,
+// 256 mentions 2.44 / 2.29 / 2.38, 1 024 mentions 9.7 / 9.45 / 9.38, 4 096 mentions 38.0 / 35.3 / 35.1 (k_cached_pairs 21.6 -> 19.5 ms,
+// the row kernels behind it 4.16 -> 3.35): profiles/r3_cached_chunk_ab.txt.  (Round 2's "64 candidates: slower" was a version that
+// lost the index / row look-ahead at the group boundary.)
+static int kCachedChunkDefault(const drin_config& c) { return c.batch >= 2048 ? 128 : 64; }
+
+// Candidates per workgroup of the cached path's kernels.  16 unless the exact-width kernel runs (see k_cached_pairs) on a
+// call large enough that the mentions alone fill the chip; DRIN_CACHED_CHUNK = candidates (multiple of 16) for probes.
+static int cached_chunk_candidates(const drin_config& c) {
+  const bool exact = c.embed_dim == 768 && c.image_dim == 2048 && vertex_act(&c) == DRIN_ACT_GELU;
+  if (!exact) return 16;
+  static const char* cc_env = getenv("DRIN_CACHED_CHUNK");
+  const int per = cc_env ? atoi(cc_env) : 0;
+  if (per >= 16) return per - per % 16;
+  return kCachedChunkDefault(c);
+}
+
 struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats
   size_t span_mean, mimg, vm0, hmfu, e1m, c_part, s2_part, vm1, hm2, agg2, mt2, et1, p_et1, h2, splitk, splitk_floats, total;
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
-    // a function of N only, so a mention scores bit-identically in any batch.  (64 candidates per workgroup for
-    // long lists - amortising the prologue 4x - measured SLOWER: 1.97 vs 1.49 ms at N = 1001.)
-    chunks = (int)((N + 15) / 16);
+    // k_cached_pairs walks its chunk in groups of 16 candidates (4 per wave); only the exact-width instantiation (D = 768,
+    // R = 2048, default activation) has the registers to look ahead across groups, every other one gets ONE group per
+    // workgroup.  cached_chunk_candidates() is the one place that knows.
+    chunks = (int)((N + cached_chunk_candidates(c) - 1) / cached_chunk_candidates(c));
     size_t off = 0;
     auto take = [&off](size_t n) {
       const size_t o = off;
@@ -679,6 +709,11 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   fa.N = N;
   fa.D4 = D / 4;
   fa.chunks = L.chunks;
+  {
+    static const char* fc_env = getenv("DRIN_CACHED_FINAL_CHUNK");   // probe: k_pair_final alone (it reads no partial sums)
+    const int per = fc_env ? atoi(fc_env) : 0;
+    if (per >= 16) fa.chunks = (int)cdiv(N, per);
+  }
   fa.ln_eps = cfg->layer_norm_eps;
   fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;

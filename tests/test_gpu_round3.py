@@ -587,3 +587,23 @@ def test_four_phase_gemm_with_a_single_k_block():
             ref = O.forward(sd, [t[rows].cpu() for t in batch])
             assert (out[rows].cpu() - ref).abs().max().item() <= 1e-5
             assert (out[rows] - model([t[rows] for t in batch])).abs().max().item() <= 5e-6
+
+
+@pytest.mark.parametrize("B", [1100, 2100])
+def test_large_call_candidate_chunking(B):
+    """From 1 024 mentions up a workgroup of the stream / pair kernels takes 48 candidates of its mention, from 2 048 up to 128
+    (here: all 37, ten per wave, ragged) instead of 16: slices against the oracle and against the same mentions scored in a
+    small call (16-candidate workgroups; equal up to fp32 re-association of the per-mention sums)."""
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=9, **TINY)
+    sd = synth.make_state_dict(cfg, 8)
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    batch = synth.make_device_batch(cfg, B, 13, DEV)[:14]
+    with torch.no_grad():
+        out = model(batch)
+        assert out.shape == (B, 37) and torch.isfinite(out).all()
+        for rows in (slice(0, 5), slice(B - 4, B), slice(B // 2, B // 2 + 5)):
+            ref = O.forward(sd, [t[rows].cpu() for t in batch])
+            assert (out[rows].cpu() - ref).abs().max().item() <= 1e-5
+            assert (out[rows] - model([t[rows] for t in batch])).abs().max().item() <= 5e-6
+        assert torch.equal(out, model(batch))

@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) k_mention_layer1_cached(const float* __re
 // 256 mentions 2.44 / 2.29 / 2.38, 1 024 mentions 9.7 / 9.45 / 9.38, 4 096 mentions 38.0 / 35.3 / 35.1 (k_cached_pairs 21.6 -> 19.5 ms,
 // the row kernels behind it 4.16 -> 3.35): profiles/r3_cached_chunk_ab.txt.  (Round 2's "64 candidates: slower" was a version that
 // lost the index / row look-ahead at the group boundary.)
-static int kCachedChunkDefault(const drin_config& c) { return c.batch >= 2048 ? 128 : 64; }
+static int cached_chunk_default(const drin_config& c) { return c.batch >= 2048 ? 128 : 64; }
 
 // Candidates per workgroup of the cached path's kernels.  16 unless the exact-width kernel runs (see k_cached_pairs) on a
 // call large enough that the mentions alone fill the chip; DRIN_CACHED_CHUNK = candidates (multiple of 16) for probes.
@@ -395,7 +395,7 @@ static int cached_chunk_candidates(const drin_config& c) {
   static const char* cc_env = getenv("DRIN_CACHED_CHUNK");
   const int per = cc_env ? atoi(cc_env) : 0;
   if (per >= 16) return per - per % 16;
-  return kCachedChunkDefault(c);
+  return cached_chunk_default(c);
 }
 
 struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DRIN_LIB_PATH: another build of the same library (the sanitizer build of `python -m drin_amd.build --asan-host`)
 LIB_PATH = os.environ.get("DRIN_LIB_PATH") or os.path.join(_HERE, "libdrin_hip.so")
 MAX_LAYERS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL = 0, 1, 2, 3
@@ -74,6 +74,7 @@ EXPORTS = {
     "drin_last_error": (C.c_char_p, []),
     "drin_build_info": (C.c_char_p, []),
     "drin_default_config": (C.c_int, [C.POINTER(DrinConfigC)]),
+    "drin_host_selftest": (C.c_int, []),
     "drin_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC), C.c_int]),
     "drin_edges_fwd": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.c_void_p, C.c_void_p, C.c_void_p]),
     "drin_pool_fwd": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -91,6 +92,7 @@ EXPORTS = {
     "drin_fused_supported": (C.c_int, [C.POINTER(DrinConfigC)]),
     "drin_prepared_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
     "drin_fused_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
+    "drin_workgroups_per_mention": (C.c_int32, [C.POINTER(DrinConfigC), C.c_int32]),
     "drin_set_pipeline": (C.c_int, [C.c_int32, C.c_int32]),
     "drin_prepare": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinParamsC), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_forward_prepared": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,

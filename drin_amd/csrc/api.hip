@@ -1090,4 +1090,81 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
   return flush(layer_sums, bias_sums.n, layer_small, dw_small.n, layer_group, dw_group.n);
 }
 
+// ---- host-side self-checks (sanitizer build / CI; no launch is made, no GPU needed) -----------------------------------
+// What the mention-sized exact-fp32 weight-gradient group of drin_backward may have to hold at once, at worst: every
+// weight-gradient product of the pass whose reduction has at most 2048 rows (dw_product above: in exact-fp32 precision all
+// of them, in split-bf16 precision the ones gemm_tn_bf16x3_fits refuses), each with small_tn_slices(rows) stored slices.
+// Layout::small_part_floats must cover it for every batch size (it did not for 1024 < B N <= 2048).
+static size_t small_group_worst_case_floats(const drin_config& c) {
+  const size_t B = c.batch, M = B * c.num_candidates, D = c.embed_dim, R = c.image_dim;
+  const int nl = c.num_layers;
+  size_t need = 0;
+  auto product = [&need](size_t rows, size_t n_out, size_t k_red) {
+    if (rows >= 1 && rows <= 2048) need += (size_t)small_tn_slices((int64_t)rows) * n_out * k_red;
+  };
+  for (int l = nl - 1; l >= 0; --l) {
+    const size_t types = l == nl - 1 ? 1 : 2;       // the top layer's image vertices are dead
+    product(types * B, D, D), product(types * M, D, D);                          // dW_h: mention rows, entity rows
+    if (c.dynamic_edges && l < nl - 1) product(2 * M, D, D), product(2 * B, D, D);   // dW_v, dW_u
+  }
+  product(B, D, D), product(M, D, D), product(B, D, R), product(M, D, R);        // the four vertex encoders
+  return need;
+}
+
+int drin_host_selftest(void) {
+  // (1) the slice scratch of the mention-sized weight-gradient group covers its worst case at every batch size
+  for (int precision : {(int)DRIN_PREC_F32, (int)DRIN_PREC_BF16X3})
+    for (int nl : {1, 2, 3})
+      for (int n : {1, 11, 101})
+        for (int dims = 0; dims < 2; ++dims)
+          for (int b = 1; b <= 4300; b += (b < 48 ? 1 : 7)) {
+            drin_config c;
+            drin_default_config(&c);
+            c.batch = b, c.num_candidates = n, c.num_layers = nl, c.precision = precision;
+            if (dims) c.embed_dim = 64, c.image_dim = 128;
+            Layout L;
+            L.build(c, true);
+            const size_t need = small_group_worst_case_floats(c);
+            if (need > L.small_part_floats) {
+              set_error("selftest: B=%d N=%d layers=%d D=%d precision=%d: the mention-sized weight-gradient group may store %zu "
+                        "floats of slices, Layout::small_part_floats = %zu", b, n, nl, c.embed_dim, precision, need, L.small_part_floats);
+              return DRIN_E_WORKSPACE;
+            }
+          }
+  // (2) a grouped launch refuses an item with an empty reduction instead of deriving a slice length of 0 from it and
+  //     dividing by that (the SIGFPE of round 3's staged backward: value-initialised items past a flushed group)
+  alignas(16) static float dummy[16];
+  {
+    F32GemmGroup g;
+    g.n = 2;
+    g.item[0] = {dummy, 4, dummy, 4, dummy, 4, 4, 4, 4};
+    g.item[1] = F32GemmGroup::Item();   // M = N = K = 0, NULL operands
+    const int rc = launch_gemm_tn_f32_group(g, nullptr, nullptr, 0, nullptr);
+    if (rc != DRIN_E_SHAPE) {
+      set_error("selftest: launch_gemm_tn_f32_group accepted an item with an empty reduction (status %d)", rc);
+      return rc == DRIN_OK ? DRIN_E_SHAPE : rc;
+    }
+    F32GemmGroup h;
+    h.n = 1;
+    h.item[0] = F32GemmGroup::Item();
+    h.bias_of[0] = nullptr;
+    const int rn = launch_gemm_nt_f32_group(h, nullptr, dummy, 16);
+    if (rn != DRIN_E_SHAPE) {
+      set_error("selftest: launch_gemm_nt_f32_group accepted an empty item (status %d)", rn);
+      return rn == DRIN_OK ? DRIN_E_SHAPE : rn;
+    }
+  }
+  // (3) an empty reduction through the single-product entry: nothing to add, nothing launched, nothing divided
+  {
+    const int rc = launch_gemm_tn(dummy, 4, dummy, 4, dummy, 4, /*M=*/0, 4, 4, DRIN_PREC_F32, nullptr, dummy, 16);
+    if (rc != DRIN_OK) return rc;
+    if (launch_gemm_tn(dummy, 4, dummy, 4, dummy, 4, /*M=*/-1, 4, 4, DRIN_PREC_F32, nullptr, dummy, 16) != DRIN_E_SHAPE) {
+      set_error("selftest: launch_gemm_tn accepted a negative reduction length");
+      return DRIN_E_SHAPE;
+    }
+  }
+  set_error("");
+  return DRIN_OK;
+}
+
 }  // extern "C"

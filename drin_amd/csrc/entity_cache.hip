@@ -434,6 +434,12 @@ struct CachedLayout {  // workspace of drin_forward_cached, offsets in floats
   }
 };
 
+int cached_chunks_per_mention(const drin_config& c) {
+  CachedLayout L;
+  L.build(c);
+  return L.chunks;
+}
+
 static int cache_supported(const drin_config* c) {
   DRIN_TRY(fused_supported(c));
   if (c->num_entities <= 0) {

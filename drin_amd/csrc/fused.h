@@ -47,6 +47,8 @@ struct Prepared {  // offsets in floats
 
 // DRIN_OK when `c` can take the folded two-layer pipelines (fused_forward.hip, entity_cache.hip)
 int fused_supported(const drin_config* c);
+// workgroups (candidate chunks) per mention of the per-entity-cache path's kernels for this call (entity_cache.hip)
+int cached_chunks_per_mention(const drin_config& c);
 
 struct StreamArgs {
   // batch (entity side) - device pointers into the caller's tensors

@@ -716,6 +716,14 @@ int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs) {
   return DRIN_OK;
 }
 
+int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached) {
+  if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
+  if (cached) return cached_chunks_per_mention(*cfg);
+  FusedLayout L;
+  L.build(*cfg);
+  return L.chunks;
+}
+
 size_t drin_fused_workspace_bytes(const drin_config* cfg) {
   if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
   const PipePlan plan = pipe_plan(*cfg);

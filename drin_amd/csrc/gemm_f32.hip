@@ -251,13 +251,12 @@ static int launch(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     return DRIN_E_ALIGN;
   }
   int kps = K;
-  if (splits > 1) {
+  if (splits > 1 && K > 0) {   // (K <= 0: one empty slice - never a slice length of 0 to divide by)
     kps = (int)(cdiv(cdiv(K, splits), BK) * BK);
     splits = (int)cdiv(K, kps);
   } else {
     splits = 1;
   }
-  if (K <= 0) splits = 1;
   if (splits_used) *splits_used = splits;
   const size_t lds = sizeof(float) * 2 * (Tile<BM>::FLOATS + Tile<BN>::FLOATS);
   static DynLdsOptIn opt_in;  // one per template instantiation; > 64 KiB of dynamic LDS needs the opt-in
@@ -500,6 +499,10 @@ int launch_gemm_nt_f32_group(const F32GemmGroup& grp, hipStream_t st, float* scr
   size_t used = 0;
   for (int i = 0; i < grp.n; ++i) {
     const auto& it = grp.item[i];
+    if (it.M <= 0 || it.N <= 0 || it.K <= 0) {
+      set_error("gemm_nt group: item %d has M=%lld N=%d K=%d", i, (long long)it.M, it.N, it.K);
+      return DRIN_E_SHAPE;
+    }
     int splits = it.K / 128;   // as launch_small_splitk
     if (splits > 8) splits = 8;
     if (splits < 1) splits = 1;
@@ -630,6 +633,14 @@ int launch_gemm_tn_f32_group(const F32GemmGroup& grp, hipStream_t st, float* scr
   size_t used = 0;
   for (int i = 0; i < grp.n; ++i) {
     const auto& it = grp.item[i];
+    // add_tn never stores an empty product; an item with a non-positive extent can only be a caller's slip (round 3's staged
+    // backward once handed over value-initialised items past a group it had already flushed: M == 0 made kps 0 and the next
+    // line's division raised SIGFPE on the host) - refused, never divided by
+    if (it.M <= 0 || it.N <= 0 || it.K <= 0 || it.M > 2048 || it.a == nullptr || it.b == nullptr || it.y == nullptr) {
+      set_error("gemm_tn group: item %d of %d has M=%lld N=%d K=%d (or a NULL operand) - outside [1, 2048] reduction rows", i,
+                grp.n, (long long)it.M, it.N, it.K);
+      return DRIN_E_SHAPE;
+    }
     int splits = small_tn_slices(it.M);
     const int kps = (int)(cdiv(cdiv(it.M, splits), BK) * BK);
     splits = (int)cdiv(it.M, kps);
@@ -684,10 +695,11 @@ int launch_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, flo
     set_error("gemm_tn: N=%d and K=%d must be multiples of 4", N, K);
     return DRIN_E_SHAPE;
   }
-  if (M > 0x7fffffff) {
-    set_error("gemm_tn: reduction length %lld too large", (long long)M);
+  if (M > 0x7fffffff || M < 0) {
+    set_error("gemm_tn: reduction length %lld outside [0, 2^31)", (long long)M);
     return DRIN_E_SHAPE;
   }
+  if (M == 0) return DRIN_OK;   // an empty sum adds nothing (and no slice length is derived from it)
   const bool small = M <= 2048;   // mention-sized reductions (a few hundred rows): 64 x 64 tiles, 4x the workgroups
   int splits;
   if (small) {

@@ -114,9 +114,14 @@ struct Layout {
       }
       {  // every weight-gradient product of at most 2048 reduction rows may store up to four slices (internal.h:
         // small_tn_slices); the mention side has 2 B rows at most, the entity side 2 M
+        // (a side's products have `rows` or 2 x `rows` reduction rows - dW_h[top] and the vertex encoders see one vertex type,
+        //  the others both - and the ones past 2048 rows leave the group: each side is sized for whichever of its two row
+        //  counts stores more.  Sized at 2 x rows alone - ADVICE r3 - a side with rows <= 2048 < 2 rows got NO scratch while
+        //  its single-type products still stored four slices: DRIN_E_WORKSPACE in exact fp32 at 1024 < B N <= 2048.)
         auto slices = [](size_t rows) { return rows > 2048 ? (size_t)0 : (rows + 127) / 128 > 4 ? (size_t)4 : (rows + 127) / 128 < 1 ? (size_t)1 : (rows + 127) / 128; };
+        auto side = [&slices](size_t rows) { return slices(rows) > slices(2 * rows) ? slices(rows) : slices(2 * rows); };
         const size_t per_side = ((size_t)2 * nl + 1) * D * D + D * R;   // dW_h, dW_u | dW_v of every layer, a text and an image encoder
-        small_part_floats = (slices(2 * B) + slices(2 * M)) * per_side + 64;
+        small_part_floats = (side(B) + side(M)) * per_side + 64;
         small_part = take(small_part_floats);
         colsum_part_floats = (size_t)8 * 64 * D;
         colsum_part = take(colsum_part_floats);

@@ -499,8 +499,10 @@ def _invalidate_after_load(module, _incompatible_keys) -> None:
 class Model(nn.Module):
     """`model_module.Model()` of `train.py:136` (drin/model.py:156-162)."""
 
-    # mentions per library call: larger batches are scored in slices of this many (mentions are independent, so the
-    # scores are bit-identical); the one-workgroup-per-(mention, chunk) grids of the row kernels stop at 65 535 mentions
+    # mentions per library call: larger batches are scored in slices of this many (mentions are independent; the candidate
+    # grouping of the per-mention sums depends on the size of the call - csrc/fused_forward.hip: 16 / 48 / whole-list
+    # workgroups - so a mention's scores in calls of different sizes agree to fp32 re-association, <= 5e-6, and are the same
+    # bits every run within one call size); the one-workgroup-per-(mention, chunk) grids of the row kernels stop at 65 535 mentions
     MAX_CALL_MENTIONS = 32768
 
     def __init__(self, cfg: Optional[DrinConfig] = None, precision: str = "bf16x3", fused: bool = True,
@@ -704,7 +706,15 @@ class Model(nn.Module):
                 call.params_ready, self._params_ready = ev, None
             else:
                 self.wait_for_parameters()
-        return _DrinScore.apply(call, prepared, training, *params)
+        try:
+            return _DrinScore.apply(call, prepared, training, *params)
+        except BaseException:
+            # a staged call that failed before the library enqueued its wait (validation / workspace error) must not lose the
+            # ordering behind the update still running on the side stream: the current stream waits here (harmless if the
+            # library already did), so that whatever reads the parameters next reads them after Adam has written them
+            if ev is not None:
+                torch.cuda.current_stream(call.device).wait_event(ev)
+            raise
 
     def _indexed_training_call(self, batch: "IndexedBatch", planes: bool) -> Optional[_Call]:
         """The table form of `drin_forward` / `drin_backward` (`drin_batch.entity_index` over tables pooled ahead of time),

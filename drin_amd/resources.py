@@ -57,6 +57,88 @@ def kernel_resources(obj_dir: str | None = None) -> List[Dict]:
     return out
 
 
+def _code_object(obj: str, tmp: str) -> str:
+    fat, co = os.path.join(tmp, "o.fat"), os.path.join(tmp, "o.co")
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", f"--targets={TARGET}", f"--input={fat}", f"--output={co}", "--unbundle"],
+                   check=True, capture_output=True)
+    return co
+
+
+def kernel_isa(obj_name: str, kernel_substring: str, obj_dir: str | None = None) -> List[tuple]:
+    """`(address, "mnemonic operands", branch target address or None)` for every instruction, in layout order, of the first
+    kernel of `csrc/build/<obj_name>` whose mangled name contains `kernel_substring` (`llvm-objdump -d` of the gfx950 code object)."""
+    obj_dir = obj_dir or os.path.join(_build.CSRC, "build")
+    with tempfile.TemporaryDirectory() as tmp:
+        co = _code_object(os.path.join(obj_dir, obj_name), tmp)
+        text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    out: List[tuple] = []
+    inside, base = False, 0
+    for ln in text.splitlines():
+        m = re.match(r"^([0-9a-f]+) <(\S+)>:", ln)
+        if m:
+            if inside:
+                break
+            inside, base = kernel_substring in m.group(2), int(m.group(1), 16)
+            continue
+        if inside and ln.startswith("\t"):
+            body, _, comment = ln.partition("//")
+            a = re.match(r"\s*([0-9A-Fa-f]+):", comment)
+            t = re.search(r"<[^>]*\+0x([0-9a-f]+)>\s*$", comment)
+            out.append((int(a.group(1), 16) if a else -1, body.strip(), base + int(t.group(1), 16) if t else None))
+    return out
+
+
+def _vgprs(operands: str) -> set:
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operands):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", operands))
+    return regs
+
+
+def untracked_load_hazards(isa: List[tuple]) -> List[str]:
+    """Instructions that touch the destination registers of a vector-memory load before an `s_waitcnt vmcnt(n)` has retired
+    it - ADVICE r3 (medium): the fp32-A four-phase GEMM issues its A loads by inline asm, so the compiler believes their
+    registers defined at the asm statement while the data lands behind the hand-counted wait; a copy / re-materialisation the
+    register allocator placed in between would read stale data and nothing else would notice.  The check walks the layout
+    order once (forward branches fall through: both sides are seen) and the body of every loop (backward branch) a second
+    time with the in-flight state of the first trip carried over; loads retire in order and `vmcnt(n)` leaves the n newest
+    vector-memory operations (LDS-DMA and stores included) outstanding."""
+    hazards: List[str] = []
+    pending: list = []     # (text, destination VGPRs) of the vector-memory operations not yet retired, oldest first
+
+    def step(text: str) -> None:
+        mnem, _, ops = text.partition(" ")
+        if mnem == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", ops)
+            if m:
+                del pending[:max(0, len(pending) - int(m.group(1)))]
+            return
+        in_flight = set().union(*[r for _t, r in pending]) if pending else set()
+        vmem = mnem.startswith(("global_load", "global_store", "buffer_load", "buffer_store", "flat_load", "flat_store", "global_atomic",
+                                "scratch_load", "scratch_store"))
+        used = _vgprs(ops)
+        if vmem and "load" in mnem and "_lds_" not in mnem and not re.search(r"\blds\b", ops):
+            dst, _, rest = ops.partition(",")
+            if _vgprs(rest) & in_flight:
+                hazards.append(f"{text}   <- reads {sorted(_vgprs(rest) & in_flight)} still in flight")
+            pending.append((text, _vgprs(dst)))
+        else:
+            if used & in_flight:
+                hazards.append(f"{text}   <- touches {sorted(used & in_flight)} of {[t for t, r in pending if r & used]}")
+            if vmem:
+                pending.append((text, set()))
+
+    index = {a: k for k, (a, _t, _b) in enumerate(isa)}
+    for k, (addr, text, target) in enumerate(isa):
+        step(text)
+        if target is not None and target <= addr and target in index:     # a loop closes here: its body once more
+            for _a, t2, _b in isa[index[target]:k + 1]:
+                step(t2)
+    return hazards
+
+
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else argv
     rows = kernel_resources()

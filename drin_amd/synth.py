@@ -99,6 +99,32 @@ def make_batch(
     return seq
 
 
+def plant_gold_signal(cfg: DrinConfig, seq: List, strength: float) -> List:
+    """In place on a `make_batch` 15-sequence (numpy arrays or CPU tensors): makes the gold candidate findable, as a stand-in
+    task for training checks (the real datasets are not available offline).  The gold candidate's text rows become the
+    mention's span mean (`ghmfc.py:54-60`) plus `1 / strength` times their original noise - WikiDiverse layout: its pooled
+    row; WikiMEL layout: its token-0 row (what the text-text edge reads, `model.py:73-75`) and the tokens the pooling of
+    `ghmfc.py:245-249` averages.  Mentions whose answer row is all zero (gold not among the candidates) stay as drawn."""
+    as_np = [t.numpy() if torch.is_tensor(t) else t for t in seq]      # views: the edits land in the caller's tensors
+    text, start, end, etext, emask, answer = as_np[0], as_np[2], as_np[3], as_np[7], as_np[8], as_np[14]
+    gold = np.where(answer.any(1), answer.argmax(1), -1)
+    for i in np.nonzero(gold >= 0)[0]:
+        span = text[i, start[i]: end[i]].mean(0)
+        g = gold[i]
+        if cfg.token_level_entities:
+            ntok = int(emask[i, g].sum())
+            rows = [0] + list(range(1, max(1, ntok - 1)))
+            etext[i, g, rows] = span[None, :] + etext[i, g, rows] / strength
+        else:
+            etext[i, g] = span + etext[i, g] / strength
+    return seq
+
+
+def make_learnable_batch(cfg: DrinConfig, batch: int, seed: int, strength: float = 2.0, **kw) -> List[torch.Tensor]:
+    """`make_batch` with the gold candidate planted (`plant_gold_signal`)."""
+    return plant_gold_signal(cfg, make_batch(cfg, batch, seed, **kw), strength)
+
+
 STATE_DICT_SHAPES = lambda D, R, layers, vector=False: (  # noqa: E731 - SURVEY.md §8(b) state_dict contract
     [
         ("vertex_encoder.mention_text_encoder.final_layer.linear.weight", (D, D)),

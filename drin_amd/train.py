@@ -668,7 +668,11 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     if world > 1 or a.force_collectives:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
+            if "MASTER_PORT" not in os.environ:                        # a free port: two such runs on one host must not collide
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", device_id=dev, rank=int(os.environ.get("RANK", "0")), world_size=world)
     seed_everything(cfg.seed)
     table = None

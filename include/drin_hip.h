@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRIN_ABI_VERSION 3
+#define DRIN_ABI_VERSION 4
 #define DRIN_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -187,6 +187,13 @@ DRIN_API const char* drin_build_info(void);      /* "gfx950 <compiler> <date>"  
  * WikiDiverse geometry).  Replaces the import-time globals of common/args.py. */
 DRIN_API int drin_default_config(drin_config* cfg);
 
+/* Host-side self-checks of the library's launch-sequencing code, for the sanitizer build and CI: no kernel is launched,
+ * no GPU is needed.  Checks that the workspace layout gives the mention-sized weight-gradient group of drin_backward
+ * (train.py:33-34 through model.py:164-209) its worst-case slice scratch at every batch size, and that the grouped GEMM
+ * launchers refuse an item with an empty reduction (DRIN_E_SHAPE) instead of dividing by a slice length derived from it.
+ * DRIN_OK, or the first failing check's status with its message in drin_last_error().  No reference counterpart. */
+DRIN_API int drin_host_selftest(void);
+
 /* Bytes of device workspace drin_forward / drin_backward need for `cfg` (0 on error). */
 DRIN_API size_t drin_workspace_bytes(const drin_config* cfg, int for_training);
 
@@ -278,6 +285,16 @@ DRIN_API int drin_prepare(const drin_config* cfg, const drin_params* params, voi
 DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* batch, const drin_params* params,
                                    const void* prepared, void* workspace, size_t workspace_bytes, float* scores,
                                    void* stream);
+/* How the row-streaming kernels of the two folded paths divide a mention's candidate list for THIS call size: the number of
+ * workgroups (candidate chunks) per mention of k_entity_stream / k_pair_layer1 / k_pair_final (cached == 0:
+ * drin_forward_prepared - 16 candidates per workgroup, 48 from 1 024 mentions, the whole list up to 128 from 2 048) or of
+ * k_cached_pairs (cached != 0: drin_forward_cached - 64 candidates, 128 from 2 048 mentions; 16 off the exact widths).  The
+ * per-mention sums are grouped by these chunks, so a mention's scores in calls of different sizes agree to fp32
+ * re-association only (<= 5e-6 measured), and are the same bits every run within one call size.  Introspection for
+ * tests and benchmarks (which instantiation did this call take?); 0 when cfg is off the folded paths.  No reference
+ * counterpart. */
+DRIN_API int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached);
+
 /* Large batches in the split-bf16 precision: drin_forward_prepared cuts the batch into chunks of mentions and runs chunk
  * c + 1's pass over the entity bytes (HBM-bound) on `stream_cus` of the CUs while chunk c's contractions (MFMA-bound) run on
  * the others - two internal streams created with hipExtStreamCreateWithCUMask, forked from and joined to `stream` by

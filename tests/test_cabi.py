@@ -184,6 +184,22 @@ def test_activation_ids_are_validated_on_host():
     assert lib.drin_workspace_bytes(C.byref(c), 1) == 0
 
 
+def test_host_selftest_layout_scratch_and_empty_reductions():
+    """`drin_host_selftest` (runs under the ASan / UBSan build through the test below): the slice scratch of the mention-sized
+    weight-gradient group covers its worst case at every batch size (exact fp32 at 1024 < B N <= 2048 got none),
+    and a grouped GEMM launch handed an item with an empty reduction - what round 3's staged backward once did, SIGFPE on the
+    host - answers DRIN_E_SHAPE instead of dividing by the slice length it would derive from it."""
+    lib = _lib.load()
+    assert lib.drin_host_selftest() == _lib.OK, lib.drin_last_error()
+    # the window ADVICE r3 names, through the public size query: WikiMEL widths, exact fp32, B = 16 (M = 1 616 <= 2 048 < 2 M):
+    # the entity side's single-type products (dW_h of the top layer, the two entity encoders) store four slices each
+    c = _lib.DrinConfigC()
+    lib.drin_default_config(C.byref(c))
+    c.batch, c.num_candidates, c.entity_tokens, c.precision = 16, 101, 8, _lib.PREC_F32
+    D, R = c.embed_dim, c.image_dim
+    assert lib.drin_workspace_bytes(C.byref(c), 1) >= 4 * 4 * (5 * D * D + D * R)
+
+
 def test_adam_entry_point_validates_on_host():
     lib = _lib.load()
     one = C.c_void_p(16)

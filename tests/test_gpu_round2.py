@@ -245,8 +245,8 @@ def million_entity_table():
 
 @pytest.mark.parametrize("path", ["fused", "cache", "exact_f32"])
 def test_config5_full_width_against_the_oracle(million_entity_table, path):
-    """N = 1001 candidates per mention gathered from a 1 000 003-row table at D = 768 / R = 2048 (63 chunks of 16
-    candidates in k_entity_stream, entity_index up to 2^20, k_cached_pairs over 23.5 KB cache rows): three mentions'
+    """N = 1001 candidates per mention gathered from a 1 000 003-row table at D = 768 / R = 2048 (workgroups of 16
+    candidates in k_entity_stream at this call size, entity_index up to 2^20, k_cached_pairs over 23.5 KB cache rows): three mentions'
     slices against the CPU oracle on the gathered rows; the remaining mentions against each other across paths."""
     cfg, table = million_entity_table
     sd = synth.make_state_dict(cfg, 7)
@@ -277,6 +277,55 @@ def test_config5_full_width_against_the_oracle(million_entity_table, path):
         plain.load_state_dict(sd)
         with torch.no_grad():
             assert (plain(ib) - got).abs().max().item() <= 1e-5         # every mention: cached == un-cached
+
+
+def test_config5_timed_instantiation_128_candidate_workgroups(million_entity_table):
+    """`bench.py`'s config-5 leg scores chunks of 4 096 mentions, where a workgroup of `k_cached_pairs` /
+    `k_pair_final` walks 128 candidates (`csrc/entity_cache.hip` cached_chunk_default: B >= 2 048) - every other full-width test
+    of the cached path stayed at B = 37 (64-candidate workgroups).  B = 2 048 x N = 1 001 on the 1 000 003-row table through the
+    per-entity cache: mentions (first, middle, last) against the CPU oracle on the gathered rows, <= 1e-5, and against the
+    same mentions scored in a small call (64-candidate workgroups), <= 5e-6."""
+    import os
+    cfg, table = million_entity_table
+    lib = _lib.load()
+    sd = synth.make_state_dict(cfg, 7)
+    B, N, E = 2048, cfg.num_candidates_model, table.num_entities
+
+    def cfg_c(batch):
+        c = _lib.DrinConfigC()
+        _lib.check(lib.drin_default_config(C.byref(c)))
+        c.batch, c.num_candidates, c.precision, c.num_entities = batch, N, _lib.PREC_BF16X3, E
+        return c
+
+    assert lib.drin_workgroups_per_mention(C.byref(cfg_c(B)), 1) == 8            # ceil(1001 / 128)
+    assert lib.drin_workgroups_per_mention(C.byref(cfg_c(37)), 1) == 16          # ceil(1001 / 64)
+    g = torch.Generator(device=DEV).manual_seed(17)
+    men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 18, DEV)
+    cand = torch.randint(0, E, (B, N), device=DEV, generator=g)
+    sims = 20.0 + 5.0 * torch.randn(2, B, N, device=DEV, generator=g)
+    ib = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    table.enable_cache(True)
+    try:
+        with torch.no_grad():
+            _lib.profile_begin()
+            got = model(ib)
+            prof = _lib.profile_end()
+            assert prof["stream"][1] == 1 and prof["gemm_planes"][1] >= 1       # k_cached_pairs once, et' W_h2^T on planes
+            assert got.shape == (B, N) and torch.isfinite(got).all() and torch.equal(got, model(ib))
+            worst = small = 0.0
+            torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+            for rows in ([0, 1], [B // 2, B // 2 + 1], [B - 2, B - 1]):
+                sub = IndexedBatch([t[rows] for t in men[:7]], table, cand[rows], sims[0][rows], sims[1][rows])
+                ref = O.forward(sd, [t.cpu() for t in sub.gathered()])
+                worst = max(worst, (got[rows].cpu() - ref).abs().max().item())
+                assert (got[rows, :-1].argmax(1).cpu() == ref[:, :-1].argmax(1)).all()
+                small = max(small, (got[rows] - model(sub)).abs().max().item())
+    finally:
+        table.enable_cache(False)
+    print(f"config 5, B = 2048 through the cache: max |score - oracle| {worst:.2e}, against the small call {small:.2e}")
+    assert worst <= 1e-5 and small <= 5e-6
 
 
 def test_table_edits_and_data_writes_are_seen_or_can_be_declared():

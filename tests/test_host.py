@@ -301,3 +301,34 @@ def test_no_kernel_uses_scratch():
            if k.get("private_segment_fixed_size", 0) or k.get("vgpr_spill_count", 0)]
     assert not bad, f"kernels with scratch / spilled VGPRs: {bad}"
     assert all(k.get("vgpr_count", 0) <= 256 for k in rows)
+
+
+def test_untracked_loads_are_not_touched_before_their_counted_wait():
+    """`k_gemm_bf16x3_p4` fetches its fp32 A units by inline-asm `global_load_dwordx4` whose data lands
+    behind a hand-counted `s_waitcnt vmcnt(4)`; the compiler believes the registers defined at the asm statement.  The
+    generated gfx950 ISA is checked instead of trusted: no instruction between a vector-memory load and the wait that retires
+    it may read or write the load's destination registers (layout order + every loop body a second time).  The same walk
+    over the other hand-pipelined kernels, and over a synthetic sequence with exactly that slip, which it must flag."""
+    from drin_amd import build, resources
+    build.build(verbose=False)
+    for obj, kernel, min_insns in (("gemm_x3_planes.o", "k_gemm_bf16x3_p4", 1000), ("gemm_x3_planes.o", "k_gemm_x3_planes_p4", 800),
+                                   ("gemm_bf16x3.o", "k_gemm_bf16x3", 1000), ("gemm_tn_bf16x3.o", "k_gemm_tn", 500),
+                                   ("fused_kernels.o", "k_entity_stream", 1000), ("entity_cache.o", "k_cached_pairs", 1000)):
+        isa = resources.kernel_isa(obj, kernel)
+        assert len(isa) >= min_insns, (obj, kernel, len(isa))
+        assert any(t.startswith("v_mfma") for _a, t, _b in isa) or "gemm" not in kernel
+        hazards = resources.untracked_load_hazards(isa)
+        assert not hazards, f"{kernel}: {hazards[:4]}"
+    p4 = resources.kernel_isa("gemm_x3_planes.o", "k_gemm_bf16x3_p4")
+    loops = [(a, b) for a, _t, b in p4 if b is not None and b <= a]
+    mfmas = lambda ab: sum(t.startswith("v_mfma") for a, t, _b in p4 if ab[1] <= a <= ab[0])   # noqa: E731
+    main = max(loops, key=mfmas)                                          # the K loop: four phases of counted waits
+    body = [t for a, t, _b in p4 if main[1] <= a <= main[0]]
+    assert sum(t.startswith("s_waitcnt vmcnt(4)") for t in body) == 4 and sum(t == "s_barrier" for t in body) == 8
+    assert sum(t.startswith("global_load_dwordx4") for t in body) == 4 and sum(t.startswith("global_load_lds_dwordx4") for t in body) == 4
+    assert sum(t.startswith("v_mfma_f32_16x16x32_bf16") for t in body) == 96
+    fake = [(0, "global_load_dwordx4 v[6:9], v[162:163], off", None), (8, "global_load_lds_dwordx4 v[10:11], off", None),
+            (16, "s_waitcnt vmcnt(1)", None), (20, "v_mov_b32_e32 v20, v6", None),          # retired: fine
+            (24, "global_load_dwordx4 v[6:9], v[162:163], off", None), (32, "v_mov_b32_e32 v21, v7", None),   # copied too early
+            (36, "s_waitcnt vmcnt(0)", None), (40, "v_mov_b32_e32 v21, v7", None)]
+    assert len(resources.untracked_load_hazards(fake)) == 1

@@ -51,6 +51,7 @@ def test_headline_code_path_at_full_width(B, groups):
     batch = synth.make_device_batch(cfg, B, 21, DEV)[:14]
     _threads()
     with torch.no_grad():
+        model(batch[:14] if B <= 8 else [t[:8] for t in batch])       # folds the weights (exact-fp32 products, once per weight version)
         _lib.profile_begin()
         out = model(batch)
         prof = _lib.profile_end()
@@ -162,8 +163,11 @@ def test_training_trajectory_at_reference_width_tracks_the_oracle_adam_loop():
     worst = max(abs(a - b) for a, b in curve)
     print(f"30 steps: worst per-step |loss hip - loss oracle| {worst:.2e}; held-out hip {hip} oracle {ora}; max |held-out score diff| {dscore:.2e}")
     assert curve[-1][1] < 0.35 * curve[0][1], "the oracle's own loop did not learn: the comparison would be vacuous"
-    assert worst <= 2e-3, worst                                        # measured: see DESIGN.md section 5
-    assert abs(hip["loss"] - ora["loss"]) <= 2e-3
-    assert ora["topk"][1] >= 40                                         # of 128: learnt (1-3 before training)
-    for k in (1, 5):
-        assert abs(hip["topk"][k] - ora["topk"][k]) <= 2, (k, hip, ora)
+    # measured on MI355X (profiles/r4_new_tests_first_run.txt): worst per-step difference 6.9e-6 (growing from 1e-7 as Adam's
+    # division by sqrt(v) amplifies the 1e-5-relative gradient differences of the split-bf16 contractions), held-out loss
+    # 0.0398390 against 0.0398395, top-1 69 = 69 and top-5 98 = 98 of 128, held-out scores within 6.7e-4 of each other
+    assert worst <= 1e-4, worst
+    assert abs(hip["loss"] - ora["loss"]) <= 1e-4
+    assert ora["topk"][1] >= 40                                         # of 128: learnt (1 before training)
+    for k in (1, 5):                                                    # equal when measured; one near-tie of slack
+        assert abs(hip["topk"][k] - ora["topk"][k]) <= 1, (k, hip, ora)

@@ -34,6 +34,8 @@ namespace drin {
 
 // side-by-side phases (below): off until measured; DRIN_PIPE / drin_set_pipeline choose
 constexpr int kPipeDefaultStreamCus = 0, kPipeDefaultChunkPairs = 51712;
+// DRIN_PREC_BF16X3_I1: the shortest candidate list whose mean averages the one-pass image contraction's noise far enough
+constexpr int kMixedMinCandidates = 64;
 
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
@@ -83,7 +85,8 @@ struct FusedLayout {  // workspace offsets in floats
     s2_part = take(B * chunks * 2 * D);
     agg2 = take(B * D);
     mt2 = take(B * D);
-    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16;
+    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16 ||
+                        c.precision == DRIN_PREC_BF16X3_I1;
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
     p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
@@ -256,7 +259,13 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   // DRIN_PREC_BF16: the three pair-sized contractions run one bf16 MFMA pass (operands rounded to bf16, no lo planes);
   // everything mention-sized keeps the split-bf16 / exact-fp32 arithmetic of DRIN_PREC_BF16X3
   const bool one_pass = cfg->precision == DRIN_PREC_BF16;
-  const int prec = one_pass ? (int)DRIN_PREC_BF16X3 : cfg->precision;
+  // DRIN_PREC_BF16X3_I1, precision by contraction: only x_i C_i^T runs one pass - its result, the layer-1 entity image
+  // vertex, reaches the score through a mean over the N candidates alone (model.py:124-129,143-144), which averages the
+  // rounding noise down: 1.7-2.5e-5 on the scores at N = 101 against 3e-4 for either D x D contraction (oracle/
+  // precision_emulation.py; tests/test_gpu_round4.py).  At N = 11 the averaging is sqrt(11): 5-10e-5, no margin under the
+  // 1e-4 bar - lists shorter than kMixedMinCandidates keep three passes (then the mode IS split-bf16, bit for bit).
+  const bool i1 = cfg->precision == DRIN_PREC_BF16X3_I1 && cfg->num_candidates >= kMixedMinCandidates;
+  const int prec = (one_pass || cfg->precision == DRIN_PREC_BF16X3_I1) ? (int)DRIN_PREC_BF16X3 : cfg->precision;
   const bool dyn = cfg->dynamic_edges != 0;
   const bool tokens = cfg->entity_tokens > 0;
   // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
@@ -388,7 +397,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
     sa.xt_lo = (xt_exact || one_pass) ? nullptr : xt_hi + MD;
     if (xi_planes) {
       sa.xi_hi = xi_hi;
-      sa.xi_lo = (bf16_feat || one_pass) ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
+      sa.xi_lo = (bf16_feat || one_pass || i1) ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
     }
   }
   sa.e0m = ws + L.e0m;
@@ -435,15 +444,16 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
     DRIN_TRY(launch_gemm_x3_planes(xt_hi, (xt_exact || one_pass) ? nullptr : xt_hi + MD, D, ct,
                                    one_pass ? nullptr : ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st, psk, pskf));
+    const bool xi_one = one_pass || i1;   // x_i C_i^T in one pass
     if (xi_planes)
-      DRIN_TRY(launch_gemm_x3_planes(xi_hi, (bf16_feat || one_pass) ? nullptr : xi_hi + MR, R, ci,
-                                     one_pass ? nullptr : ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st, psk, pskf));
+      DRIN_TRY(launch_gemm_x3_planes(xi_hi, (bf16_feat || xi_one) ? nullptr : xi_hi + MR, R, ci,
+                                     xi_one ? nullptr : ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st, psk, pskf));
     else if (bf16_feat)  // the bf16 image rows are read in place as the (only) plane of the A operand
-      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, one_pass ? nullptr : ci + (size_t)D * R, R, nullptr,
+      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, xi_one ? nullptr : ci + (size_t)D * R, R, nullptr,
                                      ws + L.h_image, D, M, D, R, st, psk, pskf));
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
-                                     ci + (size_t)D * R, false, one_pass && cdiv(M, 256) * cdiv(D, 256) >= 192,
+                                     ci + (size_t)D * R, false, xi_one && cdiv(M, 256) * cdiv(D, 256) >= 192,
                                      psk, pskf));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
@@ -554,8 +564,8 @@ static PipePlan pipe_plan(const drin_config& c) {
     if (cus < 0) cus = e_cus;
     if (chunk_pairs < 0) chunk_pairs = e_pairs;
   }
-  const bool planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL) && c.embed_dim % 32 == 0 &&
-                      c.image_dim % 32 == 0;
+  const bool planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16X3_I1) &&
+                      c.embed_dim % 32 == 0 && c.image_dim % 32 == 0;
   if (cus <= 0 || cus >= 256 || chunk_pairs < 4096 || !planes) return p;
   int per = (int)std::max<int64_t>(1, chunk_pairs / c.num_candidates);
   if (per >= 256) per -= per % 256;   // whole 256-row tiles of the mention-sized products

@@ -61,6 +61,12 @@ class GCNLayer(nn.Module):  # drin/model.py:109-119 (scaler edges: w_m is Identi
         self.layer_norm = nn.LayerNorm(d)
 
 
+# precisions that are modes of the fused inference path only: whatever else they meet (training, the per-entity cache,
+# geometries off the fused path, traced forwards) runs split-bf16
+_FUSED_ONLY = (_lib.PREC_BF16, _lib.PREC_BF16X3_I1)
+_PLANES = (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16, _lib.PREC_BF16X3_I1)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -512,7 +518,10 @@ class Model(nn.Module):
         `precision`: "bf16x3" (default: split-bf16 MFMA, fp32-equivalent - measured <= 1.4e-6 on the scores against the
         reference's fp32 forward, bar 1e-4; 2x the rate of exact fp32), "f32" (exact fp32 MFMA) or "bf16" (opt-in: the
         pair-sized contractions of the fused inference path in ONE bf16 MFMA pass - score error ~6e-4, outside the
-        1e-4 bar; training and every other path then run "bf16x3");
+        1e-4 bar; training and every other path then run "bf16x3") or "bf16x3_i1" (precision by contraction: split-bf16 except
+        the folded entity-image contraction, which runs one bf16 pass where the candidate list is long enough - N >= 64 - for
+        the mean over candidates behind it to average its rounding noise down: <= 2.5e-5 on the scores at N = 101, inside the
+        1e-4 bar; shorter lists and every other path run "bf16x3");
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;
         `grad_bucket`: backward writes every gradient into one flat bucket the `.grad`s are views of (like DDP's
         `gradient_as_bucket_view`: a `.grad` kept across `zero_grad(set_to_none=True)` + `backward()` is overwritten)."""
@@ -529,7 +538,7 @@ class Model(nn.Module):
         self._layout = None
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL,
-                          "bf16": _lib.PREC_BF16}[precision]
+                          "bf16": _lib.PREC_BF16, "bf16x3_i1": _lib.PREC_BF16X3_I1}[precision]
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 
@@ -633,7 +642,7 @@ class Model(nn.Module):
             # table form: inference gathers inside the stream kernel; everything else (training,
             # exact-fp32 precision, geometries off the fused path) gathers with torch indexing first
             inference = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
-            planes = self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16)
+            planes = self.precision in _PLANES
             t = batch.table
             if inference and self._prepared is not None and self.cfg.num_gcn_layers == 2 and (planes or t.cache_enabled):
                 seq = batch.mention + [t.text, t.mask, t.image, t.object, t.object_score,
@@ -641,7 +650,7 @@ class Model(nn.Module):
                 if t.cache_enabled and t.text.dtype == torch.bfloat16:
                     raise ValueError("the per-entity cache is built from fp32 tables; give EntityTable fp32 features")
                 # bf16-stored features are read in place by the fused path (never widened: the table is large)
-                prec = _lib.PREC_BF16X3 if (t.cache_enabled and self.precision == _lib.PREC_BF16) else self.precision
+                prec = _lib.PREC_BF16X3 if (t.cache_enabled and self.precision in _FUSED_ONLY) else self.precision
                 call = _Call(self.cfg, seq, prec, entity_index=batch.candidates, keep_bf16=planes and not t.cache_enabled)
                 if _lib.load().drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
                     if t.cache_enabled:                                # per-entity precompute cache
@@ -665,9 +674,9 @@ class Model(nn.Module):
         # features stored as bf16 are read in place by the fused inference path in split-bf16 precision; every
         # other path (training, exact fp32, geometries off the fused path) gets them widened to fp32 - exact
         in_place = (not training and self._prepared is not None and self.cfg.num_gcn_layers == 2
-                    and self.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16))
+                    and self.precision in _PLANES)
         # "bf16" is a mode of the fused inference path; anything else it meets runs split-bf16
-        prec = self.precision if (in_place or self.precision != _lib.PREC_BF16) else _lib.PREC_BF16X3
+        prec = self.precision if (in_place or self.precision not in _FUSED_ONLY) else _lib.PREC_BF16X3
         if (cls is None and training and len(batch) >= 14 and batch[7].dtype == torch.bfloat16 and batch[7].dim() == 4
                 and batch[7].is_cuda and batch[7].shape[0] > 0):
             # a training step on bf16-stored token blocks: pooled in place by the library - half
@@ -678,14 +687,14 @@ class Model(nn.Module):
             cls = etf[:, :, 0, :]
         if cls is not None:
             # pooled-ahead batch: the layer-by-layer entry points (the fused path folds the pooling into its one pass)
-            call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec, entity_text_cls=cls)
+            call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec in _FUSED_ONLY else prec, entity_text_cls=cls)
             if call.B == 0:
                 return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
             return self._score(call, None, training, *params)
         call = _Call(self.cfg, batch, prec, keep_bf16=in_place)
-        if ((call.cfg.feature_dtype != _lib.FEAT_F32 or prec == _lib.PREC_BF16)
+        if ((call.cfg.feature_dtype != _lib.FEAT_F32 or prec in _FUSED_ONLY)
                 and _lib.load().drin_fused_supported(C.byref(call.cfg)) != _lib.OK):
-            call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec == _lib.PREC_BF16 else prec)
+            call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if prec in _FUSED_ONLY else prec)
         if call.B == 0:
             return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
         return self._score(call, self._prepared, training, *params)
@@ -721,7 +730,7 @@ class Model(nn.Module):
         when the library builds it for this geometry (`indexed_supported` in csrc/api.hip); None: gather the rows."""
         t, cand = batch.table, batch.candidates
         D, R = self.cfg.bert_embed_dim, self.cfg.resnet_embed_dim
-        ok = (planes and self.precision != _lib.PREC_BF16 and self.cfg.gcn_edge_feature != "vector"
+        ok = (planes and self.cfg.gcn_edge_feature != "vector"
               and t.text.dtype == torch.float32 and t.image.dtype == torch.float32 and t.object.dtype == torch.float32
               and cand.numel() >= 1024 and cand.shape[0] <= 65535 and D % 32 == 0 and R % 32 == 0 and D >= 128
               and 128 <= R <= 2048 and t.object.shape[1] == 1 and t.image.dim() in (2, 3) and t.object.dim() in (3, 4)
@@ -733,7 +742,8 @@ class Model(nn.Module):
         seq = batch.mention + [pooled, dummy, t.image, t.object, t.object_score, batch.miet_similarity, batch.mtei_similarity]
         # the layer-by-layer kernels trust the index (the stream kernel of the fused path clamps it): clamp here, so that a
         # bad candidate row can never become an out-of-bounds read on the device
-        return _Call(self.cfg, seq, self.precision, entity_index=cand.clamp(0, t.num_entities - 1), entity_text_cls=cls)
+        prec = _lib.PREC_BF16X3 if self.precision in _FUSED_ONLY else self.precision
+        return _Call(self.cfg, seq, prec, entity_index=cand.clamp(0, t.num_entities - 1), entity_text_cls=cls)
 
     @torch.no_grad()
     def _forward_cached(self, call: _Call, table: EntityTable, params) -> torch.Tensor:
@@ -760,7 +770,7 @@ class Model(nn.Module):
         """Scores plus every stage's vertices and edges (tests / debugging)."""
         lib = _lib.load()
         self.wait_for_parameters()
-        call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if self.precision == _lib.PREC_BF16 else self.precision)
+        call = _Call(self.cfg, batch, _lib.PREC_BF16X3 if self.precision in _FUSED_ONLY else self.precision)
         params = tuple(p.detach().contiguous() for p in _param_list(self))
         pc = _lib.DrinParamsC()
         _fill_params(pc, params, call.per_layer)

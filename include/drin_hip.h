@@ -50,8 +50,17 @@ typedef enum {
                            rounded to bf16, ONE MFMA pass (BASELINE's "bf16 inference").  Measured score error
                            ~6e-4: OUTSIDE the 1e-4 bar of the path - never a default; mention-sized work keeps the
                            BF16X3 arithmetic.  Other entry points return DRIN_E_UNSUPPORTED for it. */
-  DRIN_PREC_BF16X3_ALL = 3 /* BF16X3 also for the mention-sized contractions that BF16X3 leaves on
+  DRIN_PREC_BF16X3_ALL = 3, /* BF16X3 also for the mention-sized contractions that BF16X3 leaves on
                               the fp32 kernel for latency reasons (used by the parity tests)      */
+  DRIN_PREC_BF16X3_I1 = 4  /* drin_forward_prepared only: precision BY CONTRACTION.  BF16X3 everywhere except the
+                              folded entity-image contraction x_i (W_h1 W_ei)^T - 57 % of the path's FLOPs - which runs
+                              ONE bf16 MFMA pass (operands rounded, no lo planes).  Its result feeds only the layer-1
+                              entity IMAGE vertex, which reaches the score through mean_n(ti' ei') in the layer-2
+                              mention vertex alone (model.py:124-129,143-144; vertex graph :105): the rounding noise is
+                              averaged over the N candidates before it meets the score.  Measured at N = 101: max
+                              |score - fp32 reference| <= 2.5e-5 (bar 1e-4), top-1 unchanged; taken only for
+                              num_candidates >= 64 - shorter lists (N = 11: 5-10e-5, no margin) keep three passes and
+                              equal BF16X3 bit for bit.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
 } drin_precision;
 
 /* Geometry + switches of one forward.  Names follow common/args.py. */

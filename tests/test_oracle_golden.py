@@ -143,3 +143,25 @@ def test_mention_independence():
     full = O.forward(sd, batch)
     sub = O.forward(sd, [t[2:5] for t in batch])
     np.testing.assert_allclose(full[2:5].numpy(), sub.numpy(), atol=1e-6)
+
+
+def test_precision_by_contraction_emulation():
+    """VERDICT r3 item 2, the emulation reproduced (oracle/precision_emulation.py: the oracle in fp64, the operands of ONE
+    folded contraction rounded to bf16, everything else exact; WikiMEL-shaped, N = 101): the entity-image contraction in one
+    pass moves the scores by ~2e-5 - its result meets the score through a mean over the candidates - while either D x D
+    contraction moves them by ~3e-4, outside the 1e-4 bar.  That asymmetry is what `precision="bf16x3_i1"` is built on."""
+    import torch
+    from drin_amd import synth
+    from drin_amd.config import wikimel_config
+    from oracle.precision_emulation import contraction_errors, scores_with_rounded_contraction
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    batch = synth.make_device_batch(cfg, 12, 5, "cpu")
+    exact = scores_with_rounded_contraction(sd, batch)
+    assert (exact - O.forward(sd, batch[:14], dtype=torch.float64)).abs().max().item() == 0.0     # the replay IS the oracle
+    err = contraction_errors(sd, batch, cases=(("image", "one"), ("image", "two_a"), ("text", "one"), ("wh2", "one"), ("image", "x3")))
+    print(err)
+    assert err["image:one"]["max"] <= 3e-5 and err["image:one"]["top1_flips"] == 0
+    assert err["image:two_a"]["max"] <= err["image:one"]["max"] * 1.2                 # a second pass buys little: one pass it is
+    assert err["text:one"]["max"] >= 1e-4 and err["wh2:one"]["max"] >= 1e-4           # the D x D contractions have no such margin
+    assert err["image:x3"]["max"] <= 1e-6

@@ -54,8 +54,11 @@ def asan_runtime() -> str:
     return out
 
 
-def build(force: bool = False, debug: bool = False, verbose: bool = True, asan_host: bool = False) -> str:
-    obj_dir = os.path.join(CSRC, "build_asan" if asan_host else "build")
+def build(force: bool = False, debug: bool = False, verbose: bool = True, asan_host: bool = False, variant: str = "") -> str:
+    """`variant`: a second build of the library next to the shipped one - objects under csrc/build_<variant>, the library as
+    libdrin_hip_<variant>.so - for same-box A/Bs of a compile-time switch (DRIN_EXTRA_FLAGS="-D..." python -m drin_amd.build
+    --variant NAME; select it at run time with DRIN_LIB_PATH)."""
+    obj_dir = os.path.join(CSRC, "build_asan" if asan_host else ("build_" + variant if variant else "build"))
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     flags = [f"--offload-arch={ARCH}", "-O1" if asan_host else "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -97,11 +100,12 @@ def build(force: bool = False, debug: bool = False, verbose: bool = True, asan_h
         list(ex.map(run, jobs))
     with open(stamp, "w") as f:
         f.write(want)
-    lib = ASAN_LIB if asan_host else LIB
+    lib = ASAN_LIB if asan_host else (os.path.join(HERE, f"libdrin_hip_{variant}.so") if variant else LIB)
     if jobs or not os.path.exists(lib):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + (SAN_FLAGS[:2] + ["-shared-libsan"] if asan_host else []) + objs)
     return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, debug="--debug" in sys.argv, asan_host="--asan-host" in sys.argv))
+    variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, debug="--debug" in sys.argv, asan_host="--asan-host" in sys.argv, variant=variant))

@@ -32,6 +32,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 namespace x3 {
 
 constexpr int BK = 32;
+#ifdef DRIN_X3_DRAIN
+constexpr bool kDrainEveryBlock = true;    // probe build (A/B): __syncthreads() at every K-block boundary, as up to round 3
+#else
+constexpr bool kDrainEveryBlock = false;
+#endif
 constexpr unsigned kCUs = 256;  // MI355X: the tail split below only changes how the last round of tiles is dealt
 
 // MFMA shape v_mfma_f32_16x16x32_bf16 (one k-step per K-block; +5 % over 32x32x16 at the clock the chip
@@ -45,13 +50,16 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) { split
 // ROWS x 32 floats staged by THREADS threads: thread t loads float4 #(t & 7) of rows (t >> 3) + (THREADS/8) i.
 // Loads are unconditional (no exec-masked branches in the K loop): rows past the end are clamped to the
 // last row - their products land in output rows / columns that are never stored - and K % 32 == 0.
-template <int ROWS, int THREADS>
+// KSUB = 2 (the one-pass kernel): a K-block is 64 floats per row - two sub-blocks of 32, loaded together (v, v2) and
+// stored ROUNDED to bf16 into what the split product calls the hi and the lo plane (see k_gemm_bf16x3 ONE_PASS).
+template <int ROWS, int THREADS, int KSUB = 1>
 struct Stager {
   static constexpr int RPP = THREADS / 8;  // rows per pass
   static constexpr int PASSES = (ROWS + RPP - 1) / RPP;   // (a last, partly used pass: its surplus rows are loaded clamped and not stored)
   static constexpr bool RAGGED = (ROWS % RPP) != 0;
   const float* p[PASSES];
   float4 v[PASSES];
+  float4 v2[KSUB == 2 ? PASSES : 1];
 
   // (index: row m of the operand is row index[m] of a table - table-form training gathers the vertex-encoder inputs here)
   __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
@@ -68,6 +76,25 @@ struct Stager {
   __device__ __forceinline__ void load(int k0) {
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) v[i] = ld4(p[i] + k0);
+    if (KSUB == 2) {
+#pragma unroll
+      for (int i = 0; i < PASSES; ++i) v2[i] = ld4(p[i] + k0 + BK);
+    }
+  }
+  // one-pass form: sub-block 0 rounded into the first plane, sub-block 1 into the second
+  __device__ __forceinline__ void store_rounded(char* __restrict__ plane0, char* __restrict__ plane1) const {
+    const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      if (RAGGED && r + RPP * i >= ROWS) continue;
+      const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
+      bf16x4 a, b;
+      const float4 x = v[i], y = v2[KSUB == 2 ? i : 0];
+      a[0] = (__bf16)x.x, a[1] = (__bf16)x.y, a[2] = (__bf16)x.z, a[3] = (__bf16)x.w;
+      b[0] = (__bf16)y.x, b[1] = (__bf16)y.y, b[2] = (__bf16)y.z, b[3] = (__bf16)y.w;
+      *reinterpret_cast<bf16x4*>(plane0 + off) = a;
+      *reinterpret_cast<bf16x4*>(plane1 + off) = b;
+    }
   }
   // registers -> (hi plane, lo plane): float4 #c4 of a row is the 8-byte half (c4 & 1) of chunk c4 >> 1
   template <bool WITH_LO = true>
@@ -109,13 +136,15 @@ struct PlaneDma {
       lds_off[i] = plane * ROWS * 64 + pr * 1024;
     }
   }
-  template <bool WITH_LO = true>
+  // (KB_BYTES: bytes of one plane row a K-block advances by - 64, or 128 in the one-pass kernel, whose two "planes" are the
+  //  two 32-wide sub-blocks of a 64-wide K-block of the ONE weight plane: init(hi, hi + 32, ...))
+  template <bool WITH_LO = true, int KB_BYTES = BK * 2>
   __device__ __forceinline__ void issue(char* planes_base, int kb) const {
     const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       if (!WITH_LO && (wave * PIECES + i) >= ROWS / 16) continue;  // second half of the pieces is the lo plane
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)kb * (BK * 2)), (lptr_t)(planes_base + lds_off[i]), 16,
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)kb * KB_BYTES), (lptr_t)(planes_base + lds_off[i]), 16,
                                        0, 0);
     }
   }
@@ -130,7 +159,12 @@ struct Cfg {
   static constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 16 x 16 MFMA tiles per wave
 };
 
-// ONE_PASS (DRIN_PREC_BF16): operands rounded to bf16, hi x hi only - a third of the MFMAs, no lo planes staged.
+// ONE_PASS (DRIN_PREC_BF16, and the image contraction of DRIN_PREC_BF16X3_I1): operands rounded to bf16, one MFMA pass.  A
+// K-block is then 64 wide: its two 32-wide sub-blocks take the LDS planes the split product gives to hi and lo, and a
+// 16 x 16 tile takes two MFMAs per K-block (sub-block 0, sub-block 1 - the same k order as 32-wide blocks, the same bits).
+// With 32-wide blocks an iteration held a third of the split product's MFMAs but the same barrier and the same one-block
+// prefetch distance: ~1 000 cycles of matrix work to hide ~3 000 of HBM latency behind (x_i C_i^T: 2.7 ms against 3.9 in
+// three passes); at 64 the iteration is two thirds of the split product's, with twice the bytes in flight.
 // Tail split: the last, partly filled round of workgroups (tiles [full, tiles), fewer than half the CUs) is dealt as
 // `ksplit` work items per tile, each over 1 / ksplit of K.  Part 0 stores to C as usual, the others store raw
 // accumulators to `tail` ([tile - full][ksplit - 1][BM][BN]) and k_tail_add folds them in afterwards, in order.
@@ -177,7 +211,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
       W += k0;
     }
   }
-  const int nkb = K / BK;
+  static_assert(!ONE_PASS || W_PLANES, "the one-pass kernel streams its weight plane by LDS-DMA");
+  constexpr int KSTEP = ONE_PASS ? 2 * BK : BK;   // floats of K per iteration
+  const int nkb = K / KSTEP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, c = lane >> 4;
@@ -190,25 +226,31 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
-  Stager<BM, G::THREADS> sa;
+  Stager<BM, G::THREADS, ONE_PASS ? 2 : 1> sa;
   Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;  // one dummy pass when the weights come by DMA
   PlaneDma<BN, WM * WN> dma;
   sa.init(A, lda, m0, M, a_index);
   if (W_PLANES)
-    dma.init(w_hi, w_lo, ldw, n0, N);
+    dma.init(w_hi, ONE_PASS ? w_hi + BK : w_lo, ldw, n0, N);
   else
     sb.init(W, ldw, n0, N);
+  auto stage_a = [&](char* buf) {
+    if (ONE_PASS)
+      sa.store_rounded(buf, buf + G::A_PLANE);
+    else
+      sa.template store<true>(buf, buf + G::A_PLANE);
+  };
 
   sa.load(0);
   if (W_PLANES)
-    dma.template issue<!ONE_PASS>(smem + 2 * G::A_PLANE, 0);
+    dma.template issue<true, KSTEP * 2>(smem + 2 * G::A_PLANE, 0);
   else
     sb.load(0);
-  sa.template store<!ONE_PASS>(smem, smem + G::A_PLANE);
+  stage_a(smem);
   if (!W_PLANES) sb.store(smem + 2 * G::A_PLANE, smem + 2 * G::A_PLANE + G::B_PLANE);
   if (nkb > 1) {  // tile 1 is in flight while tile 0 is computed
-    sa.load(BK);
-    if (!W_PLANES) sb.load(BK);
+    sa.load(KSTEP);
+    if (!W_PLANES) sb.load(KSTEP);
   }
   __syncthreads();
 
@@ -219,7 +261,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     for (int j = 0; j < G::NI; ++j) {
       const int off = swz(wn * (BN / WN) + j * 16 + r, c);
       bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + off);
-      if (!ONE_PASS) bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
+      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
     }
   };
   auto row_tiles = [&](const char* buf, int i0, int i1) {
@@ -228,8 +270,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
       if (i < i0 || i >= i1) continue;
       const int off = swz(wm * (BM / WM) + i * 16 + r, c);
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
-      bf16x8 al;
-      if (!ONE_PASS) al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
 #pragma unroll
       for (int j = 0; j < G::NI; ++j) {
         // the WEIGHT fragment is the first operand: a lane's four accumulator registers of a 16 x 16 tile are then four
@@ -238,8 +279,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
         if (!ONE_PASS) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+        } else {   // (ah, bh): k sub-block 0 of the 64-wide block, (al, bl): sub-block 1
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], al, acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -255,19 +299,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
     const bool more = kb + 1 < nkb;
 #ifndef DRIN_ABLATE_NO_LOADS   // timing ablations only (wrong results): the K-loop without its global traffic / without its MFMAs
-    if (W_PLANES && more) dma.template issue<!ONE_PASS>(nb + 2 * G::A_PLANE, kb + 1);
+    if (W_PLANES && more) dma.template issue<true, KSTEP * 2>(nb + 2 * G::A_PLANE, kb + 1);
 #endif
     load_b(buf);
 #ifndef DRIN_ABLATE_NO_MFMA
     row_tiles(buf, 0, G::MI / 2);
 #endif
     if (more) {
-      sa.template store<!ONE_PASS>(nb, nb + G::A_PLANE);
+      stage_a(nb);
       if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
 #ifndef DRIN_ABLATE_NO_LOADS
       if (kb + 2 < nkb) {
-        sa.load((kb + 2) * BK);
-        if (!W_PLANES) sb.load((kb + 2) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // (the counted wait at the end of the iteration relies on these being the newest)
+        sa.load((kb + 2) * KSTEP);
+        if (!W_PLANES) sb.load((kb + 2) * KSTEP);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #endif
     }
@@ -276,7 +322,24 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 #else
     row_tiles(buf, 0, 1);
 #endif
-    __syncthreads();  // also drains the LDS-DMA of this iteration (vmcnt(0))
+    // End of the iteration: the stage stores (LDS) and the weight DMA of block kb + 1 must have landed before anybody reads
+    // the other buffer - the register loads of block kb + 2, issued BEHIND that DMA, need not.  __syncthreads() would drain
+    // them too (its fence waits vmcnt(0)): half an iteration to cover an HBM miss, every iteration.  A counted wait keeps
+    // the INFLIGHT newest vector-memory operations - exactly those loads - outstanding across the raw barrier; the compiler's
+    // own wait in front of their first use (the next iteration's stage store) retires them.  kDrainEveryBlock: the old form.
+    if (kDrainEveryBlock || !ONE_PASS) {   // (three passes: same-box A/B inside 1 % either way - profiles/r4_one_pass_ab.txt - kept as it was)
+      __syncthreads();
+    } else {
+      constexpr int INFLIGHT = decltype(sa)::PASSES * (ONE_PASS ? 2 : 1) + (W_PLANES ? 0 : decltype(sb)::PASSES);
+      static_assert(INFLIGHT <= 60, "vmcnt is a 6-bit counter");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb + 2 < nkb)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   if (kpart > 0) {  // raw partial tile into the tail scratch
@@ -633,7 +696,9 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
       set_error("gemm_bf16x3: the one-pass (plain bf16) variant is built for pair-sized problems on weight planes");
       return DRIN_E_UNSUPPORTED;
     }
-    return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
+    if (K % (2 * x3::BK) == 0)   // 64-wide K-blocks; a reduction length that is an odd multiple of 32 keeps three passes
+      return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
+    one_pass = false;
   }
   if (tail != nullptr && !aligned16(tail)) tail = nullptr;
   // Mid-sized products (a few thousand to a few ten thousand rows: the training step at the reference's batch): 64 x 128 tiles

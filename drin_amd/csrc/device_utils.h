@@ -76,6 +76,15 @@ __device__ __forceinline__ float4 ld4_stream(const __bf16* p) {
 #endif
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
+// sixteen raw bytes (eight bf16) per lane with the streaming policy: the flat walk of bf16 token rows (fused_kernels.hip)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t ld16_stream(const char* p) {
+#ifdef DRIN_NO_NT_LOADS
+  return *reinterpret_cast<const u32x4_t*>(p);
+#else
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+#endif
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) {

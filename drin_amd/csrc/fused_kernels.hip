@@ -26,6 +26,15 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   const FT* const f_object = static_cast<const FT*>(a.entity_object);
   const FT* const f_mobj = static_cast<const FT*>(a.mobj);
   const int D4 = EXACT ? DV * 64 : a.D4, R4 = EXACT ? RV * 64 : a.R4, D = D4 * 4, R = R4 * 4;
+  // image / object rows stored as bf16: eight consecutive columns per lane and load (row_ops.h: the PAIR layout) - the sums
+  // over candidates below stay per register slot, only the helpers that meet memory know the column map
+  constexpr bool RP = sizeof(FT) == 2 && (RV % 2) == 0;
+  auto load_r = [&](const FT* row) -> Row<RV> {
+    if constexpr (RP)
+      return load_row_stream_pair<RV>(row, (int)(threadIdx.x & 63), R4);
+    else
+      return load_row_stream<RV>(row, (int)(threadIdx.x & 63), R4);
+  };
   float* l_mobj = lds;                          // [Km][R]
   float* l_q = l_mobj + a.Km * R;               // [2][R]   q_ti, q_ii
   float* l_red = l_q + 2 * R;                   // [2 D + 2 R] cross-wave reduction of the weighted sums
@@ -102,10 +111,72 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       if (stop < 0) stop += T;
       stop = stop < 0 ? 0 : (stop > T ? T : stop);
       const FT* base = f_text + e * (int64_t)T * D;
+      constexpr bool FLAT = sizeof(FT) == 2 && EXACT && DV == 3;   // the flat walk below
       const Row<DV> cls = load_row_stream<DV>(base, lane, D4);
       Row<DV> acc = zero_row<DV>();
       int t = 1;
-      if constexpr (sizeof(FT) == 2 && (EXACT || DV == 1)) {
+      if constexpr (FLAT) {
+        // bf16 token rows at D = 768: a row is 1 536 B - three 8-byte loads per lane, and 8-byte accesses move at 0.54-0.70 of
+        // the 16-byte rate (MI355X_MICROARCH.md; round 3: 4.66 TB/s here against 6.1 for the fp32 rows).  The token rows of an
+        // entity are contiguous, so TWO rows are exactly three 16-byte loads per lane with every lane busy: the pair is walked
+        // FLAT - chunk k, lane l holds elements 8 (64 k + l) .. + 7 of the 1 536 - with one accumulator set per (chunk, lane),
+        // four pairs (12 KB) in flight per wave.  First rows of the pairs land in flat positions 0 .. 95, second rows in
+        // 96 .. 191 = the same columns 32 lanes further on: one half-wave swap per candidate folds them, and a trip through this
+        // wave's own 3 KB of the (idle until the end) reduction area turns the 8-columns-per-lane order into the row layout
+        // the rest of the kernel works in.  The sum is the rows' sum in another association: first rows, second rows, then
+        // the unpaired last row (scores move by <= 2e-6 against the row-by-row order; tests/test_gpu_parity.py).
+        // (Measured and left out: the CLS row taken the same way, as the first row of a flat pair with token 1 - same-box
+        //  A/B inside the +-6 % placement spread of this kernel, eight registers more; profiles/r4_bf16_rows_ab.txt.)
+        float f0[8], f1[8], f2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f0[i] = f1[i] = f2[i] = 0.f;
+        const char* flat = reinterpret_cast<const char*>(base) + (size_t)lane * 16;
+        auto add8 = [](float (&f)[8], const u32x4_t v) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f[2 * i] += __builtin_bit_cast(float, v[i] << 16);
+            f[2 * i + 1] += __builtin_bit_cast(float, v[i] & 0xffff0000u);
+          }
+        };
+        for (; t + 8 <= stop; t += 8) {
+          u32x4_t r[4][3];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r[u][k] = ld16_stream(flat + (size_t)(t + 2 * u) * (2 * 768) + k * 1024);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            add8(f0, r[u][0]);
+            add8(f1, r[u][1]);
+            add8(f2, r[u][2]);
+          }
+        }
+        for (; t + 2 <= stop; t += 2) {
+          const u32x4_t r0 = ld16_stream(flat + (size_t)t * (2 * 768)), r1 = ld16_stream(flat + (size_t)t * (2 * 768) + 1024),
+                        r2 = ld16_stream(flat + (size_t)t * (2 * 768) + 2048);
+          add8(f0, r0);
+          add8(f1, r1);
+          add8(f2, r2);
+        }
+        // fold the second rows onto the first: flat position p + 96 is chunk (p + 96) / 64, lane (p + 32) % 64
+        float* scr = l_red + wave * 768;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float y1 = __shfl_xor(f1[i], 32), y2 = __shfl_xor(f2[i], 32);
+          f0[i] += lane < 32 ? y1 : y2;   // columns 8 lane .. + 7
+          f1[i] += y2;                    // lanes 0 .. 31: columns 512 + 8 lane .. + 7
+        }
+        st4(scr + 8 * lane, make_float4(f0[0], f0[1], f0[2], f0[3]));
+        st4(scr + 8 * lane + 4, make_float4(f0[4], f0[5], f0[6], f0[7]));
+        if (lane < 32) {
+          st4(scr + 512 + 8 * lane, make_float4(f1[0], f1[1], f1[2], f1[3]));
+          st4(scr + 512 + 8 * lane + 4, make_float4(f1[4], f1[5], f1[6], f1[7]));
+        }
+        __builtin_amdgcn_wave_barrier();   // this wave's own region: its LDS operations execute in order
+#pragma unroll
+        for (int j = 0; j < DV; ++j) acc.v[j] = ld4(scr + 4 * (lane + 64 * j));
+        __builtin_amdgcn_wave_barrier();
+      } else if constexpr (sizeof(FT) == 2 && (EXACT || DV == 1)) {
         // bf16 rows are half the bytes: twice as many of them in flight keeps the same bytes in flight per wave
         // (the pass is bound by per-CU memory latency, not by instruction issue); same left-to-right sum.
         // (Not in the guarded-column instantiation of the wide rows: with the column guards live, eight rows in flight
@@ -149,11 +220,11 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // ---- objects: weighted pair similarity (model.py:84-92) ------------------------------------------
     float sim = 0.f, wsum = 0.f;
     for (int j = 0; j < a.Ke; ++j) {
-      const Row<RV> eo = load_row_stream<RV>(f_object + (e * a.Ke + j) * R, lane, R4);
+      const Row<RV> eo = load_r(f_object + (e * a.Ke + j) * R);
       const float ny = fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps);
       const float es = a.entity_object_score[e * a.Ke + j];
       for (int i = 0; i < a.Km; ++i) {
-        const float xy = wave_sum(dot_row_lds<RV>(eo, l_mobj + i * R, lane, R4));
+        const float xy = wave_sum(dot_row_lds<RV, RP>(eo, l_mobj + i * R, lane, R4));
         const float w = a.mscore[b * a.Km + i] * es;
         sim += xy / (l_small[i] * ny) * w;
         wsum += w;
@@ -162,8 +233,8 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // the reference sums i-major, j-minor; with Ke = 1 (both datasets) the orders coincide
     const float ii = sim / (wsum + a.miei_eps);
     // ---- image row + edges ----------------------------------------------------------------------------
-    const Row<RV> xi = load_row_stream<RV>(f_image + e * R, lane, R4);
-    if (a.xi_hi) store_row_planes<RV>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
+    const Row<RV> xi = load_r(f_image + e * R);
+    if (a.xi_hi) store_row_planes<RV, RP>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
     const float e_it = (a.miet[p] / a.clip) * a.mask[2];
@@ -172,8 +243,8 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     if (dyn) {  // e' = sigmoid(mean_d(W_u(u) * W_v(v)) + e) with W_v folded into q, kappa (model.py:148-153)
       const float d_tt = wave_sum(dot_row_lds<DV>(xt, l_mt + D, lane, D4));
       const float d_it = wave_sum(dot_row_lds<DV>(xt, l_mt + 2 * D, lane, D4));
-      const float d_ti = wave_sum(dot_row_lds<RV>(xi, l_q, lane, R4));
-      const float d_ii = wave_sum(dot_row_lds<RV>(xi, l_q + R, lane, R4));
+      const float d_ti = wave_sum(dot_row_lds<RV, RP>(xi, l_q, lane, R4));
+      const float d_ii = wave_sum(dot_row_lds<RV, RP>(xi, l_q + R, lane, R4));
       n_tt = edge_act_apply(a.act_e, (d_tt + kap_tt) * inv_d + e_tt);
       n_ti = edge_act_apply(a.act_e, (d_ti + kap_ti) * inv_d + e_ti);
       n_it = edge_act_apply(a.act_e, (d_it + kap_it) * inv_d + e_it);
@@ -217,7 +288,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < RV; ++j) {
-        const int c4 = lane + 64 * j;
+        const int c4 = row_col4<RP>(lane, j);
         if (c4 < R4) {
           float* p0 = l_red + 2 * D + c4 * 4;
           float* p1 = l_red + 2 * D + R + c4 * 4;

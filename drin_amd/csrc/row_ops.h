@@ -10,6 +10,16 @@ struct Row {
   float4 v[V];
 };
 
+// Which float4 column of the row register slot jj of lane `lane` holds.  Default: lane, lane + 64, ... (one 16-byte fp32 load
+// per slot).  PAIR (rows stored as bf16): slots 2 q and 2 q + 1 are the two halves of EIGHT consecutive columns
+// 8 (lane + 64 q) .. + 7 - one 16-byte load of bf16 per pair of slots instead of two 8-byte ones (8-byte accesses move at
+// 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md).  Every helper that meets memory takes the same flag; the arithmetic
+// on whole rows (dot_rows, axpy_row) does not care.
+template <bool PAIR>
+__device__ __forceinline__ int row_col4(int lane, int jj) {
+  return PAIR ? 2 * (lane + 64 * (jj >> 1)) + (jj & 1) : lane + 64 * jj;
+}
+
 template <int V, typename T = float>
 __device__ __forceinline__ Row<V> load_row(const T* __restrict__ p, int lane, int n4) {
   Row<V> r;
@@ -31,6 +41,26 @@ __device__ __forceinline__ Row<V> load_row_stream(const T* __restrict__ p, int l
   }
   return r;
 }
+// a bf16 row in the PAIR layout: V / 2 loads of 16 bytes per lane (n4 even)
+template <int V>
+__device__ __forceinline__ Row<V> load_row_stream_pair(const __bf16* __restrict__ p, int lane, int n4) {
+  static_assert(V % 2 == 0, "the PAIR layout takes two register slots per load");
+  Row<V> r;
+#pragma unroll
+  for (int q = 0; q < V / 2; ++q) {
+    const int c8 = lane + 64 * q;
+    if (2 * c8 < n4) {
+      const u32x4_t v = ld16_stream(reinterpret_cast<const char*>(p) + (size_t)c8 * 16);
+      r.v[2 * q] = make_float4(__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xffff0000u),
+                               __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xffff0000u));
+      r.v[2 * q + 1] = make_float4(__builtin_bit_cast(float, v[2] << 16), __builtin_bit_cast(float, v[2] & 0xffff0000u),
+                                   __builtin_bit_cast(float, v[3] << 16), __builtin_bit_cast(float, v[3] & 0xffff0000u));
+    } else {
+      r.v[2 * q] = r.v[2 * q + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  return r;
+}
 template <int V>
 __device__ __forceinline__ void store_row(float* __restrict__ p, const Row<V>& r, int lane, int n4) {
 #pragma unroll
@@ -40,7 +70,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const Row<V>& r
   }
 }
 // v = hi + lo in bf16 (operand planes of the split-bf16 GEMM, gemm_x3_planes.hip)
-template <int V>
+template <int V, bool PAIR = false>
 __device__ __forceinline__ void store_row_planes(void* __restrict__ hi, void* __restrict__ lo, int64_t row_off,
                                                  const Row<V>& r, int lane, int n4) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +78,7 @@ __device__ __forceinline__ void store_row_planes(void* __restrict__ hi, void* __
   __bf16* pl = reinterpret_cast<__bf16*>(lo) + row_off;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    const int c4 = lane + 64 * j;
+    const int c4 = row_col4<PAIR>(lane, j);
     if (c4 < n4) {
       const float4 v = r.v[j];
       bf16x4 h, l;
@@ -80,12 +110,12 @@ __device__ __forceinline__ Row<V> zero_row() {
   return r;
 }
 // dot with a vector that lives in LDS (same lane -> column map)
-template <int V>
+template <int V, bool PAIR = false>
 __device__ __forceinline__ float dot_row_lds(const Row<V>& a, const float* lds, int lane, int n4) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    const int c4 = lane + 64 * j;
+    const int c4 = row_col4<PAIR>(lane, j);
     if (c4 < n4) s += dot4(a.v[j], ld4(lds + c4 * 4));
   }
   return s;

@@ -967,7 +967,11 @@ def _bf16_features(batch):
     (dict(max_mention_sentence_len=16, resnet_num_region=4), 40),
     (dict(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY), 6),
     (dict(num_candidates_data=7, gcn_edge_type="static", **TINY), 9),
-], ids=["wikimel_dims", "wikidiverse_dims", "tiny_tokens", "tiny_pooled_static"])
+    # 4 .. 27 tokens per entity: the flat two-rows-per-three-loads walk of the bf16 token block at D = 768 with four pairs in
+    # flight, single pairs, the unpaired last row, and none at all (round 4)
+    (dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=27, max_mention_sentence_len=16,
+          resnet_num_region=4), 3),
+], ids=["wikimel_dims", "wikidiverse_dims", "tiny_tokens", "tiny_pooled_static", "wikimel_dims_long_token_lists"])
 def test_bf16_stored_features(kw, B):
     """Features stored as bf16 and read in place by the fused path (half the bytes of the HBM-bound pass): the scores
     equal the reference forward on the SAME features widened to fp32 (oracle, 1e-5) and the library's own fp32-feature

@@ -43,8 +43,18 @@ from drin_amd.config import DrinConfig, wikimel_config  # noqa: E402
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
-TRAFFIC_FILE = os.path.join("profiles", "r3_hbm_traffic.json")
-MFMA_PMC_FILE = os.path.join("profiles", "r3_mfma_pmc.json")
+def _latest(name):
+    """The newest round's committed counter file (profiles/rN_<name>), as a repo-relative path."""
+    for r in (4, 3):
+        rel = os.path.join("profiles", f"r{r}_{name}")
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel)):
+            return rel
+    return os.path.join("profiles", f"r3_{name}")
+
+
+TRAFFIC_FILE = _latest("hbm_traffic.json")
+MFMA_PMC_FILE = _latest("mfma_pmc.json")
+XGMI_LINKS, XGMI_GBS_PER_LINK = 7, 153.0   # MI355X_MICROARCH.md / SURVEY.md section 5: point-to-point links per GPU
 FEAT_SLOTS = (0, 4, 5, 7, 9, 10)  # the six feature tensors of the 14-sequence
 
 
@@ -244,6 +254,18 @@ def measured_traffic(kernel_prefix, section, matches):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def measured_whole_path_traffic(section, matches):
+    """HBM bytes of ALL kernels of one scoring call (launches per call x bytes per launch, summed; tools/collect_pmc.py
+    `whole_path`) from the committed PMC passes of this configuration - replayed, not re-measured; None without a pass."""
+    path = os.path.join(REPO, TRAFFIC_FILE)
+    if not (matches and os.path.exists(path)):
+        return None
+    try:
+        return json.load(open(path))["whole_path"][section]["hbm_bytes_per_call"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def measured_mfma_busy(section, family):
@@ -509,6 +531,17 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
     roof, ab, stream_bytes_pair, flops_pair = score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused)
     value = pairs * ctx.world * steps / elapsed
     fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision)
+    # the one HBM-bound pass over the entity bytes, whichever class is the longest of this leg
+    s_ms, s_n = prof.get("stream", (0.0, 0))
+    hbm_kernel = None
+    if s_n:
+        s_bytes = stream_bytes_pair * pairs * steps / s_n
+        hbm_kernel = {"kernel": "k_cached_pairs" if cached else "k_entity_stream", "avg_launch_ms": s_ms / s_n,
+                      "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms / s_n * 1e-3) / 1e9, "unit": "GB/s",
+                      "frac": s_bytes / (s_ms / s_n * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    default_cfg = B == 4096 and precision == "bf16x3" and fused and features == "f32" and workload == "wikimel"
+    whole_traffic = (measured_whole_path_traffic("kernels_table_cache", B == 4096 and features == "f32") if cached
+                     else measured_whole_path_traffic("kernels", default_cfg))
     line = {
         "metric": "mention x candidate pairs scored/sec",
         "value": value, "unit": "pairs/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
@@ -522,8 +555,15 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
                    "parallelism": f"dp{ctx.world} (mentions sharded, no collective)"},
         "rank_ms_per_step": [t / steps * 1e3 for t in per_rank],
         "roofline": roof,
+        "hbm_kernel": hbm_kernel,
         "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items()},
         **fr,
+        # every kernel of the step, not the dominant one alone: HBM bytes per step from the committed PMC passes (replayed)
+        # against the compulsory input bytes - intermediates that round-trip through HBM show up here
+        "hbm_traffic_whole_path": whole_traffic,
+        "hbm_traffic_whole_path_over_algorithmic": (whole_traffic / (ab["whole_path"] * pairs)) if whole_traffic else None,
+        "hbm_traffic_whole_path_source": (f"{TRAFFIC_FILE} whole_path: launches per call x FETCH_SIZE / WRITE_SIZE bytes per launch of every "
+                                          "kernel of the call (tools/collect_pmc.py), replayed - not re-measured in this run") if whole_traffic else None,
         "launch": "hipGraph replay" if graph else "eager",
         "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + precision
                 + (", features stored as bf16" if features == "bf16" else ""),
@@ -533,7 +573,8 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
     return line
 
 
-def compact(line, keep=("value", "unit", "ms_per_step", "steps", "dtype", "path", "roofline", "kernel_ms_per_step", "hbm_fraction_whole_path",
+def compact(line, keep=("value", "unit", "ms_per_step", "steps", "dtype", "path", "roofline", "hbm_kernel", "kernel_ms_per_step",
+                        "hbm_fraction_whole_path", "hbm_traffic_whole_path", "hbm_traffic_whole_path_over_algorithmic",
                         "mfma_fraction_whole_path", "parity")):
     """A secondary leg's entry of the one JSON line."""
     out = {"workload": line["config"]["workload"], "mentions_per_step": line["config"]["mentions_per_step_per_gpu"]}
@@ -626,6 +667,36 @@ def step_floor(cfg, B, N, bytes_per_pair, flops_per_pair, precision):
     mfma_ms = passes * flops_per_pair * B * N / (1.3e15 if passes == 3 else 0.82 * PEAK_F32_MATRIX_TFLOPS * 1e12) * 1e3
     return {"ms": max(hbm_ms, mfma_ms), "serial_ms": hbm_ms + mfma_ms, "hbm_ms": hbm_ms, "mfma_ms": mfma_ms,
             "rates": "6.3 TB/s streaming reads (MI355X_MICROARCH.md); 1.3 PF/s executed bf16 (this library's K-loop, DESIGN.md 4.2)"}
+
+
+def scaling_model(step_ms, allreduce_bytes, hideable_ms, worlds=(2, 4, 8)):
+    """What a data-parallel step should cost at N GPUs of one node, stated BEFORE anybody has measured it (no 8-GPU node has
+    been available to this repository; the driver computes the measured efficiency from its own runs): the per-rank step
+    without a collective (`step_ms`, measured here), one all-reduce of the flat gradient bucket over xGMI - a ring moves
+    2 (N - 1) / N of the bucket through ONE link per hop; reduce-scatter + all-gather with every peer directly uses N - 1 of
+    the 7 links at once - of which the parameter-free head of the next forward (`hideable_ms`: pooling + static edges,
+    measured here) hides its length (drin_amd.train.OverlappedStep).  Mention shards are independent: nothing else couples."""
+    out = {"step_ms_without_collective": step_ms, "allreduce_bytes": allreduce_bytes, "hideable_ms": hideable_ms,
+           "xgmi": {"links_per_gpu": XGMI_LINKS, "GB_per_s_per_link": XGMI_GBS_PER_LINK}, "by_world": {}}
+    for n in worlds:
+        ring = 2.0 * (n - 1) / n * allreduce_bytes / (XGMI_GBS_PER_LINK * 1e9) * 1e3
+        direct = 2.0 * (allreduce_bytes / n) / (XGMI_GBS_PER_LINK * 1e9) * 1e3       # each peer's share over its own link, both phases
+        exposed = max(0.0, ring - hideable_ms)
+        out["by_world"][str(n)] = {"ring_allreduce_ms": ring, "direct_allreduce_ms": direct, "expected_exposed_ms": exposed,
+                                   "expected_step_ms": step_ms + exposed,
+                                   "expected_weak_scaling_efficiency": step_ms / (step_ms + exposed)}
+    return out
+
+
+def gather_ranks(ctx, value):
+    """[value of rank 0, rank 1, ...] (floats)."""
+    if ctx.world == 1:
+        return [float(value)]
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.dev)
+    parts = [torch.empty_like(t) for _ in range(ctx.world)]
+    dist.all_gather(parts, t)
+    return [float(x[0]) for x in parts]
 
 
 def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f32", train_form="gathered", train_entities=50_000,
@@ -757,6 +828,13 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
                 "steps_with_early_piece": bucket.overlapped,
                 "serial_ms_per_step": serial_ms, "no_collective_ms_per_step": none_ms}
     bucket.close()
+    step_ms = elapsed / steps * 1e3
+    hideable = (prof.get("pool", (0.0, 0))[0] + prof.get("edge", (0.0, 0))[0]) / steps
+    # (the loss kernels count under "edge" too: ~0.03 ms of the class belongs to the end of the step, not to the next forward's head)
+    model_of_scaling = scaling_model(none_ms if none_ms is not None else step_ms, plain_bucket.nbytes(), max(0.0, hideable - 0.03))
+    rank_gemm_ms = gather_ranks(ctx, roof["avg_launch_ms"] if roof else 0.0)
+    if coll is not None:
+        coll["rank_gemm_avg_launch_ms"] = rank_gemm_ms
     return {
         "metric": "mention x candidate pairs trained/sec (forward + backward + Adam)" + (" [hipGraph replay]" if graph else ""),
         "value": B * N * world * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps,
@@ -769,6 +847,7 @@ def bench_train(ctx, cfg, sd, B, steps, warmup, precision="bf16x3", features="f3
                    "global_batch": B * world, "parallelism": f"dp{world}, one flat-bucket RCCL all-reduce per step"},
         "rank_ms_per_step": [t / steps * 1e3 for t in per_rank],
         "allreduce_ms": ar_ms, "allreduce_exposed_ms": exposed_ms, "allreduce_bytes": plain_bucket.nbytes(), "collective": coll,
+        "scaling_model": model_of_scaling, "rank_roofline_avg_launch_ms": rank_gemm_ms,
         "step_floor_ms": floor["ms"] if floor else None, "step_floor": floor,
         "optimizer": opt.describe() if hasattr(opt, "describe") else type(opt).__name__,
         "library_launches_per_step": sum(v[1] for v in prof.values()) / steps,
@@ -1002,6 +1081,11 @@ def main(argv=None):
     cached = args.workload == "table" and args.entity_cache
     line = score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, args.steps, args.warmup, args.precision, args.features,
                       args.workload, cached, fused, args.graph)
+    line["rank_roofline_avg_launch_ms"] = gather_ranks(ctx, line["roofline"]["avg_launch_ms"])
+    line["scaling_model"] = {"collectives_in_the_scoring_path": 0,
+                             "expected": "every rank scores its own mentions with the N = 1 schedule: ms_per_step and the dominant kernel's "
+                                         "launch time of each rank equal the N = 1 run's (the stream kernel's +-4 % placement band per "
+                                         "process apart), value = N x the N = 1 value; the timed bracket is the max over ranks"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["parity"] = parity_of_timed_batch(cfg, sd, batch, out, n_slices=(2 if args.workload == "table" else 8),
                                                width=(1 if args.workload == "table" else 8 if cfg.token_level_entities else 16))

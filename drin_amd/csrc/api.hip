@@ -888,6 +888,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
     return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st,
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
   };
+  SliceSum ln_sums;        // second level of the LayerNorm backward's column sums (dgamma, dbeta, db_h of every layer)
   ColsumBatch bias_sums;   // the bias gradients of W_u / W_v and of the vertex encoders: one launch
   // dW (+)= dY^T X.  The pair-sized products of the whole pass (dW_h, dW_v of every layer, the two entity encoders) are
   // collected and run as ONE launch at the end: alone, each deals its ~15-stage slices over the chip between a pipeline
@@ -952,9 +953,11 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
     const float* st_e = ws + L.ln_stat_e[l];
     // (a) LayerNorm + GELU backward; column sums give dgamma, dbeta and db_h
     // (mention and entity rows in one launch)
+    // (its column sums' second level rides in the slice sum at the end of the pass: per-layer level-1 rows behind the block rows)
     DRIN_TRY(launch_layernorm_gelu_bwd2(ws + L.h_m[l], st_m, st_m + 2 * (size_t)B, gm, (int64_t)types * B, ws + L.h_e[l], st_e,
                                         st_e + 2 * M, ge, (int64_t)types * M, W.ln_weight, W.ln_bias, G.ln_weight, G.ln_bias,
-                                        G.b_h, ws + L.ln_part, D, st, act_v));
+                                        G.b_h, ws + L.ln_part, D, st, act_v, nl <= 2 ? &ln_sums : nullptr,
+                                        ws + L.ln_part + ((size_t)(1024 + 16) + (size_t)16 * l) * 3 * D));
     // (b) dW_h += dH^T A
     if (G.w_h) {
       DRIN_TRY(dw_product(gm, D, ws + L.agg_m[l], D, G.w_h, D, (int64_t)types * B, D, D));
@@ -996,14 +999,14 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
       // dpre = g e' (1 - e');  dfv_t = (dpre_tt fu_t + dpre_it fu_i) / D ; dfv_i = (dpre_ti fu_t + dpre_ii fu_i) / D: one pass
       DRIN_TRY(launch_edge_update_bwd(g_e[cur], from_z ? ws + L.edge_z[l] : ws + L.edges[l + 1], fu, dpre, dfv, B, N, D, inv_d, st, act_eb));
       // dfu_t = sum_n (dpre_tt fv_t + dpre_ti fv_i) / D ; dfu_i = sum_n (dpre_it fv_t + dpre_ii fv_i) / D
-      if (B <= 65535) {
-        DRIN_TRY(launch_mention_reduce2(dpre, fv, fv + MD, nullptr, nullptr, dfu, dfu + BD, B, N, D, inv_d, st));
-      } else {
+      // (B <= 65535: nothing reads dfu before the mention side of the aggregation backward below, (f): the two reductions
+      //  share ONE launch there - and dW_u, which reads dfu, is collected behind it)
+      if (B > 65535) {
         DRIN_TRY(launch_mention_reduce(dpre, fv, dpre + M, fv + MD, nullptr, dfu, B, N, D, inv_d, st));
         DRIN_TRY(launch_mention_reduce(dpre + 2 * M, fv, dpre + 3 * M, fv + MD, nullptr, dfu + BD, B, N, D, inv_d, st));
+        DRIN_TRY(dw_product(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, nullptr, G.b_u));
       }
       DRIN_TRY(dw_product(dfv, D, et, D, G.w_v, D, 2 * (int64_t)M, D, D, nullptr, G.b_v));
-      DRIN_TRY(dw_product(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, nullptr, G.b_u));
       de_extra = dpre;
     } else if (!cfg->dynamic_edges && have_edge) {
       de_extra = g_e[cur];  // static edges pass through (model.py:136)
@@ -1025,7 +1028,12 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
       DRIN_TRY(launch_entity_side_bwd(dA_mt, dA_mi, dA_et, dA_ei, mt, mi, et, ei, e, de_extra, ge_next, ge_next + MD,
                                       g_e[nxt], B, N, D, cfg->edge_enabled, edge_update, st));
       // (f) mention side
-      if (B <= 65535) {
+      if (B <= 65535 && edge_update) {
+        const float* fv = ws + L.fv[l];
+        DRIN_TRY(launch_mention_reduce2_pair(dpre, fv, fv + MD, nullptr, nullptr, dfu, dfu + BD, 1.0f / (float)D,          // (d): dfu
+                                             e, dA_et, dA_ei, dA_mt, dA_mi, gm_next, gm_next + BD, 1.0f, B, N, D, st));   // (f)
+        DRIN_TRY(dw_product(dfu, D, mt, D, G.w_u, D, 2 * (int64_t)B, D, D, nullptr, G.b_u));
+      } else if (B <= 65535) {
         DRIN_TRY(launch_mention_reduce2(e, dA_et, dA_ei, dA_mt, dA_mi, gm_next, gm_next + BD, B, N, D, 1.0f, st));
       } else {
         DRIN_TRY(launch_mention_reduce(e, dA_et, e + M, dA_ei, dA_mt, gm_next, B, N, D, 1.0f, st));
@@ -1066,7 +1074,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
   // pair-sized weight gradients of the staged pass differ from drin_backward's in the last bits - by the summation
   // split only; each is reproducible.
   const int64_t target = 0;
-  auto flush = [&](int s0, int s1, int f0, int f1, int g0, int g1) -> int {
+  auto flush = [&](int s0, int s1, int f0, int f1, int g0, int g1, bool with_layernorm) -> int {
     ColsumBatch cs;
     for (int i = s0; i < s1; ++i) {
       cs.x[cs.n] = bias_sums.x[i], cs.out[cs.n] = bias_sums.out[i], cs.rows[cs.n] = bias_sums.rows[i];
@@ -1078,16 +1086,17 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
     TnGroup tg;
     for (int i = g0; i < g1; ++i) tg.item[tg.n++] = dw_group.item[i];
     SliceSum sums;
+    if (with_layernorm) sums = ln_sums;   // (layer gradients: they belong to the first part of a staged pass)
     DRIN_TRY(launch_colsum_batch(cs, st, csp, L.colsum_part_floats, &sums));
     DRIN_TRY(launch_gemm_tn_f32_group(fg, st, smp, L.small_part_floats, &sums));
     DRIN_TRY(launch_gemm_tn_group(tg, st, tnp, tnf, &sums, target));
     return launch_slice_sum(sums, st);
   };
-  if (layers_ready_event == nullptr) return flush(0, bias_sums.n, 0, dw_small.n, 0, dw_group.n);
-  DRIN_TRY(flush(0, layer_sums, 0, layer_small, 0, layer_group));
+  if (layers_ready_event == nullptr) return flush(0, bias_sums.n, 0, dw_small.n, 0, dw_group.n, true);
+  DRIN_TRY(flush(0, layer_sums, 0, layer_small, 0, layer_group, true));
   hipError_t ev = hipEventRecord((hipEvent_t)layers_ready_event, st);
   if (ev != hipSuccess) return hip_fail(ev, "hipEventRecord(layers_ready)");
-  return flush(layer_sums, bias_sums.n, layer_small, dw_small.n, layer_group, dw_group.n);
+  return flush(layer_sums, bias_sums.n, layer_small, dw_small.n, layer_group, dw_group.n, false);
 }
 
 // ---- host-side self-checks (sanitizer build / CI; no launch is made, no GPU needed) -----------------------------------

@@ -268,9 +268,11 @@ __global__ void __launch_bounds__(256) k_layernorm_gelu_bwd(const LnBwdSeg sa, c
 //   level 2 (out_partial == NULL): dst_q[c] += sum of all `blocks` (<= 64) rows      (q: dgamma, dbeta, dbias)
 // Block = 4 waves x 64 columns; wave w takes rows w, w + 4, ... of its slice (at most 16, all in flight at once);
 // the waves are combined through LDS in order.
+// (q_major: level-1 rows laid out [q][z][D] instead of [z][q][D] - one contiguous [z][D] slice array per quantity, the form
+//  the ordered slice sum at the end of the backward pass takes: level 2 then rides in that launch, internal.h SliceSum)
 __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ partial, int blocks, int D,
                                                       float* __restrict__ out_partial, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta, float* __restrict__ dbias) {
+                                                      float* __restrict__ dbeta, float* __restrict__ dbias, int q_major) {
   __shared__ float comb[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 64 + lane, q = blockIdx.y;
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
   if (wave != 0 || c >= D) return;
   s = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
   if (out_partial != nullptr) {
-    out_partial[((int64_t)blockIdx.z * 3 + q) * D + c] = s;
+    out_partial[(q_major ? (int64_t)q * gridDim.z + blockIdx.z : (int64_t)blockIdx.z * 3 + q) * D + c] = s;
   } else {
     float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : dbias);
     if (dst != nullptr) dst[c] += s;
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
 int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* rstd, float* g, int64_t rows, const float* h2,
                                const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
                                const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
-                               hipStream_t st, int act) {
+                               hipStream_t st, int act, SliceSum* defer, float* level1_own) {
   const int64_t total = rows + (h2 != nullptr ? rows2 : 0);
   if (total <= 0) return DRIN_OK;
   if (D % 4 || D > 256 * MAXV) {
@@ -322,13 +324,25 @@ int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* r
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, sa, sb, gamma, beta, partial, D / 4, act);
   DRIN_CHECK_LAUNCH("k_layernorm_gelu_bwd");
   // partial: [kLnBwdMaxBlocks][3][D] block rows, then [kLnBwdMaxBlocks / 64][3][D] for the first reduction level
-  float* level1 = partial + (int64_t)kLnBwdMaxBlocks * 3 * D;
   const int z = (int)cdiv(blocks, 64);
+  // defer: the second level - up to 16 rows per quantity - is handed to the caller's ordered slice sum (one launch at the end
+  // of the backward pass for every split reduction) instead of being a launch of its own; the level-1 rows then live in
+  // `level1_own`, which nothing overwrites before that launch (one area per layer)
+  const bool deferred = defer != nullptr && level1_own != nullptr && defer->n + 3 <= SliceSum::MAX_DST - 24 /* the pass's other split reductions: three collections of at most eight */ &&
+                        defer->n_seg + 3 <= SliceSum::MAX_SEG && (D % 4) == 0 && aligned16(level1_own) &&
+                        (dgamma == nullptr || aligned16(dgamma)) && (dbeta == nullptr || aligned16(dbeta)) &&
+                        (dbias == nullptr || aligned16(dbias));
+  float* level1 = deferred ? level1_own : partial + (int64_t)kLnBwdMaxBlocks * 3 * D;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)cdiv(D, 64), 3, (unsigned)z), dim3(256), 0, st, partial, (int)blocks, D,
-                     level1, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     level1, (float*)nullptr, (float*)nullptr, (float*)nullptr, deferred ? 1 : 0);
   DRIN_CHECK_LAUNCH("k_sum_partials");
+  if (deferred) {
+    float* dst[3] = {dgamma, dbeta, dbias};
+    for (int q = 0; q < 3; ++q) DRIN_TRY(defer->add(dst[q], D, 1, D, level1 + (int64_t)q * z * D, z));   // no-op for a NULL destination
+    return DRIN_OK;
+  }
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)cdiv(D, 64), 3, 1), dim3(256), 0, st, level1, z, D, (float*)nullptr, dgamma,
-                     dbeta, dbias);
+                     dbeta, dbias, 0);
   DRIN_CHECK_LAUNCH("k_sum_partials");
   return DRIN_OK;
 }
@@ -337,7 +351,7 @@ int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rs
                               const float* beta, float* g, float* dgamma, float* dbeta, float* dbias, float* partial,
                               int64_t rows, int D, hipStream_t st, int act) {
   return launch_layernorm_gelu_bwd2(h, mean, rstd, g, rows, nullptr, nullptr, nullptr, nullptr, 0, gamma, beta, dgamma, dbeta,
-                                    dbias, partial, D, st, act);
+                                    dbias, partial, D, st, act, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,11 +555,16 @@ int launch_mention_reduce(const float* w1, const float* v1, const float* w2, con
 //   outA[b] = scale (sum_n w[0][p] v1[p] + sum_n w[1][p] v2[p]) + uA[b]
 //   outB[b] = scale (sum_n w[2][p] v1[p] + sum_n w[3][p] v2[p]) + uB[b]         w = [4][pairs]; v2 / uA / uB may be NULL
 // Candidate split and summation order are those of k_mention_reduce: bit-identical to two launches of it, v1 / v2 read once.
-__global__ void __launch_bounds__(256) k_mention_reduce2(const float* __restrict__ w, int64_t pairs,
-                                                         const float* __restrict__ v1, const float* __restrict__ v2,
-                                                         const float* __restrict__ uA, const float* __restrict__ uB,
-                                                         float* __restrict__ outA, float* __restrict__ outB, int N,
-                                                         int D4, float scale) {
+struct MentionReduceJob {
+  const float *w, *v1, *v2, *uA, *uB;
+  float *outA, *outB;
+  float scale;
+};
+__device__ __forceinline__ void mention_reduce2_body(const float* __restrict__ w, int64_t pairs,
+                                                     const float* __restrict__ v1, const float* __restrict__ v2,
+                                                     const float* __restrict__ uA, const float* __restrict__ uB,
+                                                     float* __restrict__ outA, float* __restrict__ outB, int N,
+                                                     int D4, float scale) {
   __shared__ float4 comb[2][4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c4 = blockIdx.x * 64 + lane;
@@ -601,6 +620,36 @@ __global__ void __launch_bounds__(256) k_mention_reduce2(const float* __restrict
   if (uB != nullptr) sB = sB + ld4(uB + b * (int64_t)D4 * 4 + (int64_t)c4 * 4);
   st4(outA + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, sA);
   st4(outB + b * (int64_t)D4 * 4 + (int64_t)c4 * 4, sB);
+}
+__global__ void __launch_bounds__(256) k_mention_reduce2(const float* __restrict__ w, int64_t pairs,
+                                                         const float* __restrict__ v1, const float* __restrict__ v2,
+                                                         const float* __restrict__ uA, const float* __restrict__ uB,
+                                                         float* __restrict__ outA, float* __restrict__ outB, int N,
+                                                         int D4, float scale) {
+  mention_reduce2_body(w, pairs, v1, v2, uA, uB, outA, outB, N, D4, scale);
+}
+// two such reductions that do not depend on each other (the edge update's dfu and the aggregation's mention side of one
+// layer's backward) in ONE launch: blockIdx.z picks the job; the arithmetic - hence every bit - is the single kernel's
+__global__ void __launch_bounds__(256) k_mention_reduce2_pair(const MentionReduceJob a, const MentionReduceJob b, int64_t pairs,
+                                                              int N, int D4) {
+  const MentionReduceJob& j = blockIdx.z == 0 ? a : b;
+  mention_reduce2_body(j.w, pairs, j.v1, j.v2, j.uA, j.uB, j.outA, j.outB, N, D4, j.scale);
+}
+
+int launch_mention_reduce2_pair(const float* wa, const float* va1, const float* va2, const float* uaA, const float* uaB, float* outaA,
+                                float* outaB, float scale_a, const float* wb, const float* vb1, const float* vb2, const float* ubA,
+                                const float* ubB, float* outbA, float* outbB, float scale_b, int B, int N, int D, hipStream_t st) {
+  if (B <= 0 || N <= 0) return DRIN_OK;
+  if (B > 65535 || (D % 4)) {
+    set_error("mention_reduce2_pair: B=%d D=%d outside the grid / 16-byte contract", B, D);
+    return DRIN_E_SHAPE;
+  }
+  const MentionReduceJob ja{wa, va1, va2, uaA, uaB, outaA, outaB, scale_a}, jb{wb, vb1, vb2, ubA, ubB, outbA, outbB, scale_b};
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_mention_reduce2_pair, dim3((unsigned)cdiv(D / 4, 64), (unsigned)B, 2), dim3(256), 0, st, ja, jb,
+                     (int64_t)B * N, N, D / 4);
+  DRIN_CHECK_LAUNCH("k_mention_reduce2_pair");
+  return DRIN_OK;
 }
 
 int launch_mention_reduce2(const float* w, const float* v1, const float* v2, const float* uA, const float* uB,

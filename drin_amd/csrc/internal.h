@@ -287,7 +287,8 @@ int launch_layernorm_gelu_bwd(const float* h, const float* mean, const float* rs
 int launch_layernorm_gelu_bwd2(const float* h, const float* mean, const float* rstd, float* g, int64_t rows, const float* h2,
                                const float* mean2, const float* rstd2, float* g2, int64_t rows2, const float* gamma,
                                const float* beta, float* dgamma, float* dbeta, float* dbias, float* partial, int D,
-                               hipStream_t st, int act = DRIN_ACT_GELU);
+                               hipStream_t st, int act = DRIN_ACT_GELU, SliceSum* defer = nullptr, float* level1_own = nullptr);
+// (defer + level1_own [3][16][D] floats: the second level of the column-sum reduction joins the caller's slice sum)
 // out[c] += sum_rows x[row, c].  The rows are dealt over up to kColsumMaxSlices workgroups per 256 columns, whose sums go to
 // the scratch ([slices][C] floats) and from there to out in order (SliceSum); without scratch one workgroup per 256 columns
 // walks all rows and adds to out itself - slower, the same kind of result: no atomics either way.
@@ -318,6 +319,10 @@ int launch_mention_reduce(const float* w1, const float* v1, const float* w2, con
 // two such reductions over the same rows in one pass: w = [4][B*N]; outA takes planes 0 / 1, outB planes 2 / 3
 int launch_mention_reduce2(const float* w, const float* v1, const float* v2, const float* uA, const float* uB,
                            float* outA, float* outB, int B, int N, int D, float scale, hipStream_t st);
+// two independent launch_mention_reduce2 jobs (a, b) over the same B x N x D geometry in one launch; same bits
+int launch_mention_reduce2_pair(const float* wa, const float* va1, const float* va2, const float* uaA, const float* uaB, float* outaA,
+                                float* outaB, float scale_a, const float* wb, const float* vb1, const float* vb2, const float* ubA,
+                                const float* ubB, float* outbA, float* outbB, float scale_b, int B, int N, int D, hipStream_t st);
 // out[p,:] = scale (w1[p] m1[b,:] + w2[p] m2[b,:])       (m2 optional)
 int launch_entity_combine(const float* w1, const float* m1, const float* w2, const float* m2, float* out, int B, int N,
                           int D, float scale, hipStream_t st);

@@ -105,7 +105,7 @@ struct Layout {
       }
       // backward temporaries: gradients w.r.t. two generations of vertices/edges + GEMM operands
       wt = take(((size_t)2 * nl + 1) * D * D);   // slots 2 l, 2 l + 1: W_h^T, W_v^T of layer l; slot 2 nl: the product in flight
-      ln_part = take((1024 + 16) * 3 * D);
+      ln_part = take((size_t)(1024 + 16 + 16 * (nl > 0 ? nl : 1)) * 3 * D);   // + one level-1 area per layer (deferred second level)
       {  // one workgroup per CU over the whole group of weight-gradient products (launch_gemm_tn_group): at most 256 partial
         // tiles of 256 x 256 - or, where one product alone has more tiles than that, one slice of each product
         const size_t one_slice = ((size_t)2 * nl + 1) * D * D + D * R;

@@ -131,6 +131,10 @@ __device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float
 #pragma unroll
   for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
   const float inv_d = 1.0f / (float)(D4 * 4);
+  // (Measured in round 4 and dropped - profiles/r4_ln_stats_ab.txt: both moments in ONE round of wave reductions,
+  //  var = E[x^2] - mu^2, so that the mean -> centred squares chain is one stage shorter.  Same box, alternating: the row
+  //  kernels of the headline 1.12 -> 1.24 ms, of config 5 3.35 -> 3.48 ms - slower, although it is fewer instructions; the
+  //  dependent reductions are not what these kernels wait for.)
   const float mu = wave_sum(s) * inv_d;
   float q = 0.f;
 #pragma unroll

@@ -18,7 +18,11 @@ cp $O/train512_bench_under_rocprof.json $P/${R}_train_b512_bench_under_rocprof.j
 cp $O/train64_rccl_world1_bench_under_rocprof.json $P/${R}_train_b64_rccl_world1_bench_under_rocprof.json
 cp $O/config5_1M_stream.json $P/${R}_config5_1M_mentions_streamed.json
 cp $O/hbm_traffic.json $P/${R}_hbm_traffic.json
-cp $O/r3_mfma_pmc.json $P/${R}_mfma_pmc.json
+cp $O/${R}_mfma_pmc.json $P/${R}_mfma_pmc.json
+cp "$(stats mixed)" $P/${R}_wikimel_b4096_mixed_bf16x3_i1_kernel_stats.csv
+cp "$(stats bf16f)" $P/${R}_wikimel_b4096_bf16_features_kernel_stats.csv
+cp $O/mixed_bench_under_rocprof.json $P/${R}_wikimel_b4096_mixed_bf16x3_i1_bench_under_rocprof.json
+cp $O/bf16f_bench_under_rocprof.json $P/${R}_wikimel_b4096_bf16_features_bench_under_rocprof.json
 cp $O/summary.txt $P/${R}_mfma_pmc_summary.txt
 # the default line three times (one JSON line each)
 cat $O/wm_bench.json $O/wm_bench_1.json $O/wm_bench_2.json > $P/${R}_wikimel_b4096_bench_all_legs.json

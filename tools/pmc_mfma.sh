@@ -14,6 +14,7 @@ run() {  # section, bench arguments
   echo "[pmc_mfma] $sec done"
 }
 run wikimel_b4096 --steps 3 --warmup 1 --no-cpu-baseline --legs none
+run wikimel_b4096_mixed --precision bf16x3_i1 --steps 3 --warmup 1 --no-cpu-baseline --legs none
 run wikidiverse_b16384 --workload wikidiverse --steps 3 --warmup 1 --no-cpu-baseline --legs none
 run train_b64 --mode train --batch 64 --steps 5 --warmup 5
 run train_b512 --mode train --batch 512 --steps 3 --warmup 3

@@ -5,6 +5,7 @@
 #   tools/pmc_mfma.sh (separate call: it writes gpurun_out/pmc_mfma/).
 # rocprofv3: program directly after `--`, counters in their own passes.
 set -e
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round
 rm -rf $O && mkdir -p $O
@@ -17,6 +18,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 $HEAD > $O/pmc_write.log 2>&1
 python3 tools/collect_pmc.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic.json kernels > $O/hbm_traffic.txt
 echo "[profile_round] default PMC done"
+# the mixed-precision leg (bf16x3_i1: x_i C_i^T in one bf16 pass) and the bf16-stored-features leg: kernel stats of their own commands
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/mixed -- python3 bench.py --precision bf16x3_i1 --steps 10 --warmup 3 $HEAD > $O/mixed_bench_under_rocprof.json 2> $O/mixed.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16f -- python3 bench.py --features bf16 --steps 10 --warmup 3 $HEAD > $O/bf16f_bench_under_rocprof.json 2> $O/bf16f.err
+echo "[profile_round] mixed precision / bf16 features done"
 TAB="--workload table --batch 4096 --entity-cache"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tab -- python3 bench.py $TAB --steps 5 --warmup 2 $HEAD > $O/table_cache_bench_under_rocprof.json 2> $O/tab.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tab -- python3 bench.py $TAB --steps 2 --warmup 1 $HEAD > $O/pmc_fetch_tab.log 2>&1
@@ -31,6 +36,6 @@ python3 bench.py --workload table --entity-cache --mentions 1000000 --chunk 4096
 echo "[profile_round] config 5 full stream done"
 for i in 1 2; do python3 bench.py > $O/wm_bench_$i.json 2>> $O/wm_bench.err; done
 echo "[profile_round] two more default lines done"
-bash tools/pmc_mfma.sh r3 > $O/pmc_mfma.log 2>&1 && cp gpurun_out/pmc_mfma/r3_mfma_pmc.json gpurun_out/pmc_mfma/summary.txt $O/
+bash tools/pmc_mfma.sh $TAG > $O/pmc_mfma.log 2>&1 && cp gpurun_out/pmc_mfma/${TAG}_mfma_pmc.json gpurun_out/pmc_mfma/summary.txt $O/
 echo "[profile_round] SQ / MFMA counter passes done"
 ls $O

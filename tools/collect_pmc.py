@@ -38,7 +38,9 @@ anchor = next((k for k in out if "k_entity_stream" in k or "k_cached_pairs" in k
 whole = None
 if anchor:
     calls = COUNTS[anchor]
-    per_call = {k: COUNTS[k] / calls for k in out if COUNTS.get(k, 0) >= calls}
+    # (a kernel of the step runs a whole number of times per call; weight folds and the per-entity cache build run once per
+    #  process - their launch counts are no multiple of the number of calls)
+    per_call = {k: COUNTS[k] // calls for k in out if COUNTS.get(k, 0) >= calls and COUNTS[k] % calls == 0}
     whole = {"calls_in_the_pass": calls, "launches_per_call": per_call,
              "hbm_bytes_per_call": sum(out[k]["hbm_bytes_per_launch"] * n for k, n in per_call.items()),
              "fetch_bytes_per_call": sum(out[k]["fetch_bytes_per_launch"] * n for k, n in per_call.items()),

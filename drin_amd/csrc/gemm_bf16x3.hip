@@ -656,6 +656,7 @@ static int launch_sk(const float* x, int64_t ldx, const float* w, const void* w_
   return DRIN_OK;
 }
 
+
 }  // namespace x3
 
 int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int N, unsigned col_tiles, unsigned full,
@@ -696,6 +697,9 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
       set_error("gemm_bf16x3: the one-pass (plain bf16) variant is built for pair-sized problems on weight planes");
       return DRIN_E_UNSUPPORTED;
     }
+    // (Measured in round 4 and removed - profiles/r4_one_pass_ab.txt: an all-DMA three-stage ring for this product, raw fp32
+    //  activation rows straight into LDS, two 48 KiB stages in flight, fragments rounded at read time.  Correct, and slower
+    //  (x_i C_i^T 1.9 against 1.6 ms): six LDS-DMA instructions per wave per 32 MFMAs cost more issue time than they hide.)
     if (K % (2 * x3::BK) == 0)   // 64-wide K-blocks; a reduction length that is an odd multiple of 32 keeps three passes
       return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
     one_pass = false;

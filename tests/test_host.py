@@ -332,3 +332,4 @@ def test_untracked_loads_are_not_touched_before_their_counted_wait():
             (24, "global_load_dwordx4 v[6:9], v[162:163], off", None), (32, "v_mov_b32_e32 v21, v7", None),   # copied too early
             (36, "s_waitcnt vmcnt(0)", None), (40, "v_mov_b32_e32 v21, v7", None)]
     assert len(resources.untracked_load_hazards(fake)) == 1
+

@@ -294,7 +294,7 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
     dom = max(prof, key=lambda k: prof[k][0])
     ms, launches = prof[dom]
     per_launch_ms = ms / max(launches, 1)
-    x3 = precision in ("bf16x3", "bf16", "bf16x3_i1")
+    x3 = precision in ("bf16x3", "bf16", "bf16x3_i1", "bf16x3_if16")
     flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
     ab = algorithmic_bytes(cfg, batch)
     stream_bytes_pair = ab["entity"] + ab["mention_stream"]          # what k_entity_stream itself has to read
@@ -336,7 +336,8 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(launches),
                 "avg_launch_ms": per_launch_ms}
         if dom != "gemm":
-            passes = 1 if (precision == "bf16" or (precision == "bf16x3_i1" and dom == "gemm_x3" and N >= 64)) else 3
+            passes = 1 if (precision == "bf16" or (precision == "bf16x3_i1" and dom == "gemm_x3" and N >= 64)
+                           or (precision == "bf16x3_if16" and dom == "gemm_x3")) else 3
             roof["executed_bf16_tflops"] = passes * achieved
             roof["executed_frac"] = passes * achieved / peak
             section = None
@@ -348,11 +349,11 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
 
 def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision):
     D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
-    x3 = precision in ("bf16x3", "bf16", "bf16x3_i1")
+    x3 = precision in ("bf16x3", "bf16", "bf16x3_i1", "bf16x3_if16")
     peak = (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12
     ref_flops = 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D
     executed = ((1 if precision == "bf16" else 3) if x3 else 1) * flops_pair
-    if precision == "bf16x3_i1" and cfg.num_candidates_model >= 64:
+    if (precision == "bf16x3_i1" and cfg.num_candidates_model >= 64) or precision == "bf16x3_if16":
         executed -= 2 * 2.0 * R * D                       # the image contraction in one pass instead of three
     return {
         "hbm_fraction_whole_path": ab["whole_path"] * rate_per_gpu / (PEAK_HBM_GBS * 1e9),
@@ -927,7 +928,7 @@ def parse_args(argv=None):
                          "--mentions 1000000 --chunk 4096); a step is one chunk")
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 4096 wikimel / 16384 wikidiverse / 512 table)")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16", "bf16x3_i1"],
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16", "bf16x3_i1", "bf16x3_if16"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
                          "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
     ap.add_argument("--features", default="f32", choices=["f32", "bf16"],
@@ -961,7 +962,7 @@ def parse_args(argv=None):
 
 
 def wanted_legs(args, world):
-    names = ("f32_exact", "wikimel_mixed_bf16", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "train_b512", "wikidiverse", "table_cache")
+    names = ("f32_exact", "wikimel_mixed_bf16", "wikimel_mixed_f16", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "train_b512", "wikidiverse", "table_cache")
     default_headline = (args.workload == "wikimel" and args.mode == "score" and not args.batch and not args.generic
                         and args.precision == "bf16x3" and args.features == "f32" and not args.graph)
     if args.legs == "auto":
@@ -1117,6 +1118,19 @@ def main(argv=None):
             ln["parity"]["top1_agreement_vs_headline_all_mentions"] = float((o[:, :-1].argmax(1) == out[:, :-1].argmax(1)).float().mean())
             return compact(ln)
         extra["wikimel_mixed_bf16"] = leg_guard("wikimel_mixed_bf16", mixed_leg)
+    if "wikimel_mixed_f16" in legs and world == 1:
+        def f16_leg():
+            # the same one pass on the FP16 matrix instruction (`bf16x3_if16`): 11-bit operands, every image row scaled by a power
+            # of two into fp16's range and back - an eighth of the bf16 pass's rounding error, i.e. the split product's own level
+            m = make_model(cfg, sd, dev, "bf16x3_if16")
+            st = min(args.steps, 10)
+            e, pr, o, pf = run_score(ctx, m, batch, st, 2)
+            ln = score_line(ctx, cfg, args, B, batch, e, pr, pf, st, 2, "bf16x3_if16", args.features, args.workload, False, fused)
+            ln["parity"] = parity_of_timed_batch(cfg, sd, batch, o, n_slices=8, width=8)
+            ln["parity"]["max_abs_diff_vs_headline_scores_all"] = float((o - out).abs().max())
+            ln["parity"]["top1_agreement_vs_headline_all_mentions"] = float((o[:, :-1].argmax(1) == out[:, :-1].argmax(1)).float().mean())
+            return compact(ln)
+        extra["wikimel_mixed_f16"] = leg_guard("wikimel_mixed_f16", f16_leg)
     if "wikimel_bf16_features" in legs and world == 1:
         def bf16_leg():
             # BASELINE configs 2-3 say "bf16": the headline batch with its six feature tensors stored as bf16 (read in place by

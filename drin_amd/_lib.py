@@ -18,7 +18,7 @@ MAX_LAYERS = 8
 ABI_VERSION = 4
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL, PREC_BF16X3_I1 = 0, 1, 2, 3, 4
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL, PREC_BF16X3_I1, PREC_BF16X3_IF16 = 0, 1, 2, 3, 4, 5
 FEAT_F32, FEAT_BF16 = 0, 1
 ACTIVATIONS = {"gelu": 1, "sigmoid": 2, "relu": 3, "tanh": 4, "silu": 5}   # drin_activation
 

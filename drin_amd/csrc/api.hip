@@ -152,7 +152,7 @@ int validate_config(const drin_config* c) {
     return DRIN_E_UNSUPPORTED;
   }
   if (c->precision != DRIN_PREC_F32 && c->precision != DRIN_PREC_BF16X3 && c->precision != DRIN_PREC_BF16X3_ALL &&
-      c->precision != DRIN_PREC_BF16 && c->precision != DRIN_PREC_BF16X3_I1) {
+      c->precision != DRIN_PREC_BF16 && c->precision != DRIN_PREC_BF16X3_I1 && c->precision != DRIN_PREC_BF16X3_IF16) {
     set_error("config: precision %d is not a drin_precision", c->precision);
     return DRIN_E_UNSUPPORTED;
   }
@@ -168,8 +168,8 @@ static int validate_batch(const drin_config* c, const drin_batch* b) {
     set_error("bf16 feature storage is read by drin_forward_prepared only; widen the features to fp32 for this entry point");
     return DRIN_E_UNSUPPORTED;
   }
-  if (c->precision == DRIN_PREC_BF16 || c->precision == DRIN_PREC_BF16X3_I1) {
-    set_error("DRIN_PREC_BF16 / DRIN_PREC_BF16X3_I1 (one-pass bf16 contractions) are inference modes of drin_forward_prepared; use DRIN_PREC_BF16X3 here");
+  if (c->precision == DRIN_PREC_BF16 || c->precision == DRIN_PREC_BF16X3_I1 || c->precision == DRIN_PREC_BF16X3_IF16) {
+    set_error("DRIN_PREC_BF16 / DRIN_PREC_BF16X3_I1 / _IF16 (one-pass contractions) are inference modes of drin_forward_prepared; use DRIN_PREC_BF16X3 here");
     return DRIN_E_UNSUPPORTED;
   }
   const void* req[] = {b->mention_text,  b->mention_start,        b->mention_end,     b->mention_image,

@@ -29,6 +29,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+// the smallest power of two >= m for a positive finite m (1 for m == 0, a NaN or an infinity: such a row is not scaled -
+// its NaNs / infinities propagate through the product as they are)
+__device__ __forceinline__ float pow2_at_least(float m) {
+  if (!(m > 0.f) || !(m < __builtin_inff())) return 1.0f;
+  const uint32_t bits = __builtin_bit_cast(uint32_t, m);
+  const uint32_t up = (bits & 0x007fffffu) ? ((bits & 0x7f800000u) + 0x00800000u) : (bits & 0x7f800000u);
+  // (a denormal m rounds up to the smallest normal; the largest binade rounds up to 2^127 at most - finite)
+  const float p = __builtin_bit_cast(float, up ? (up >= 0x7f800000u ? 0x7f000000u : up) : 0x00800000u);
+  return p;
+}
+
 // v = hi + lo with hi = bf16(v), lo = bf16(v - hi), both rounded to nearest-even (the operand planes of the split-bf16
 // products).  Written on PAIRS: one packed conversion gives both hi's, two bit operations widen them again, a packed
 // subtract and one packed conversion give both lo's - five vector instructions per pair.  Element by element the same

@@ -39,7 +39,7 @@ constexpr int kMixedMinCandidates = 64;
 
 struct FusedLayout {  // workspace offsets in floats
   size_t span_mean, mimg, vm0, hmfu, q, e0m, e1m, xt, s_part, s_text, s_img, sig, tm, tm2, agg1, vm1, hm2, h_text, h_image,
-      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, splitk, splitk_floats, pair_splitk, pair_splitk_floats, total;
+      et1, s2_part, agg2, mt2, p_xt, p_xi, p_et1, xi_scale, splitk, splitk_floats, pair_splitk, pair_splitk_floats, total;
   int chunks;
   void build(const drin_config& c) {
     const size_t B = c.batch, N = c.num_candidates, D = c.embed_dim, R = c.image_dim, M = B * N;
@@ -86,10 +86,11 @@ struct FusedLayout {  // workspace offsets in floats
     agg2 = take(B * D);
     mt2 = take(B * D);
     const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16 ||
-                        c.precision == DRIN_PREC_BF16X3_I1;
+                        c.precision == DRIN_PREC_BF16X3_I1 || c.precision == DRIN_PREC_BF16X3_IF16;
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
     p_xi = take(planes ? M * R : 0);   // used by the table form only
     p_et1 = take(planes ? M * D : 0);
+    xi_scale = take(c.precision == DRIN_PREC_BF16X3_IF16 ? M : 0);   // per-pair power-of-two scale of the image row
     // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
     // (in split-bf16 precision at least 192 partial 256 x 256 tiles, so that a partly filled last round of tiles of the
     //  larger products can split K over the idle CUs - gemm_bf16x3.hip)
@@ -220,6 +221,7 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
     DRIN_TRY(launch_split_planes(pb + P.c_txt, q, q + dd, dd, st));
     q = reinterpret_cast<__bf16*>(pb + P.p_cimg);
     DRIN_TRY(launch_split_planes(pb + P.c_img, q, q + dr, dr, st));
+    DRIN_TRY(launch_to_f16(pb + P.c_img, pb + P.p_cimg_f16, (int64_t)dr, st));   // DRIN_PREC_BF16X3_IF16: one fp16 plane
     q = reinterpret_cast<__bf16*>(pb + P.p_wh2);
     DRIN_TRY(launch_split_planes(params->layer[1].w_h, q, q + dd, dd, st));
     // mention-sized GEMM weights (they matter for short candidate lists: at N = 11 the mention side is a third
@@ -265,7 +267,8 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   // precision_emulation.py; tests/test_gpu_round4.py).  At N = 11 the averaging is sqrt(11): 5-10e-5, no margin under the
   // 1e-4 bar - lists shorter than kMixedMinCandidates keep three passes (then the mode IS split-bf16, bit for bit).
   const bool i1 = cfg->precision == DRIN_PREC_BF16X3_I1 && cfg->num_candidates >= kMixedMinCandidates;
-  const int prec = (one_pass || cfg->precision == DRIN_PREC_BF16X3_I1) ? (int)DRIN_PREC_BF16X3 : cfg->precision;
+  const int prec = (one_pass || cfg->precision == DRIN_PREC_BF16X3_I1 || cfg->precision == DRIN_PREC_BF16X3_IF16) ? (int)DRIN_PREC_BF16X3
+                                                                                                                  : cfg->precision;
   const bool dyn = cfg->dynamic_edges != 0;
   const bool tokens = cfg->entity_tokens > 0;
   // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
@@ -277,6 +280,10 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   // kernel gains on that GEMM (-0.35 ms).  Only the table form, which has to gather the rows anyway, writes them.
   static const char* xi_env = getenv("DRIN_XI_PLANES");   // probe switch: image rows as planes in the gathered form too
   const bool xi_planes = planes && (indexed || (xi_env != nullptr && xi_env[0] == '1' && cfg->feature_dtype == DRIN_FEAT_F32));
+  // DRIN_PREC_BF16X3_IF16: x_i C_i^T in one FP16 pass, image rows scaled by a power of two each (k_entity_stream hands the
+  // scales over).  For the per-pair fp32 image rows of a call that fills whole 256 x 256 grids; everything else: three passes.
+  const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !xi_planes && cfg->feature_dtype == DRIN_FEAT_F32 &&
+                    gemm_nt_f16_scaled_fits(b->entity_image, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
   if (b->entity_text_cls) {
     set_error("drin_forward_prepared: entity_text_cls (text pooled ahead of time) is a form of the training entry points");
     return DRIN_E_UNSUPPORTED;
@@ -400,6 +407,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
       sa.xi_lo = (bf16_feat || one_pass || i1) ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
     }
   }
+  sa.xi_scale = if16 ? ws + L.xi_scale : nullptr;
   sa.e0m = ws + L.e0m;
   sa.e1m = ws + L.e1m;
   sa.s_part = ws + L.s_part;
@@ -451,6 +459,8 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
     else if (bf16_feat)  // the bf16 image rows are read in place as the (only) plane of the A operand
       DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, xi_one ? nullptr : ci + (size_t)D * R, R, nullptr,
                                      ws + L.h_image, D, M, D, R, st, psk, pskf));
+    else if (if16)
+      DRIN_TRY(launch_gemm_nt_f16_scaled(b->entity_image, R, pb + P.p_cimg_f16, R, ws + L.xi_scale, ws + L.h_image, D, M, D, R, st));
     else
       DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
                                      ci + (size_t)D * R, false, xi_one && cdiv(M, 256) * cdiv(D, 256) >= 192,
@@ -564,7 +574,8 @@ static PipePlan pipe_plan(const drin_config& c) {
     if (cus < 0) cus = e_cus;
     if (chunk_pairs < 0) chunk_pairs = e_pairs;
   }
-  const bool planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16X3_I1) &&
+  const bool planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16X3_I1 ||
+                       c.precision == DRIN_PREC_BF16X3_IF16) &&
                       c.embed_dim % 32 == 0 && c.image_dim % 32 == 0;
   if (cus <= 0 || cus >= 256 || chunk_pairs < 4096 || !planes) return p;
   int per = (int)std::max<int64_t>(1, chunk_pairs / c.num_candidates);

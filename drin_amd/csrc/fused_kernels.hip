@@ -235,6 +235,15 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // ---- image row + edges ----------------------------------------------------------------------------
     const Row<RV> xi = load_r(f_image + e * R);
     if (a.xi_hi) store_row_planes<RV, RP>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
+    if (a.xi_scale) {
+      // DRIN_PREC_BF16X3_IF16: the power of two that brings this row's largest |x| into [0.5, 1] - the contraction kernel
+      // divides the row by it (exact) before rounding to fp16 and multiplies its output row back
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < RV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(xi.v[j].x), fabsf(xi.v[j].y)), fmaxf(fabsf(xi.v[j].z), fabsf(xi.v[j].w))));
+      m = wave_max(m);
+      if (lane == 0) a.xi_scale[p] = pow2_at_least(m);
+    }
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
     const float e_it = (a.miet[p] / a.clip) * a.mask[2];

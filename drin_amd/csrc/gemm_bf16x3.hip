@@ -28,6 +28,8 @@ namespace drin {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace x3 {
 
@@ -79,6 +81,22 @@ struct Stager {
     if (KSUB == 2) {
 #pragma unroll
       for (int i = 0; i < PASSES; ++i) v2[i] = ld4(p[i] + k0 + BK);
+    }
+  }
+  // one FP16 pass: as store_rounded, every row multiplied by its (power-of-two: exact) factor first and rounded to fp16
+  __device__ __forceinline__ void store_f16(char* __restrict__ plane0, char* __restrict__ plane1, const float (&inv)[PASSES]) const {
+    const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      if (RAGGED && r + RPP * i >= ROWS) continue;
+      const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
+      f16x4 a, b;
+      const float4 x = v[i], y = v2[KSUB == 2 ? i : 0];
+      const float f = inv[i];
+      a[0] = (_Float16)(x.x * f), a[1] = (_Float16)(x.y * f), a[2] = (_Float16)(x.z * f), a[3] = (_Float16)(x.w * f);
+      b[0] = (_Float16)(y.x * f), b[1] = (_Float16)(y.y * f), b[2] = (_Float16)(y.z * f), b[3] = (_Float16)(y.w * f);
+      *reinterpret_cast<f16x4*>(plane0 + off) = a;
+      *reinterpret_cast<f16x4*>(plane1 + off) = b;
     }
   }
   // one-pass form: sub-block 0 rounded into the first plane, sub-block 1 into the second
@@ -170,12 +188,16 @@ struct Cfg {
 // accumulators to `tail` ([tile - full][ksplit - 1][BM][BN]) and k_tail_add folds them in afterwards, in order.
 // (B = 512 training: 606 tiles on 256 CUs = 2.37 rounds ran as 3; with the 94 tail tiles halved, as 2.5:
 //  same-box A/B of the whole step 8.55 -> 8.44 ms.)
-template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
+// F16 (with ONE_PASS; DRIN_PREC_BF16X3_IF16): the one pass runs on v_mfma_f32_16x16x32_f16 - 11-bit operands.  w_hi is then the
+// weight as an fp16 plane; row m of A is multiplied by 1 / a_scale[m] (a power of two: exact) on its way into LDS and output row
+// m by a_scale[m] in the epilogue, so that fp16's range never matters.
+template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false, bool F16 = false>
 __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
                   const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
                   int64_t ldc, int64_t M, int N, int K, int accumulate, unsigned col_tiles, unsigned full, int ksplit,
-                  float* __restrict__ tail, const int64_t* __restrict__ a_index) {
+                  float* __restrict__ tail, const int64_t* __restrict__ a_index, const float* __restrict__ a_scale) {
+  static_assert(!F16 || ONE_PASS, "the fp16 form is a one-pass form");
   using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with
@@ -234,8 +256,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     dma.init(w_hi, ONE_PASS ? w_hi + BK : w_lo, ldw, n0, N);
   else
     sb.init(W, ldw, n0, N);
+  float inv_s[decltype(sa)::PASSES];
+  if (F16) {
+#pragma unroll
+    for (int i = 0; i < decltype(sa)::PASSES; ++i) {
+      int64_t row = m0 + (threadIdx.x >> 3) + decltype(sa)::RPP * i;
+      row = row < M ? row : M - 1;
+      inv_s[i] = 1.0f / a_scale[row];
+    }
+  }
   auto stage_a = [&](char* buf) {
-    if (ONE_PASS)
+    if (F16)
+      sa.store_f16(buf, buf + G::A_PLANE, inv_s);
+    else if (ONE_PASS)
       sa.store_rounded(buf, buf + G::A_PLANE);
     else
       sa.template store<true>(buf, buf + G::A_PLANE);
@@ -280,9 +313,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
-        } else {   // (ah, bh): k sub-block 0 of the 64-wide block, (al, bl): sub-block 1
+        } else if (!F16) {   // (ah, bh): k sub-block 0 of the 64-wide block, (al, bl): sub-block 1
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], al, acc[i][j], 0, 0, 0);
+        } else {             // the same two sub-blocks as fp16 fragments (the planes hold fp16 bit patterns)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[j]), __builtin_bit_cast(f16x8, ah), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl[j]), __builtin_bit_cast(f16x8, al), acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -357,10 +393,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   for (int i = 0; i < G::MI; ++i) {
     const int64_t row = m0 + wm * (BM / WM) + i * 16 + r;  // C/D of a 16 x 16 tile: row lane & 15, columns 4 (lane >> 4) + v
     if (row >= M) continue;
+    const float rs = F16 ? a_scale[row] : 1.0f;
 #pragma unroll
     for (int j = 0; j < G::NI; ++j) {
       const int col = n0 + wn * (BN / WN) + j * 16 + c * 4;
       float* dst = C + row * ldc + col;
+      if (F16) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[i][j][v] *= rs;
+      }
       if (vec_ok && col + 3 < N) {
         float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         if (bias != nullptr) o = o + ld4(bias + col);
@@ -389,17 +430,17 @@ __global__ void __launch_bounds__(BN) k_tail_add(const float* __restrict__ tail,
   C[row * ldc + col] = s;
 }
 
-template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false>
+template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false, bool F16 = false>
 static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
                   const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate,
-                  float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr) {
+                  float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr, const float* a_scale = nullptr) {
   using G = Cfg<BM, BN, WM, WN>;
   const int64_t mt = cdiv(M, BM), nt = cdiv(N, BN);
   if (mt * nt > (int64_t)1 << 30) {
     set_error("gemm_bf16x3: %lld tiles exceed the grid limit; split the batch", (long long)(mt * nt));
     return DRIN_E_SHAPE;
   }
-  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES, ONE_PASS>;
+  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES, ONE_PASS, F16>;
   static DynLdsOptIn opt_in;  // one per template instantiation
   DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), G::LDS_BYTES, "hipFuncSetAttribute(gemm_bf16x3)"));
   // tail split (one workgroup per CU tiles only): the last round holds `frac` tiles; split K so that it fills the chip
@@ -431,7 +472,7 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
   const unsigned items = full + (tiles - full) * (unsigned)ksplit;
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(kern, dim3(items), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
-                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail, a_index);
+                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail, a_index, a_scale);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
   if (ksplit > 1) {
     hipLaunchKernelGGL((k_tail_add<BM, BN>), dim3(BM, tiles - full), dim3(BN), 0, st, tail, y, ldy, M, N, (unsigned)nt,
@@ -665,6 +706,44 @@ int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int
   hipLaunchKernelGGL((x3::k_tail_add<256, 256>), dim3(256, tail_tiles), dim3(256), 0, st, tail, y, ldy, M, N, col_tiles, full,
                      ksplit);
   DRIN_CHECK_LAUNCH("k_tail_add");
+  return DRIN_OK;
+}
+
+bool gemm_nt_f16_scaled_fits(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N,
+                             int K) {
+  return cdiv(M, 256) * cdiv(N, 256) >= 192 && K > 0 && (K % (2 * x3::BK)) == 0 && (ldx % 4) == 0 && (ldw % 8) == 0 && (N % 4) == 0 &&
+         (ldy % 4) == 0 && aligned16(x) && aligned16(w_f16) && aligned16(y);
+}
+
+int launch_gemm_nt_f16_scaled(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* row_scale, float* y, int64_t ldy,
+                              int64_t M, int N, int K, hipStream_t st) {
+  if (M <= 0 || N <= 0) return DRIN_OK;
+  if (row_scale == nullptr || !gemm_nt_f16_scaled_fits(x, ldx, w_f16, ldw, y, ldy, M, N, K)) {
+    set_error("gemm_f16_scaled: built for whole 256 x 256 grids, K %% 64 == 0, 16-byte aligned operands and a row-scale array");
+    return DRIN_E_UNSUPPORTED;
+  }
+  return x3::launch<256, 256, 2, 4, true, true, true>(x, ldx, nullptr, w_f16, w_f16, ldw, nullptr, y, ldy, M, N, K, st, false, nullptr, 0,
+                                                      nullptr, row_scale);
+}
+
+__global__ void __launch_bounds__(256) k_to_f16(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = ld4(x + i * 4);
+  f16x4 h;
+  h[0] = (_Float16)v.x, h[1] = (_Float16)v.y, h[2] = (_Float16)v.z, h[3] = (_Float16)v.w;
+  *reinterpret_cast<f16x4*>(out + i * 4) = h;
+}
+
+int launch_to_f16(const float* x, void* out, int64_t n, hipStream_t st) {
+  if (n <= 0) return DRIN_OK;
+  if ((n % 4) || !aligned16(x) || (reinterpret_cast<uintptr_t>(out) & 7u)) {
+    set_error("to_f16: %lld elements (multiple of 4) from a 16-byte aligned source", (long long)n);
+    return DRIN_E_SHAPE;
+  }
+  KernelTimer timer(DRIN_KC_GCN, st);
+  hipLaunchKernelGGL(k_to_f16, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, x, (_Float16*)out, n / 4);
+  DRIN_CHECK_LAUNCH("k_to_f16");
   return DRIN_OK;
 }
 

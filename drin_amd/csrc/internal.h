@@ -135,6 +135,14 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
                           const void* w_lo = nullptr, bool accumulate = false, bool one_pass = false,
                           float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr);
 // (a_index: row m of x is row a_index[m] of a table)
+// y = x w^T in ONE fp16 MFMA pass (DRIN_PREC_BF16X3_IF16): row m of x is multiplied by 1 / row_scale[m] (powers of two: exact)
+// before it is rounded to fp16 and output row m by row_scale[m] afterwards; w_f16 is the weight as one fp16 plane [N][K].
+// Whole 256 x 256 grids with K % 64 == 0 only: DRIN_E_UNSUPPORTED otherwise (the caller runs the split-bf16 product).
+int launch_gemm_nt_f16_scaled(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* row_scale, float* y, int64_t ldy,
+                              int64_t M, int N, int K, hipStream_t st);
+bool gemm_nt_f16_scaled_fits(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N, int K);
+// fp32 -> fp16 (round to nearest even), n % 4 == 0
+int launch_to_f16(const float* x, void* out, int64_t n, hipStream_t st);
 // (tail: optional scratch; a partly filled last round of 256 x 256 tiles is then split along K over the idle CUs)
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)

@@ -63,8 +63,8 @@ class GCNLayer(nn.Module):  # drin/model.py:109-119 (scaler edges: w_m is Identi
 
 # precisions that are modes of the fused inference path only: whatever else they meet (training, the per-entity cache,
 # geometries off the fused path, traced forwards) runs split-bf16
-_FUSED_ONLY = (_lib.PREC_BF16, _lib.PREC_BF16X3_I1)
-_PLANES = (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16, _lib.PREC_BF16X3_I1)
+_FUSED_ONLY = (_lib.PREC_BF16, _lib.PREC_BF16X3_I1, _lib.PREC_BF16X3_IF16)
+_PLANES = (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16, _lib.PREC_BF16X3_I1, _lib.PREC_BF16X3_IF16)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -521,7 +521,9 @@ class Model(nn.Module):
         1e-4 bar; training and every other path then run "bf16x3") or "bf16x3_i1" (precision by contraction: split-bf16 except
         the folded entity-image contraction, which runs one bf16 pass where the candidate list is long enough - N >= 64 - for
         the mean over candidates behind it to average its rounding noise down: <= 2.5e-5 on the scores at N = 101, inside the
-        1e-4 bar; shorter lists and every other path run "bf16x3");
+        1e-4 bar; shorter lists and every other path run "bf16x3") or "bf16x3_if16" (the same one pass on the FP16 matrix
+        instruction, every image row scaled by a power of two into fp16's range: <= 4e-6 on the scores at N = 101, <= 8e-6 at
+        N = 11 - the level of "bf16x3" itself - for the per-pair fp32 image rows of large inference calls; else "bf16x3");
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;
         `grad_bucket`: backward writes every gradient into one flat bucket the `.grad`s are views of (like DDP's
         `gradient_as_bucket_view`: a `.grad` kept across `zero_grad(set_to_none=True)` + `backward()` is overwritten)."""
@@ -538,7 +540,7 @@ class Model(nn.Module):
         self._layout = None
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL,
-                          "bf16": _lib.PREC_BF16, "bf16x3_i1": _lib.PREC_BF16X3_I1}[precision]
+                          "bf16": _lib.PREC_BF16, "bf16x3_i1": _lib.PREC_BF16X3_I1, "bf16x3_if16": _lib.PREC_BF16X3_IF16}[precision]
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 

@@ -52,7 +52,7 @@ typedef enum {
                            BF16X3 arithmetic.  Other entry points return DRIN_E_UNSUPPORTED for it. */
   DRIN_PREC_BF16X3_ALL = 3, /* BF16X3 also for the mention-sized contractions that BF16X3 leaves on
                               the fp32 kernel for latency reasons (used by the parity tests)      */
-  DRIN_PREC_BF16X3_I1 = 4  /* drin_forward_prepared only: precision BY CONTRACTION.  BF16X3 everywhere except the
+  DRIN_PREC_BF16X3_I1 = 4, /* drin_forward_prepared only: precision BY CONTRACTION.  BF16X3 everywhere except the
                               folded entity-image contraction x_i (W_h1 W_ei)^T - 57 % of the path's FLOPs - which runs
                               ONE bf16 MFMA pass (operands rounded, no lo planes).  Its result feeds only the layer-1
                               entity IMAGE vertex, which reaches the score through mean_n(ti' ei') in the layer-2
@@ -61,6 +61,14 @@ typedef enum {
                               |score - fp32 reference| <= 2.5e-5 (bar 1e-4), top-1 unchanged; taken only for
                               num_candidates >= 64 - shorter lists (N = 11: 5-10e-5, no margin) keep three passes and
                               equal BF16X3 bit for bit.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
+  DRIN_PREC_BF16X3_IF16 = 5 /* drin_forward_prepared only: as BF16X3_I1, but the one pass of the entity-image contraction runs
+                              on the FP16 matrix instruction (11-bit operands: an eighth of the bf16 pass's rounding error).
+                              fp16's range is made a non-issue by scaling every image row by a power of two (its max |x|
+                              into [0.5, 1): exact) before the conversion and the output row back afterwards; the folded
+                              weight is converted once by drin_prepare.  Measured: <= 4e-6 on the scores at N = 101 and <= 8e-6
+                              at N = 11 - the level of BF16X3 itself - so there is no candidate-count gate.  Taken for the
+                              per-pair fp32 image rows of large calls (the benchmark's form); bf16-stored features, the table
+                              form and small calls run BF16X3.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
 } drin_precision;
 
 /* Geometry + switches of one forward.  Names follow common/args.py. */

@@ -39,6 +39,11 @@ def _rounded_product_error(a: torch.Tensor, w: torch.Tensor, mode: str) -> torch
     if mode == "two_w":
         hi = _r(w)
         return _r(a) @ (hi + _r(w - hi)).T - exact
+    if mode == "one_f16":                            # one fp16 pass: 11-bit operands; activation rows scaled by a power of two
+        # (max |row| into [0.5, 1): exact, keeps every row inside fp16's range whatever the features' scale), weights as they are
+        sc = torch.exp2(torch.ceil(torch.log2(a.abs().amax(-1, keepdim=True).clamp_min(1e-30))))
+        h = lambda x: x.to(torch.float32).to(torch.float16).to(torch.float64)   # noqa: E731
+        return (h(a / sc) @ h(w).T) * sc - exact
     if mode == "x3":                                 # the default split product: hi hi + hi lo + lo hi (lo lo dropped)
         ah, wh = _r(a), _r(w)
         al, wl = _r(a - ah), _r(w - wh)

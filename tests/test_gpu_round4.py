@@ -255,3 +255,90 @@ def test_mixed_precision_short_candidate_lists_and_other_paths_stay_split_bf16()
     with torch.no_grad():
         ref16 = m_exact([t.float() if t.dtype == torch.bfloat16 else t for t in b16])
         assert (m_mixed(b16) - ref16).abs().max().item() <= 2.5e-5
+
+
+# ---- the same one pass on the FP16 matrix instruction, rows scaled into range (`bf16x3_if16`) --------------------------------
+def test_f16_image_contraction_every_score_of_a_headline_step():
+    """`precision="bf16x3_if16"`: x_i (W_h1 W_ei)^T in ONE pass of v_mfma_f32_16x16x32_f16 (11-bit operands), every image row
+    scaled by a power of two into fp16's range by the stream kernel's hand-over (`xi_scale`), the output row scaled back.  All
+    413 696 scores of a headline-sized step against the exact-fp32 MFMA path: <= 1e-5 - the guard every split-bf16 test of this
+    suite uses (bar 1e-4) - top-1 unchanged; CPU-oracle slices; the class time of the contraction next to split-bf16's."""
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    B = 4096
+    batch = synth.make_device_batch(cfg, B, 100, DEV)[:14]
+    exact, f16, x3 = _models(cfg, sd, "f32", "bf16x3_if16", "bf16x3")
+    assert f16.precision == _lib.PREC_BF16X3_IF16
+    _threads()
+    with torch.no_grad():
+        ref = exact(batch)
+        f16(batch)
+        _lib.profile_begin()
+        got = f16(batch)
+        prof_f16 = _lib.profile_end()
+        _lib.profile_begin()
+        base = x3(batch)
+        prof_x3 = _lib.profile_end()
+        err, err_x3 = (got - ref).abs().max().item(), (base - ref).abs().max().item()
+        top1 = (got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean().item()
+        worst_oracle = 0.0
+        for rows in (slice(0, 8), slice(2044, 2052), slice(B - 8, B)):
+            o = O.forward(sd, [t[rows].cpu() for t in batch])
+            worst_oracle = max(worst_oracle, (got[rows].cpu() - o).abs().max().item())
+        assert torch.equal(got, f16(batch))
+    print(f"bf16x3_if16 over {got.numel()} scores: max |score - exact fp32| {err:.2e} (bf16x3 {err_x3:.2e}), oracle slices {worst_oracle:.2e}, "
+          f"top-1 agreement {top1}; class 'gemm_x3' {prof_x3['gemm_x3'][0]:.3f} -> {prof_f16['gemm_x3'][0]:.3f} ms")
+    assert err <= 1e-5 and worst_oracle <= 1e-5 and top1 == 1.0
+    assert prof_f16["gemm_x3"][0] < 0.8 * prof_x3["gemm_x3"][0], "the one-pass fp16 kernel did not run"
+
+
+def test_f16_image_contraction_is_blind_to_the_scale_of_the_rows():
+    """fp16 holds 6e-5 .. 65 504: image rows far outside that (x 1e6, x 1e-6, x 3e37 next to the largest fp32 binades), an
+    all-zero row and ordinary rows in one batch.  The cosine / LayerNorm pipeline behind the contraction is not scale
+    invariant, so the yardstick is the exact-fp32 path on the SAME rows: <= 1e-5 on every score."""
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    B, N = 2048, cfg.num_candidates_model
+    batch = synth.make_device_batch(cfg, B, 55, DEV)[:14]
+    img = batch[9]                                                    # [B, N, 1, R]
+    img[0] *= 1e6
+    img[1] *= 1e-6
+    img[2, ::2] *= 3e4
+    img[3, 5] = 0.0
+    img[4] *= 1e-30
+    img[5, 7] *= 3e37 / img[5, 7].abs().max()
+    exact, f16 = _models(cfg, sd, "f32", "bf16x3_if16")
+    with torch.no_grad():
+        ref, got = exact(batch), f16(batch)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    print(f"rows scaled by 1e6 / 1e-6 / 3e4 / 0 / 1e-30 / up to 3e37: max |score - exact fp32| {err:.2e}")
+    assert err <= 1e-5
+    assert (got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).all()
+
+
+def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
+    """N = 11 (WikiDiverse-shaped, 16 384 mentions): the mean over candidates behind the contraction averages less, the fp16
+    pass still stays at the split product's level (<= 2e-5 here, bar 1e-4; emulation: 6e-6 over 2 816 scores).  Calls too small
+    for whole 256 x 256 grids, bf16-stored features and training run split-bf16 - bit for bit."""
+    cfg = DrinConfig()
+    sd = synth.make_state_dict(cfg, 7)
+    batch = synth.make_device_batch(cfg, 16384, 5, DEV)
+    exact, f16, x3 = _models(cfg, sd, "f32", "bf16x3_if16", "bf16x3")
+    with torch.no_grad():
+        ref, got = exact(batch[:14]), f16(batch[:14])
+        err = (got - ref).abs().max().item()
+        print(f"N = 11, 16 384 mentions: max |score - exact fp32| {err:.2e}")
+        assert err <= 2e-5 and (got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean().item() >= 0.9999
+        small = [t[:64] for t in batch[:14]]
+        assert torch.equal(f16(small), x3(small))
+        b16 = [t.to(torch.bfloat16) if i in (0, 4, 5, 7, 9, 10) else t for i, t in enumerate(batch[:14])]
+        assert torch.equal(f16(b16), x3(b16))
+    f16.train()
+    x3.train()
+    g = []
+    for m in (f16, x3):
+        m.zero_grad(set_to_none=True)
+        TripletLoss(cfg.triplet_margin)(batch[14][:64], m([t[:64] for t in batch[:14]])).backward()
+        g.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert all(torch.equal(g[0][k], g[1][k]) for k in g[0])

@@ -159,9 +159,13 @@ def test_precision_by_contraction_emulation():
     batch = synth.make_device_batch(cfg, 12, 5, "cpu")
     exact = scores_with_rounded_contraction(sd, batch)
     assert (exact - O.forward(sd, batch[:14], dtype=torch.float64)).abs().max().item() == 0.0     # the replay IS the oracle
-    err = contraction_errors(sd, batch, cases=(("image", "one"), ("image", "two_a"), ("text", "one"), ("wh2", "one"), ("image", "x3")))
+    err = contraction_errors(sd, batch, cases=(("image", "one"), ("image", "two_a"), ("text", "one"), ("wh2", "one"), ("image", "x3"),
+                                               ("image", "one_f16"), ("text", "one_f16")))
     print(err)
     assert err["image:one"]["max"] <= 3e-5 and err["image:one"]["top1_flips"] == 0
     assert err["image:two_a"]["max"] <= err["image:one"]["max"] * 1.2                 # a second pass buys little: one pass it is
     assert err["text:one"]["max"] >= 1e-4 and err["wh2:one"]["max"] >= 1e-4           # the D x D contractions have no such margin
     assert err["image:x3"]["max"] <= 1e-6
+    # the same single pass on fp16's 11-bit operands (rows scaled by a power of two into range: `bf16x3_if16`): an eighth of the
+    # bf16 pass's error - the level of the split product itself; a D x D contraction would still cost a third of the bar
+    assert err["image:one_f16"]["max"] <= 4e-6 and err["text:one_f16"]["max"] >= 2e-5

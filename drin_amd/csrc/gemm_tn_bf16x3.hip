@@ -231,6 +231,9 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
       }
     }
     row_tiles(buf, MI / 2, MI);
+    // (Measured in round 4 and left as it is - profiles/r4_train_fusions_ab.txt: a counted wait that keeps the stage kb + 2 loads
+    //  in flight across a raw barrier instead of this drain.  Same box, alternating: split-bf16 GEMM time per step 0.673 against
+    //  0.668 ms at B = 64, 4.07-4.10 against 4.05-4.08 at B = 512 - the drain is not what this kernel waits for.)
     __syncthreads();
   }
 

@@ -562,7 +562,9 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
         # every kernel of the step, not the dominant one alone: HBM bytes per step from the committed PMC passes (replayed)
         # against the compulsory input bytes - intermediates that round-trip through HBM show up here
         "hbm_traffic_whole_path": whole_traffic,
-        "hbm_traffic_whole_path_over_algorithmic": (whole_traffic / (ab["whole_path"] * pairs)) if whole_traffic else None,
+        # (compulsory bytes of THIS path: through the per-entity cache a pair needs its cache row, not its raw feature rows)
+        "hbm_traffic_whole_path_over_algorithmic": (whole_traffic / (((stream_bytes_pair + ab["mention_pool"] + 4) if cached
+                                                                      else ab["whole_path"]) * pairs)) if whole_traffic else None,
         "hbm_traffic_whole_path_source": (f"{TRAFFIC_FILE} whole_path: launches per call x FETCH_SIZE / WRITE_SIZE bytes per launch of every "
                                           "kernel of the call (tools/collect_pmc.py), replayed - not re-measured in this run") if whole_traffic else None,
         "launch": "hipGraph replay" if graph else "eager",

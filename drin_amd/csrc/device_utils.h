@@ -29,10 +29,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// max over the 64 lanes of non-negative values, the same way (the DPP fill value 0 is neutral for them)
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
+  v = dpp_max<0xB1>(v);
+  v = dpp_max<0x4E>(v);
+  v = dpp_max<0x141>(v);
+  v = dpp_max<0x140>(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // the smallest power of two >= m for a positive finite m (1 for m == 0, a NaN or an infinity: such a row is not scaled -
 // its NaNs / infinities propagate through the product as they are)

@@ -283,6 +283,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   // DRIN_PREC_BF16X3_IF16: x_i C_i^T in one FP16 pass, image rows scaled by a power of two each (k_entity_stream hands the
   // scales over).  For the per-pair fp32 image rows of a call that fills whole 256 x 256 grids; everything else: three passes.
   const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !xi_planes && cfg->feature_dtype == DRIN_FEAT_F32 &&
+                    D == 768 && R == 2048 &&   // (the stream kernel's row-scale hand-over is an instantiation of the exact widths)
                     gemm_nt_f16_scaled_fits(b->entity_image, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
   if (b->entity_text_cls) {
     set_error("drin_forward_prepared: entity_text_cls (text pooled ahead of time) is a form of the training entry points");

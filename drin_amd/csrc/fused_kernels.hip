@@ -18,7 +18,9 @@ namespace drin {
 // EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048): the column guards of the row helpers fold away
 // FT: storage type of the feature tensors (float, or __bf16 with drin_config.feature_dtype = DRIN_FEAT_BF16 - half
 // the bytes of this HBM-bound pass; all arithmetic stays fp32)
-template <int DV, int RV, bool TOKENS, bool EXACT, typename FT>
+// XSCALE: also hand over a power-of-two scale per image row (DRIN_PREC_BF16X3_IF16) - a separate instantiation, so that the
+// code (and the register allocation: 230 VGPRs) of every other call is what it was
+template <int DV, int RV, bool TOKENS, bool EXACT, typename FT, bool XSCALE = false>
 __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const FT* const f_text = static_cast<const FT*>(a.entity_text);
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // ---- image row + edges ----------------------------------------------------------------------------
     const Row<RV> xi = load_r(f_image + e * R);
     if (a.xi_hi) store_row_planes<RV, RP>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
-    if (a.xi_scale) {
+    if constexpr (XSCALE) {
       // DRIN_PREC_BF16X3_IF16: the power of two that brings this row's largest |x| into [0.5, 1] - the contraction kernel
       // divides the row by it (exact) before rounding to fp16 and multiplies its output row back
       float m = 0.f;
@@ -339,10 +341,10 @@ size_t entity_stream_lds_bytes(const StreamArgs& a) {
   return sizeof(float) * (a.Km * R + 2 * R + 2 * D + 2 * R + 3 * D + a.Km + 4);
 }
 
-template <int DV, int RV, bool TOKENS, bool EXACT, typename FT>
+template <int DV, int RV, bool TOKENS, bool EXACT, typename FT, bool XSCALE = false>
 static int launch_stream_ft(const StreamArgs& a, hipStream_t st) {
   const size_t lds = entity_stream_lds_bytes(a);
-  auto kern = k_entity_stream<DV, RV, TOKENS, EXACT, FT>;
+  auto kern = k_entity_stream<DV, RV, TOKENS, EXACT, FT, XSCALE>;
   static DynLdsOptIn opt_in;  // one per template instantiation
   if (lds > 48 * 1024)
     DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(entity_stream)"));
@@ -354,6 +356,13 @@ static int launch_stream_ft(const StreamArgs& a, hipStream_t st) {
 
 template <int DV, int RV, bool TOKENS, bool EXACT>
 static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
+  if (a.xi_scale != nullptr) {   // fp32 features at the exact widths only (fused_forward.hip decides)
+    if constexpr (EXACT && DV == 3) {
+      if (!a.bf16_features) return launch_stream_ft<DV, RV, TOKENS, EXACT, float, true>(a, st);
+    }
+    set_error("entity_stream: row scales are built for fp32 features at D = 768, R = 2048");
+    return DRIN_E_UNSUPPORTED;
+  }
   return a.bf16_features ? launch_stream_ft<DV, RV, TOKENS, EXACT, __bf16>(a, st)
                          : launch_stream_ft<DV, RV, TOKENS, EXACT, float>(a, st);
 }

@@ -346,6 +346,10 @@ __device__ __forceinline__ void issue_unit(const Src& s, char* buf, int kb) {
 
 }  // namespace p4
 
+// A_LO = false: the activation operand is exact in bf16 (features stored as bf16: the image rows read in place) - the hi x lo_a
+// term does not exist, 16 MFMAs per phase instead of 24.  The A units keep their shape and their DMA count (the wave group that
+// would fetch the lo plane fetches the hi plane once more, into the slot nobody reads), so that every counted wait is unchanged.
+template <bool A_LO = true>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes_p4(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                         const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     for (int i = 0; i < 4; ++i) {
       const char* p = buf + half * p4::UNIT_BYTES + swz16(wm * 64 + i * 16 + r, c);
       ah[i] = *reinterpret_cast<const bf16x8*>(p);
-      al[i] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
+      if (A_LO) al[i] = *reinterpret_cast<const bf16x8*>(p + 128 * 64);
     }
   };
   auto read_b = [&](const char* buf, int half) {
@@ -421,10 +425,12 @@ __global__ void __launch_bounds__(THREADS, 2)
     // term-major over the quadrant's eight tiles: an accumulator's next MFMA is eight issues away (same order of the three
     // terms per accumulator as everywhere: hi lo, lo hi, hi hi - same bits)
     if (p4::kTermMajor) {
+      if (A_LO) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+      }
       mid();
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -438,7 +444,8 @@ __global__ void __launch_bounds__(THREADS, 2)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+          if (A_LO) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], cc[i][j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], cc[i][j], 0, 0, 0);
 #pragma unroll
@@ -1075,15 +1082,19 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
   }
   {  // the full split product (both lo planes) on whole tiles + tail slices: the four-phase pipeline (DRIN_P4=0: the previous kernel, for A/Bs)
     static const char* p4 = getenv("DRIN_P4");
-    if (!(p4 != nullptr && p4[0] == '0') && a_lo_plane && b_lo_plane && splits == 1 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) &&
-        (bias == nullptr || aligned16(bias))) {
-      static DynLdsOptIn opt;
-      DRIN_TRY(ensure_dynamic_lds(opt, reinterpret_cast<const void*>(x3p::k_gemm_x3_planes_p4), x3p::p4::LDS, "hipFuncSetAttribute(gemm_x3_planes_p4)"));
+    // (an activation operand without a lo plane - exact in bf16 - takes the A_LO = false instantiation from half a round of tiles up;
+    //  smaller grids of it keep the two-phase kernel and its split-K forms)
+    if (!(p4 != nullptr && p4[0] == '0') && b_lo_plane && (a_lo_plane || tiles >= 128) && splits == 1 && (N % 4) == 0 && (ldy % 4) == 0 &&
+        aligned16(y) && (bias == nullptr || aligned16(bias))) {
+      static DynLdsOptIn opt[2];
+      auto kern = a_lo_plane ? x3p::k_gemm_x3_planes_p4<true> : x3p::k_gemm_x3_planes_p4<false>;
+      DRIN_TRY(ensure_dynamic_lds(opt[a_lo_plane ? 0 : 1], reinterpret_cast<const void*>(kern), x3p::p4::LDS, "hipFuncSetAttribute(gemm_x3_planes_p4)"));
       const unsigned p4_items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
       {
         KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
-        hipLaunchKernelGGL(x3p::k_gemm_x3_planes_p4, dim3(p4_items), dim3(x3p::THREADS), x3p::p4::LDS, st, (const __bf16*)a_hi,
-                           (const __bf16*)a_lo, lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K, nx, full, ksplit, splitk);
+        hipLaunchKernelGGL(kern, dim3(p4_items), dim3(x3p::THREADS), x3p::p4::LDS, st, (const __bf16*)a_hi,
+                           (const __bf16*)(a_lo_plane ? a_lo : a_hi), lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K, nx,
+                           full, ksplit, splitk);
         DRIN_CHECK_LAUNCH("k_gemm_x3_planes_p4");
       }
       if (ksplit > 1) DRIN_TRY(launch_tail_add_256(splitk, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));

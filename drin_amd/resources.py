@@ -131,8 +131,22 @@ def untracked_load_hazards(isa: List[tuple]) -> List[str]:
                 pending.append((text, set()))
 
     index = {a: k for k, (a, _t, _b) in enumerate(isa)}
+    # if / else as the compiler lays it out - `s_cbranch ELSE; <then>; s_branch END; ELSE: <else>; END:` - is two paths, not one
+    # sequence: nothing falls through an unconditional branch, so the instruction behind it starts from the state of the
+    # conditional branch that leads there (the first one recorded).  At a join the fall-through state goes on (the straight-line
+    # K-loops this check exists for have no joins; a then-side load that is still in flight behind its join is not followed).
+    entry: dict = {}
+    dead = False
     for k, (addr, text, target) in enumerate(isa):
+        if dead and addr in entry:
+            pending[:] = entry[addr]
+        entry.pop(addr, None)
+        dead = False
         step(text)
+        mnem = text.split(" ", 1)[0]
+        if target is not None and target > addr and mnem.startswith("s_cbranch"):
+            entry.setdefault(target, list(pending))
+        dead = mnem == "s_branch" and target is not None and target > addr
         if target is not None and target <= addr and target in index:     # a loop closes here: its body once more
             for _a, t2, _b in isa[index[target]:k + 1]:
                 step(t2)

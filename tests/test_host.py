@@ -311,8 +311,11 @@ def test_untracked_loads_are_not_touched_before_their_counted_wait():
     over the other hand-pipelined kernels, and over a synthetic sequence with exactly that slip, which it must flag."""
     from drin_amd import build, resources
     build.build(verbose=False)
-    for obj, kernel, min_insns in (("gemm_x3_planes.o", "k_gemm_bf16x3_p4", 1000), ("gemm_x3_planes.o", "k_gemm_x3_planes_p4", 800),
-                                   ("gemm_bf16x3.o", "k_gemm_bf16x3", 1000), ("gemm_tn_bf16x3.o", "k_gemm_tn", 500),
+    for obj, kernel, min_insns in (("gemm_x3_planes.o", "k_gemm_bf16x3_p4", 1000), ("gemm_x3_planes.o", "k_gemm_x3_planes_p4ILb1E", 800),
+                                   ("gemm_x3_planes.o", "k_gemm_x3_planes_p4ILb0E", 800),
+                                   ("gemm_bf16x3.o", "k_gemm_bf16x3ILi256ELi256ELi2ELi4ELb1ELb1ELb0E", 1000),     # one bf16 pass: counted wait
+                                   ("gemm_bf16x3.o", "k_gemm_bf16x3ILi256ELi256ELi2ELi4ELb1ELb1ELb1E", 1000),     # one fp16 pass
+                                   ("gemm_bf16x3.o", "k_gemm_bf16x3ILi256ELi256ELi2ELi4ELb1ELb0ELb0E", 1000), ("gemm_tn_bf16x3.o", "k_gemm_tn", 500),
                                    ("fused_kernels.o", "k_entity_stream", 1000), ("entity_cache.o", "k_cached_pairs", 1000)):
         isa = resources.kernel_isa(obj, kernel)
         assert len(isa) >= min_insns, (obj, kernel, len(isa))
@@ -332,4 +335,8 @@ def test_untracked_loads_are_not_touched_before_their_counted_wait():
             (24, "global_load_dwordx4 v[6:9], v[162:163], off", None), (32, "v_mov_b32_e32 v21, v7", None),   # copied too early
             (36, "s_waitcnt vmcnt(0)", None), (40, "v_mov_b32_e32 v21, v7", None)]
     assert len(resources.untracked_load_hazards(fake)) == 1
+    # an if / else the compiler lays out as load | s_branch over | mov into the same registers is NOT a hazard (two paths) ...
+    ifelse = [(0, "s_cbranch_scc1 5", 16), (4, "global_load_dwordx2 v[4:5], v[2:3], off", None), (12, "s_branch 1", 20),
+              (16, "v_mov_b64_e32 v[4:5], v[12:13]", None), (20, "s_waitcnt vmcnt(0)", None), (24, "v_add_u32_e32 v6, v4, v5", None)]
+    assert not resources.untracked_load_hazards(ifelse)
 

@@ -287,7 +287,7 @@ KERNEL_NAMES = {"stream": "k_entity_stream", "gemm_planes": "k_gemm_x3_planes", 
                 "gcn": "row kernels (k_pair_layer1, k_pair_final, ...)", "pool": "pooling kernels", "edge": "edge kernels"}
 
 
-def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused):
+def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused, cache_format="f32"):
     """Roofline object of the dominant kernel class of an instrumented pass + the whole-path fractions' inputs."""
     D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
     pairs = B * N
@@ -301,7 +301,10 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
     if cached:
         # k_cached_pairs: one gathered cache row in (h_t, h_i, c^, o^, sg and, with dynamic edges, fv_t, fv_i),
         # the candidate index and two similarities; et' planes and the four layer-2 edges out
-        row = ((5 if cfg.gcn_edge_type == "dynamic" else 3) * D + R + 4) * 4
+        dyn = cfg.gcn_edge_type == "dynamic"
+        row = ((5 if dyn else 3) * D + R + 4) * 4
+        if cache_format == "mixed_f16":    # h_t, h_i, c^ fp32; o^ (and fv_t, fv_i) scaled fp16; sg + the three scales (drin_hip.h)
+            row = 3 * D * 4 + ((2 if dyn else 0) * D + R) * 2 + 16
         stream_bytes_pair = row + 8 + 8 + D * 4 + 16
         flops_pair = 2.0 * D * D
     names = dict(KERNEL_NAMES)
@@ -311,7 +314,8 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
         work = stream_bytes_pair * pairs * steps / max(launches, 1)
         achieved = work / (per_launch_ms * 1e-3) / 1e9
         default_cfg = B == 4096 and precision == "bf16x3" and fused and features == "f32" and workload == "wikimel"
-        traffic = (measured_traffic("k_cached_pairs", "kernels_table_cache", B == 4096 and features == "f32") if cached
+        traffic = (measured_traffic("k_cached_pairs", "kernels_table_cache_mixed_f16" if cache_format == "mixed_f16" else "kernels_table_cache",
+                                    B == 4096 and features == "f32") if cached
                    else measured_traffic("k_entity_stream", "kernels", default_cfg))
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
@@ -526,10 +530,12 @@ def run_score(ctx, model, batch, steps, warmup, graph=False):
     return elapsed, per_rank, out, prof
 
 
-def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup, precision, features, workload, cached, fused, graph=False):
+def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup, precision, features, workload, cached, fused, graph=False,
+               cache_format=None):
     D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
     pairs = B * N
-    roof, ab, stream_bytes_pair, flops_pair = score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused)
+    cache_format = cache_format or getattr(args, "cache_format", "f32")
+    roof, ab, stream_bytes_pair, flops_pair = score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused, cache_format)
     value = pairs * ctx.world * steps / elapsed
     fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision)
     # the one HBM-bound pass over the entity bytes, whichever class is the longest of this leg
@@ -541,7 +547,8 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
                       "algorithmic_bytes_per_launch": s_bytes, "achieved": s_bytes / (s_ms / s_n * 1e-3) / 1e9, "unit": "GB/s",
                       "frac": s_bytes / (s_ms / s_n * 1e-3) / 1e9 / PEAK_HBM_GBS}
     default_cfg = B == 4096 and precision == "bf16x3" and fused and features == "f32" and workload == "wikimel"
-    whole_traffic = (measured_whole_path_traffic("kernels_table_cache", B == 4096 and features == "f32") if cached
+    whole_traffic = (measured_whole_path_traffic("kernels_table_cache_mixed_f16" if cache_format == "mixed_f16" else "kernels_table_cache",
+                                                 B == 4096 and features == "f32") if cached
                      else measured_whole_path_traffic("kernels", default_cfg))
     line = {
         "metric": "mention x candidate pairs scored/sec",
@@ -568,7 +575,7 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
         "hbm_traffic_whole_path_source": (f"{TRAFFIC_FILE} whole_path: launches per call x FETCH_SIZE / WRITE_SIZE bytes per launch of every "
                                           "kernel of the call (tools/collect_pmc.py), replayed - not re-measured in this run") if whole_traffic else None,
         "launch": "hipGraph replay" if graph else "eager",
-        "path": ("per-entity cache + layer 2" if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + precision
+        "path": ((f"per-entity cache ({cache_format} rows) + layer 2") if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + precision
                 + (", features stored as bf16" if features == "bf16" else ""),
         "algorithmic": {"bytes_per_pair": ab["whole_path"], "dominant_kernel_bytes_per_pair": stream_bytes_pair,
                         "bytes_per_pair_split": ab, "flops_per_pair_executed": flops_pair, "flops_per_pair_reference": ref_flops},
@@ -923,6 +930,9 @@ def parse_args(argv=None):
                     help="wikimel: 100-cand token-level (headline); wikidiverse: 10-cand pooled; table: BASELINE config 5 - "
                          "1000 candidates per mention gathered on the device from a table of --entities random entities")
     ap.add_argument("--entities", type=int, default=1_000_000)
+    ap.add_argument("--cache-format", default="f32", choices=["f32", "mixed_f16"],
+                    help="--entity-cache: row format of the per-entity cache (drin_cache_format): every field fp32, or the fields that "
+                         "reach the score through an per-pair scalars' operands stored as scaled fp16 (16.4 KB instead of 23.5 KB per pair)")
     ap.add_argument("--entity-cache", action="store_true",
                     help="table workload: score from the per-entity precompute cache (SURVEY.md 8f-2; built during warm-up)")
     ap.add_argument("--mentions", type=int, default=0,
@@ -1056,7 +1066,7 @@ def main(argv=None):
     if args.workload == "table":
         table, g = build_table(cfg, args.entities, dev)
         if args.entity_cache:
-            table.enable_cache()
+            table.enable_cache(True, format=args.cache_format)
         if args.mentions:
             # config 5 streamed: a step is one chunk; K is fixed by --mentions / --chunk
             with torch.no_grad():
@@ -1071,7 +1081,7 @@ def main(argv=None):
                                            f"{args.entities}-entity table, streamed in chunks of {args.chunk} mentions (each drawn on the device right before it is scored)",
                                "mentions_per_step_per_gpu": args.chunk, "pairs_per_step": args.chunk * N * world,
                                "parallelism": f"dp{world} (mentions sharded, no collective)"},
-                    "path": ("per-entity cache + layer 2" if args.entity_cache else "fused two-layer") + ", " + args.precision}
+                    "path": (f"per-entity cache ({args.cache_format} rows) + layer 2" if args.entity_cache else "fused two-layer") + ", " + args.precision}
             if rank == 0:
                 line["parity"] = parity_of_timed_batch(cfg, sd, last, out, n_slices=2, width=1)
                 emit(line)
@@ -1242,6 +1252,20 @@ def main(argv=None):
                         "value": mentions * N / el, "ms_per_step": el / n_chunks * 1e3, "steps": n_chunks,
                         "resident_chunk_value": ln["value"],
                         "parity": parity_of_timed_batch(tc, tsd, last, o2, n_slices=8, width=1)})
+            # the same chunks from DRIN_CACHE_MIXED_F16 rows (precision by storage: the operands of per-pair scalars as scaled
+            # fp16, 16.4 KB per pair instead of 23.5): every score of the resident chunk against the fp32 rows'
+            table.enable_cache(True, format="mixed_f16")
+            with torch.no_grad():
+                m(make_table_chunk(tc, table, 64, 99, dev, g))              # builds the 16.4 GB cache
+            el_m, n_m, _, _ = stream_table(ctx, m, tc, table, g, mentions, chunk)
+            e, pr, o3, pf = run_score(ctx, m, last, st, 1)
+            lm = score_line(ctx, tc, args, chunk, last, e, pr, pf, st, 1, "bf16x3", "f32", "table", True, True, cache_format="mixed_f16")
+            rm = compact(lm)
+            rm.update({"value": mentions * N / el_m, "ms_per_step": el_m / n_m * 1e3, "steps": n_m, "resident_chunk_value": lm["value"],
+                       "parity": parity_of_timed_batch(tc, tsd, last, o3, n_slices=8, width=1),
+                       "vs_f32_rows": {"max_abs_score_diff": float((o3 - o2).abs().max()), "scores": int(o3.numel()),
+                                       "top1_agreement": float((o3[:, :-1].argmax(1) == o2[:, :-1].argmax(1)).float().mean())}})
+            res["mixed_f16_rows"] = rm
             return res
         extra["table_cache"] = leg_guard("table_cache", table_leg)
 

@@ -15,11 +15,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DRIN_LIB_PATH: another build of the same library (the sanitizer build of `python -m drin_amd.build --asan-host`)
 LIB_PATH = os.environ.get("DRIN_LIB_PATH") or os.path.join(_HERE, "libdrin_hip.so")
 MAX_LAYERS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_BF16X3_ALL, PREC_BF16X3_I1, PREC_BF16X3_IF16 = 0, 1, 2, 3, 4, 5
 FEAT_F32, FEAT_BF16 = 0, 1
+CACHE_F32, CACHE_MIXED_F16 = 0, 1                                      # drin_cache_format
+CACHE_FORMATS = {"f32": CACHE_F32, "mixed_f16": CACHE_MIXED_F16}
 ACTIVATIONS = {"gelu": 1, "sigmoid": 2, "relu": 3, "tanh": 4, "silu": 5}   # drin_activation
 
 fp = C.POINTER(C.c_float)
@@ -35,7 +37,7 @@ class DrinConfigC(C.Structure):
         ("dynamic_edges", C.c_int32), ("edge_enabled", C.c_float * 4), ("layer_norm_eps", C.c_float),
         ("cosine_eps", C.c_float), ("miei_eps", C.c_float), ("clip_scale", C.c_float), ("precision", C.c_int32),
         ("num_entities", C.c_int32), ("vector_edges", C.c_int32), ("feature_dtype", C.c_int32),
-        ("vertex_activation", C.c_int32), ("edge_activation", C.c_int32),
+        ("vertex_activation", C.c_int32), ("edge_activation", C.c_int32), ("cache_format", C.c_int32),
     ]
 
 

@@ -151,6 +151,10 @@ int validate_config(const drin_config* c) {
     set_error("config: edge_activation %d is not a drin_activation", c->edge_activation);
     return DRIN_E_UNSUPPORTED;
   }
+  if (c->cache_format != DRIN_CACHE_F32 && c->cache_format != DRIN_CACHE_MIXED_F16) {
+    set_error("config: cache_format %d is not a drin_cache_format", c->cache_format);
+    return DRIN_E_UNSUPPORTED;
+  }
   if (c->precision != DRIN_PREC_F32 && c->precision != DRIN_PREC_BF16X3 && c->precision != DRIN_PREC_BF16X3_ALL &&
       c->precision != DRIN_PREC_BF16 && c->precision != DRIN_PREC_BF16X3_I1 && c->precision != DRIN_PREC_BF16X3_IF16) {
     set_error("config: precision %d is not a drin_precision", c->precision);

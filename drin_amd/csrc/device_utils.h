@@ -57,6 +57,10 @@ __device__ __forceinline__ float pow2_at_least(float m) {
   return p;
 }
 
+// the scale of one fp16 field of a DRIN_CACHE_MIXED_F16 row: |x| / scale <= 1, and the scale's reciprocal is a normal
+// number too (2^-126 .. 2^126), so that dividing and multiplying by it are exact in any denormal mode
+__device__ __forceinline__ float cache_field_scale(float max_abs) { return fminf(pow2_at_least(max_abs), 0x1p126f); }
+
 // v = hi + lo with hi = bf16(v), lo = bf16(v - hi), both rounded to nearest-even (the operand planes of the split-bf16
 // products).  Written on PAIRS: one packed conversion gives both hi's, two bit operations widen them again, a packed
 // subtract and one packed conversion give both lo's - five vector instructions per pair.  Element by element the same
@@ -112,6 +116,29 @@ __device__ __forceinline__ u32x4_t ld16_stream(const char* p) {
 #else
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 #endif
+}
+// eight raw bytes (four fp16 of a DRIN_CACHE_MIXED_F16 row) per lane, same policy
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2_t ld8_stream(const char* p) {
+#ifdef DRIN_NO_NT_LOADS
+  return *reinterpret_cast<const u32x2_t*>(p);
+#else
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+#endif
+}
+// four fp16 values in two dwords <-> float4 (widening is exact; narrowing rounds to nearest even)
+__device__ __forceinline__ float4 f16x4_to_float4(uint32_t a, uint32_t b) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t x = __builtin_bit_cast(h2_t, a), y = __builtin_bit_cast(h2_t, b);
+  return make_float4((float)x[0], (float)x[1], (float)y[0], (float)y[1]);
+}
+__device__ __forceinline__ u32x2_t float4_to_f16x4(float4 v) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t x = {(_Float16)v.x, (_Float16)v.y}, y = {(_Float16)v.z, (_Float16)v.w};
+  u32x2_t r;
+  r[0] = __builtin_bit_cast(uint32_t, x);
+  r[1] = __builtin_bit_cast(uint32_t, y);
+  return r;
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

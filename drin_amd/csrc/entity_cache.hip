@@ -21,6 +21,23 @@
 //
 // The cache is a function of the weights: it is rebuilt (one pass over the table + four table-sized GEMMs)
 // whenever they change, so it serves inference / evaluation with frozen weights - never training.
+//
+// Row formats (drin_cache_format).  DRIN_CACHE_F32, floats:  h_t 0 | h_i D | fv_t 2D | fv_i 3D | c^ 4D | o^ 5D | sg 5D+R (+3 pad).
+// DRIN_CACHE_MIXED_F16 - precision by storage: the three contraction results / direction rows that carry a vertex (h_t, h_i)
+// or the text-text edge (c^) stay fp32; the operands of per-pair SCALARS that only enter a sigmoid or a weight - fv_t, fv_i
+// (mean_d(.) inside the edge sigmoid, model.py:148-153) and o^ (the image-image edge, model.py:84-92, which feeds mi' and ei'
+// alone) - are fp16, each with ONE power-of-two scale per row (2^ceil(log2 max|.|): exact to apply, so the row may have any
+// magnitude; fp16 keeps 11 bits and a D- or R-long dot averages its rounding).  Floats:
+//   h_t 0 | h_i D | c^ 2D [fp32] | fv 3D [per float4 column c4 one 16-byte unit: fv_t[4 c4 .. +3], fv_i[4 c4 .. +3]] |
+//   o^ 4D [R f16, natural order: read in the PAIR layout of row_ops.h] | tail 4D + R/2: sg, s_fvt, s_fvi, s_o
+// 16 400 B per entity instead of 23 568 at D = 768, R = 2 048.  k_cached_pairs at config 5 is bound by the gathered
+// row bytes down to ~12 ms per 4 096 x 1 001 chunk (tools/cached_floor_probe.sh: 19.2-19.7 ms on the fp32 rows, 11.7 ms
+// with every row L2-resident), so the smaller row is worth its conversions.  Emulated cost on the scores
+// (oracle/precision_emulation.py::scores_with_rounded_cache_fields): 2e-7 at N = 101, 6e-7 at N = 11 - below the split-bf16
+// contractions' own 1.3e-6.  (h_i as fp16 too - 14 880 B - was built and measured first: 139-140 M pairs/s against 133-135,
+// 2.3e-6 emulated on a homogeneous table.  Not kept: h_i is a VERTEX operand - the cached path forms the layer-1 mention
+// aggregates from sum_n e h_i - so its 2^-12 rounding is averaged only as long as the candidates' rows are of one size, and
+// ten times the error for 4 % of the chunk time is the wrong trade on a 1e-4 bar: profiles/r4_mixed_cache_ab.txt.)
 #include <string.h>
 
 #include <stdlib.h>
@@ -32,7 +49,11 @@
 
 namespace drin {
 
-static inline size_t cache_row_floats(const drin_config& c) { return 5 * (size_t)c.embed_dim + c.image_dim + 4; }
+static inline bool cache_mixed(const drin_config& c) { return c.cache_format == DRIN_CACHE_MIXED_F16; }
+static inline size_t cache_row_floats(const drin_config& c) {
+  const size_t D = (size_t)c.embed_dim, R = (size_t)c.image_dim;
+  return cache_mixed(c) ? 4 * D + R / 2 + 4 : 5 * D + R + 4;
+}
 constexpr int64_t kCacheSlab = 262144;  // entities per builder slab (pooled-text scratch: slab * D floats)
 
 struct CacheBuildArgs {
@@ -45,6 +66,7 @@ struct CacheBuildArgs {
   int64_t ldc, rows;
   int D4, R4, T, Ke;
   float cos_eps;
+  int mixed;                         // DRIN_CACHE_MIXED_F16 row (c^ at 2 D, o^ as scaled fp16 at 4 D, tail at 4 D + R / 2)
 };
 
 // one wave per entity
@@ -94,7 +116,7 @@ __global__ void __launch_bounds__(256) k_entity_cache_rows(const CacheBuildArgs 
     const float inv = 1.0f / fmaxf(sqrtf(wave_sum(dot_rows<DV>(cls, cls))), a.cos_eps);
 #pragma unroll
     for (int j = 0; j < DV; ++j) cls.v[j] = cls.v[j] * inv;
-    store_row<DV>(row + 4 * D, cls, lane, D4);
+    store_row<DV>(row + (a.mixed ? 2 * D : 4 * D), cls, lane, D4);
   }
   Row<RV> o = zero_row<RV>();
   float sg = 0.f;
@@ -104,8 +126,68 @@ __global__ void __launch_bounds__(256) k_entity_cache_rows(const CacheBuildArgs 
     axpy_row<RV>(o, es / fmaxf(sqrtf(wave_sum(dot_rows<RV>(eo, eo))), a.cos_eps), eo);
     sg += es;
   }
+  if (a.mixed) {  // o^ as fp16 under one power-of-two scale; tail = sg, s_fvt, s_fvi (k_cache_pack_mixed), s_o
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < RV; ++j)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(o.v[j].x), fabsf(o.v[j].y)), fmaxf(fabsf(o.v[j].z), fabsf(o.v[j].w))));
+    const float s_o = cache_field_scale(wave_max(m)), inv = 1.0f / s_o;
+    char* dst = reinterpret_cast<char*>(row + 4 * D);
+#pragma unroll
+    for (int j = 0; j < RV; ++j) {
+      const int c4 = lane + 64 * j;
+      if (c4 < R4) *reinterpret_cast<u32x2_t*>(dst + (size_t)c4 * 8) = float4_to_f16x4(o.v[j] * inv);
+    }
+    float* tail = row + 4 * D + R / 2;
+    if (lane == 0) {
+      tail[0] = sg;
+      tail[3] = s_o;
+    }
+    return;
+  }
   store_row<RV>(row + 5 * D, o, lane, R4);
   if (lane == 0) st4(row + 5 * D + R, make_float4(sg, 0.f, 0.f, 0.f));
+}
+
+// DRIN_CACHE_MIXED_F16: the two table-sized edge-update products fv_t, fv_i ([rows][2 D] fp32 scratch) -> scaled fp16 in the
+// cache row.  One wave per entity.
+template <int DV>
+__global__ void __launch_bounds__(256) k_cache_pack_mixed(const float* __restrict__ tmp, float* __restrict__ cache, int64_t ldc,
+                                                          int64_t rows, int D4, int R4, int have_fv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= rows) return;
+  const int D = D4 * 4, R = R4 * 4;
+  float* row = cache + e * ldc;
+  const float* src = tmp + e * 2 * (int64_t)D;
+  Row<DV> f[2];
+  float sc[2], inv[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    f[k] = have_fv ? load_row<DV>(src + (int64_t)k * D, lane, D4) : zero_row<DV>();
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < DV; ++j)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(f[k].v[j].x), fabsf(f[k].v[j].y)), fmaxf(fabsf(f[k].v[j].z), fabsf(f[k].v[j].w))));
+    sc[k] = cache_field_scale(wave_max(m));
+    inv[k] = 1.0f / sc[k];
+  }
+  char* fv = reinterpret_cast<char*>(row + 3 * D);
+#pragma unroll
+  for (int j = 0; j < DV; ++j) {
+    const int c4 = lane + 64 * j;
+    if (c4 < D4) {
+      const u32x2_t t = float4_to_f16x4(f[0].v[j] * inv[0]), i = float4_to_f16x4(f[1].v[j] * inv[1]);
+      u32x4_t u;
+      u[0] = t[0], u[1] = t[1], u[2] = i[0], u[3] = i[1];
+      *reinterpret_cast<u32x4_t*>(fv + (size_t)c4 * 16) = u;
+    }
+  }
+  if (lane == 0) {
+    float* tail = row + 4 * D + R / 2;
+    tail[1] = sc[0];
+    tail[2] = sc[1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,7 +224,26 @@ struct CachedArgs {
 #endif
 // EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048) - the column guards of the row helpers fold away and the
 // loop body becomes straight-line code
-template <int DV, int RV, bool EXACT, bool GENERIC_ACT = false>
+// the edge-phase operands of one cache row: 17 KB of the 23.5 KB fp32 row; in the mixed format 10.2 KB - c^ and the raw
+// fp16 units of fv_t | fv_i and o^ (widened where they are used: half the registers while the row is in flight) + the scales
+template <int DV, int RV, bool MIXED>
+struct CachedPairRow;
+template <int DV, int RV>
+struct CachedPairRow<DV, RV, false> {
+  Row<DV> chat, fvt, fvi;
+  Row<RV> ohat;
+  float sg, mtei, miet;
+};
+template <int DV, int RV>
+struct CachedPairRow<DV, RV, true> {
+  Row<DV> chat;
+  u32x4_t fv[DV];       // per float4 column: fv_t (two dwords), fv_i (two dwords)
+  u32x4_t oh[RV / 2];   // o^ in the PAIR layout: eight consecutive columns per lane and load
+  float sg, s_fvt, s_fvi, s_o, mtei, miet;
+};
+
+// MIXED: rows in the DRIN_CACHE_MIXED_F16 format (RV even)
+template <int DV, int RV, bool EXACT, bool GENERIC_ACT = false, bool MIXED = false>
 __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pairs(const CachedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D4 = EXACT ? DV * 64 : a.D4, R4 = EXACT ? RV * 64 : a.R4, D = D4 * 4, R = R4 * 4;
@@ -194,19 +295,38 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
         st4(l_fu + i * 4, ld4(a.fu + ((int64_t)which * a.B + b) * a.ldfu + c4 * 4));
       }
   }
-  struct PairRow {  // the operands of the edge phase: 17 KB of the 23.5 KB row
-    Row<DV> chat, fvt, fvi;
-    Row<RV> ohat;
-    float sg, mtei, miet;
-  };
+  typedef CachedPairRow<DV, RV, MIXED> PairRow;
   auto fetch = [&](PairRow& r, int64_t e, int64_t p) {
     const float* row = a.cache + e * a.ldc;
-    r.chat = load_row_stream<DV>(row + 4 * D, lane, D4);
-    r.ohat = load_row_stream<RV>(row + 5 * D, lane, R4);
-    r.sg = row[5 * D + R];
-    if (dyn) {
-      r.fvt = load_row_stream<DV>(row + 2 * D, lane, D4);
-      r.fvi = load_row_stream<DV>(row + 3 * D, lane, D4);
+    if constexpr (MIXED) {
+      r.chat = load_row_stream<DV>(row + 2 * D, lane, D4);
+      const char* op = reinterpret_cast<const char*>(row + 4 * D);
+#pragma unroll
+      for (int q = 0; q < RV / 2; ++q) {
+        const int c8 = lane + 64 * q;
+        if (2 * c8 < R4) r.oh[q] = ld16_stream(op + (size_t)c8 * 16);
+        else r.oh[q] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+      const float* tail = row + 4 * D + R / 2;
+      r.sg = tail[0];
+      r.s_fvt = tail[1];
+      r.s_fvi = tail[2];
+      r.s_o = tail[3];
+      const char* fp = reinterpret_cast<const char*>(row + 3 * D);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        const int c4 = lane + 64 * j;
+        if (dyn && c4 < D4) r.fv[j] = ld16_stream(fp + (size_t)c4 * 16);
+        else r.fv[j] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+    } else {
+      r.chat = load_row_stream<DV>(row + 4 * D, lane, D4);
+      r.ohat = load_row_stream<RV>(row + 5 * D, lane, R4);
+      r.sg = row[5 * D + R];
+      if (dyn) {
+        r.fvt = load_row_stream<DV>(row + 2 * D, lane, D4);
+        r.fvi = load_row_stream<DV>(row + 3 * D, lane, D4);
+      }
     }
     r.mtei = a.mtei[p];
     r.miet = a.miet[p];
@@ -269,19 +389,53 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later pairs' loads into this one (spills)
     // the vertex-phase operands of THIS pair: requested now, needed after the edge phase
     const Row<DV> ht = load_row_stream<DV>(a.cache + e_cur * a.ldc, lane, D4);
-    const Row<DV> hi = load_row_stream<DV>(a.cache + e_cur * a.ldc + D, lane, D4);
+    const Row<DV> hi = load_row_stream<DV>(a.cache + e_cur * a.ldc + D, lane, D4);   // (same offset in both formats)
     // ---- static edges (model.py:71-92, 201-204) ------------------------------------------------------------
     const float e_tt = wave_sum(dot_row_lds<DV>(r.chat, l_s, lane, D4)) * a.mask[0];
     const float e_ti = (r.mtei / a.clip) * a.mask[1];
     const float e_it = (r.miet / a.clip) * a.mask[2];
-    const float e_ii = wave_sum(dot_row_lds<RV>(r.ohat, l_mu, lane, R4)) / (sum_ms * r.sg + a.miei_eps) * a.mask[3];
+    float e_ii;
+    if constexpr (MIXED) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < RV / 2; ++q) {
+        const int c8 = lane + 64 * q;
+        if (2 * c8 < R4) {
+          s += dot4(f16x4_to_float4(r.oh[q][0], r.oh[q][1]), ld4(l_mu + c8 * 8));
+          s += dot4(f16x4_to_float4(r.oh[q][2], r.oh[q][3]), ld4(l_mu + c8 * 8 + 4));
+        }
+      }
+      e_ii = wave_sum(s) * r.s_o / (sum_ms * r.sg + a.miei_eps) * a.mask[3];
+    } else {
+      e_ii = wave_sum(dot_row_lds<RV>(r.ohat, l_mu, lane, R4)) / (sum_ms * r.sg + a.miei_eps) * a.mask[3];
+    }
     // ---- layer-2 edges (model.py:148-153; static: pass-through, model.py:136) ------------------------------
     float n_tt = e_tt, n_ti = e_ti, n_it = e_it, n_ii = e_ii;
     if (dyn) {
-      n_tt = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvt, l_fu, lane, D4)) * inv_d + e_tt);
-      n_ti = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvi, l_fu, lane, D4)) * inv_d + e_ti);
-      n_it = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvt, l_fu + D, lane, D4)) * inv_d + e_it);
-      n_ii = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
+      if constexpr (MIXED) {
+        float d_tt = 0.f, d_ti = 0.f, d_it = 0.f, d_ii = 0.f;
+#pragma unroll
+        for (int j = 0; j < DV; ++j) {
+          const int c4 = lane + 64 * j;
+          if (c4 < D4) {
+            const float4 t = f16x4_to_float4(r.fv[j][0], r.fv[j][1]), i = f16x4_to_float4(r.fv[j][2], r.fv[j][3]);
+            const float4 u0 = ld4(l_fu + c4 * 4), u1 = ld4(l_fu + D + c4 * 4);
+            d_tt += dot4(t, u0);
+            d_ti += dot4(i, u0);
+            d_it += dot4(t, u1);
+            d_ii += dot4(i, u1);
+          }
+        }
+        n_tt = edge_act_apply(a.act_e, wave_sum(d_tt) * r.s_fvt * inv_d + e_tt);
+        n_ti = edge_act_apply(a.act_e, wave_sum(d_ti) * r.s_fvi * inv_d + e_ti);
+        n_it = edge_act_apply(a.act_e, wave_sum(d_it) * r.s_fvt * inv_d + e_it);
+        n_ii = edge_act_apply(a.act_e, wave_sum(d_ii) * r.s_fvi * inv_d + e_ii);
+      } else {
+        n_tt = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvt, l_fu, lane, D4)) * inv_d + e_tt);
+        n_ti = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvi, l_fu, lane, D4)) * inv_d + e_ti);
+        n_it = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvt, l_fu + D, lane, D4)) * inv_d + e_it);
+        n_ii = edge_act_apply(a.act_e, wave_sum(dot_row_lds<DV>(r.fvi, l_fu + D, lane, D4)) * inv_d + e_ii);
+      }
     }
     n_tt *= a.mask[0];
     n_ti *= a.mask[1];
@@ -455,14 +609,19 @@ static int cache_supported(const drin_config* c) {
     set_error("entity cache: bf16 feature storage / DRIN_PREC_BF16 / DRIN_PREC_BF16X3_I1 belong to drin_forward_prepared only");
     return DRIN_E_UNSUPPORTED;
   }
+  if (cache_mixed(*c) && (c->embed_dim % 8 || c->image_dim % 8)) {
+    set_error("entity cache: DRIN_CACHE_MIXED_F16 needs embed_dim %% 8 == 0 and image_dim %% 8 == 0 (got %d, %d)", c->embed_dim,
+              c->image_dim);
+    return DRIN_E_SHAPE;
+  }
   return DRIN_OK;
 }
 
-template <int DV, int RV, bool EXACT, bool GENERIC_ACT = false>
+template <int DV, int RV, bool EXACT, bool GENERIC_ACT = false, bool MIXED = false>
 static int launch_cached_pairs_t(const CachedArgs& a, hipStream_t st) {
   const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;
   const size_t lds = sizeof(float) * (9 * D + R + 32 + 12 * D);
-  auto kern = k_cached_pairs<DV, RV, EXACT, GENERIC_ACT>;
+  auto kern = k_cached_pairs<DV, RV, EXACT, GENERIC_ACT, MIXED>;
   static DynLdsOptIn opt_in;  // one per template instantiation
   if (lds > 48 * 1024)
     DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), (int)lds, "hipFuncSetAttribute(cached_pairs)"));
@@ -486,7 +645,8 @@ DRIN_API size_t drin_entity_cache_bytes(const drin_config* cfg) {
 DRIN_API size_t drin_entity_cache_build_workspace_bytes(const drin_config* cfg) {
   if (validate_config(cfg) != DRIN_OK || cache_supported(cfg) != DRIN_OK) return 0;
   const int64_t slab = cfg->num_entities < kCacheSlab ? cfg->num_entities : kCacheSlab;
-  return (size_t)slab * cfg->embed_dim * sizeof(float);
+  // pooled text of a slab; mixed format: + the two table-sized products that are stored as fp16 ([slab][2 D] fp32)
+  return (size_t)slab * cfg->embed_dim * sizeof(float) * (cache_mixed(*cfg) ? 3 : 1);
 }
 
 DRIN_API size_t drin_cached_workspace_bytes(const drin_config* cfg) {
@@ -527,6 +687,9 @@ DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* t
   const bool dyn = cfg->dynamic_edges != 0;
   const int prec = cfg->precision;
   float* xt = (float*)workspace;
+  const bool mixed = cache_mixed(*cfg);
+  const int64_t slab_rows = E < kCacheSlab ? E : kCacheSlab;
+  float* tmp = xt + slab_rows * (int64_t)D;   // mixed format: [slab][2 D] = fv_t | fv_i
   for (int64_t e0 = 0; e0 < E; e0 += kCacheSlab) {
     const int64_t rows = E - e0 < kCacheSlab ? E - e0 : kCacheSlab;
     float* crow = (float*)cache + e0 * ldc;
@@ -545,6 +708,7 @@ DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* t
     a.T = T;
     a.Ke = cfg->entity_objects;
     a.cos_eps = cfg->cosine_eps;
+    a.mixed = mixed ? 1 : 0;
     {
       KernelTimer timer(DRIN_KC_STREAM, st);
       const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
@@ -561,11 +725,25 @@ DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* t
     }
     const float* ximg = tables->entity_image + e0 * (int64_t)R;
     // h_t = x_t C_t^T, h_i = x_i C_i^T
+    // (mixed format: h_t, h_i straight into the row, the two fp16 fields through the fp32 scratch and k_cache_pack_mixed)
+    float* const y_hi = crow + D;
+    float* const y_fvt = mixed ? tmp : crow + 2 * D;
+    float* const y_fvi = mixed ? tmp + D : crow + 3 * D;
+    const int64_t ldy = mixed ? 2 * (int64_t)D : ldc;
     DRIN_TRY(launch_gemm_nt(xt, D, pb + P.c_txt, D, nullptr, crow, ldc, rows, D, D, false, prec, st));
-    DRIN_TRY(launch_gemm_nt(ximg, R, pb + P.c_img, R, nullptr, crow + D, ldc, rows, D, R, false, prec, st));
+    DRIN_TRY(launch_gemm_nt(ximg, R, pb + P.c_img, R, nullptr, y_hi, ldc, rows, D, R, false, prec, st));
     if (dyn) {  // fv = x (W_v1 W_e)^T + (W_v1 b_e + b_v1); etmp keeps W_v1 [W_et | W_ei] un-transposed, row stride D + R
-      DRIN_TRY(launch_gemm_nt(xt, D, pb + P.etmp, D + R, pb + P.k_t, crow + 2 * D, ldc, rows, D, D, false, prec, st));
-      DRIN_TRY(launch_gemm_nt(ximg, R, pb + P.etmp + D, D + R, pb + P.k_i, crow + 3 * D, ldc, rows, D, R, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(xt, D, pb + P.etmp, D + R, pb + P.k_t, y_fvt, ldy, rows, D, D, false, prec, st));
+      DRIN_TRY(launch_gemm_nt(ximg, R, pb + P.etmp + D, D + R, pb + P.k_i, y_fvi, ldy, rows, D, R, false, prec, st));
+    }
+    if (mixed) {   // (static edges: zero units, unit scales)
+      KernelTimer timer(DRIN_KC_STREAM, st);
+      const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+      if (D / 4 <= 64)
+        hipLaunchKernelGGL((k_cache_pack_mixed<1>), grid, block, 0, st, tmp, crow, ldc, rows, D / 4, R / 4, dyn ? 1 : 0);
+      else
+        hipLaunchKernelGGL((k_cache_pack_mixed<3>), grid, block, 0, st, tmp, crow, ldc, rows, D / 4, R / 4, dyn ? 1 : 0);
+      DRIN_CHECK_LAUNCH("k_cache_pack_mixed");
     }
   }
   return DRIN_OK;
@@ -667,7 +845,19 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   a.ln_eps = cfg->layer_norm_eps;
   a.act_v = vertex_act(cfg);
   a.act_e = edge_act(cfg);
-  if (a.act_v != DRIN_ACT_GELU && a.D4 <= 64 && a.R4 <= 64)   // non-default vertex activation: the generic-width instantiations
+  if (cache_mixed(*cfg)) {   // DRIN_CACHE_MIXED_F16 rows (the o^ row is read in the PAIR layout: an even number of slots)
+    const bool gen = a.act_v != DRIN_ACT_GELU, tiny = a.D4 <= 64 && a.R4 <= 128;
+    if (gen && tiny)
+      DRIN_TRY((launch_cached_pairs_t<1, 2, false, true, true>(a, st)));
+    else if (gen)
+      DRIN_TRY((launch_cached_pairs_t<3, 8, false, true, true>(a, st)));
+    else if (tiny)
+      DRIN_TRY((launch_cached_pairs_t<1, 2, false, false, true>(a, st)));
+    else if (a.D4 == 192 && a.R4 == 512)
+      DRIN_TRY((launch_cached_pairs_t<3, 8, true, false, true>(a, st)));
+    else
+      DRIN_TRY((launch_cached_pairs_t<3, 8, false, false, true>(a, st)));
+  } else if (a.act_v != DRIN_ACT_GELU && a.D4 <= 64 && a.R4 <= 64)   // non-default vertex activation: the generic-width instantiations
     DRIN_TRY((launch_cached_pairs_t<1, 1, false, true>(a, st)));
   else if (a.act_v != DRIN_ACT_GELU)
     DRIN_TRY((launch_cached_pairs_t<3, 8, false, true>(a, st)));

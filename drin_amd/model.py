@@ -134,16 +134,23 @@ class EntityTable:
     def __init__(self, text, mask, image, object, object_score):
         self.text, self.mask, self.image, self.object, self.object_score = text, mask, image, object, object_score
         self.cache_enabled = False
+        self.cache_format = "f32"
         self._cache: Optional[torch.Tensor] = None
         self._cache_key = None
         self._pooled = None
 
-    def enable_cache(self, on: bool = True) -> "EntityTable":
+    def enable_cache(self, on: bool = True, format: str = "f32") -> "EntityTable":
         """Let inference calls score from a per-entity precompute cache (`drin_build_entity_cache`):
-        23.5 KB per entity at D=768 / R=2048, rebuilt by the first inference call after any weight change."""
+        23.5 KB per entity at D=768 / R=2048, rebuilt by the first inference call after any weight change.
+        `format="mixed_f16"` (`DRIN_CACHE_MIXED_F16`): the operands of per-pair scalars - the two edge-update rows and the object
+        row - are stored as fp16 under a power-of-two scale per row and field, the vertex contractions and the CLS row stay
+        fp32: 16.4 KB per entity, scores within ~2e-7 of the fp32 rows' (`oracle/precision_emulation.py`)."""
+        if format not in _lib.CACHE_FORMATS:
+            raise ValueError(f"cache format {format!r}: one of {sorted(_lib.CACHE_FORMATS)}")
         self.cache_enabled = on
-        if not on:
+        if not on or format != self.cache_format:
             self._cache, self._cache_key = None, None
+        self.cache_format = format
         return self
 
     def invalidate(self) -> "EntityTable":
@@ -158,7 +165,8 @@ class EntityTable:
                      if t is not None)
 
     def _get_cache(self, call: "_Call", key, pc, prepared: torch.Tensor) -> torch.Tensor:
-        key = (key, call.cfg.precision, call.cfg.num_entities, self._table_key())
+        call.cfg.cache_format = _lib.CACHE_FORMATS[self.cache_format]
+        key = (key, call.cfg.precision, call.cfg.num_entities, call.cfg.cache_format, self._table_key())
         if key != self._cache_key or self._cache is None:
             lib = _lib.load()
             n = lib.drin_entity_cache_bytes(C.byref(call.cfg))
@@ -195,7 +203,7 @@ class EntityTable:
     def to(self, device) -> "EntityTable":
         mv = lambda t: None if t is None else t.to(device)  # noqa: E731
         moved = EntityTable(mv(self.text), mv(self.mask), mv(self.image), mv(self.object), mv(self.object_score))
-        moved.cache_enabled = self.cache_enabled
+        moved.cache_enabled, moved.cache_format = self.cache_enabled, self.cache_format
         return moved
 
     def gather(self, index: torch.Tensor):

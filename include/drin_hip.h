@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRIN_ABI_VERSION 4
+#define DRIN_ABI_VERSION 5
 #define DRIN_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -106,7 +106,23 @@ typedef struct {
                                return DRIN_E_UNSUPPORTED (widen the features on the caller side). */
   int32_t vertex_activation; /* drin_activation: gcn_vertex_activation (args.py:35; model.py:117,128), default gelu    */
   int32_t edge_activation;   /* drin_activation: gcn_edge_activation   (args.py:36; model.py:118,133), default sigmoid */
+  int32_t cache_format;      /* drin_cache_format: row format of the per-entity cache (drin_build_entity_cache /
+                                drin_forward_cached only; every other entry point ignores it)                           */
 } drin_config;
+
+/* Row format of the per-entity precompute cache.  DRIN_CACHE_F32: every field fp32 ([5 D + R + 4] floats per entity).
+ * DRIN_CACHE_MIXED_F16 ("precision by storage"): the fields that carry a vertex or the text-text edge - the two layer-1
+ * entity contractions h_t, h_i and the normalised CLS row (model.py:71-76,128,146) - stay fp32; the operands of per-pair
+ * SCALARS - W_v1(et0), W_v1(ei0) (the edge update: a mean over D inside a sigmoid, model.py:148-153) and the score-weighted
+ * normalised object row (the image-image edge, model.py:84-92, which feeds mi' and ei' alone) - are stored as fp16 with one
+ * power-of-two scale per field and row (exact to apply; the row may have any magnitude): [4 D + R / 2 + 4] floats per
+ * entity, 16 400 B instead of 23 568 at D = 768, R = 2 048.  Effect on the scores: 2e-7 at N = 101, 6e-7 at N = 11
+ * (oracle/precision_emulation.py; measured: tests/test_gpu_round4.py) - below the split-bf16 contractions' own 1.3e-6.
+ * Needs embed_dim % 8 == 0 and image_dim % 8 == 0. */
+typedef enum {
+  DRIN_CACHE_F32 = 0,
+  DRIN_CACHE_MIXED_F16 = 1
+} drin_cache_format;
 
 /* The reference resolves `getattr(torch.nn.functional, name)` (model.py:117-118) - any function name.  Built here: the
  * five below for the vertices; sigmoid, tanh and relu for the edges (their backward needs the derivative from the stored
@@ -325,7 +341,8 @@ DRIN_API int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs);
  * With frozen weights, what the first GCN layer takes from an entity (its rows of the entity_* tables,
  * `drin/data.py:87-93`) does not depend on the mention: `W_h1 W_et x_t`, `W_h1 W_ei x_i`, `W_v1(et0)`,
  * `W_v1(ei0)`, the normalised CLS row and the score-weighted normalised object row are computed ONCE per
- * entity and weight version into `cache` ([num_entities][5 D + R + 4] fp32).  drin_forward_cached then
+ * entity and weight version into `cache` ([num_entities][5 D + R + 4] fp32; cfg.cache_format = DRIN_CACHE_MIXED_F16:
+ * [num_entities][4 D + R / 2 + 4] floats of fp32 and scaled-fp16 fields, see drin_cache_format).  drin_forward_cached then
  * scores table-form batches (drin_batch.entity_index + the mention-side tensors + the two similarity
  * matrices; the entity_* pointers are not read) with one gathered pass over cache rows and the layer-2
  * contraction - same scores as drin_forward_prepared to fp32 re-association.  `cfg.num_entities` = table

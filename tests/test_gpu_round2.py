@@ -507,3 +507,39 @@ def test_train_cli_runs_end_to_end(tmp_path, dataset, monkeypatch):
     import re
     assert sum(bool(re.match(r"^\d+:\t\[", r)) for r in rows) == 2 * 8   # two test passes x 8 mentions (the answer rows' repr may wrap)
     assert rows[0].startswith("0:\t[") and len(eval(rows[0].split(":\t", 1)[1])) == cfg.num_candidates_model
+
+
+def test_config5_mixed_f16_cache_rows_every_score_of_a_chunk(million_entity_table):
+    """`EntityTable.enable_cache(format="mixed_f16")` at config 5's own shape (2 048 mentions x 1 001 candidates over the
+    1 000 003-row table, 128-candidate workgroups of `k_cached_pairs<3, 8, exact, MIXED>`): ALL 2 050 048 scores against the
+    fp32 cache rows - the storage format's own effect, emulated at 2e-7 for 101 candidates - top-1 unchanged on every mention; three slices against the CPU oracle."""
+    import os
+    cfg, table = million_entity_table
+    sd = synth.make_state_dict(cfg, 7)
+    B, N, E = 2048, cfg.num_candidates_model, table.num_entities
+    g = torch.Generator(device=DEV).manual_seed(23)
+    men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 24, DEV)
+    cand = torch.randint(0, E, (B, N), device=DEV, generator=g)
+    sims = 20.0 + 5.0 * torch.randn(2, B, N, device=DEV, generator=g)
+    ib = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    try:
+        with torch.no_grad():
+            table.enable_cache(True)
+            full = model(ib)
+            table.enable_cache(True, format="mixed_f16")
+            mixed = model(ib)
+            assert table._cache.numel() == E * 16400 and torch.equal(mixed, model(ib))
+            err = (mixed - full).abs().max().item()
+            flips = int((mixed[:, :-1].argmax(1) != full[:, :-1].argmax(1)).sum())
+            torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+            worst = 0.0
+            for rows in ([0, 1], [B // 2], [B - 1]):
+                sub = IndexedBatch([t[rows] for t in men[:7]], table, cand[rows], sims[0][rows], sims[1][rows])
+                ref = O.forward(sd, [t.cpu() for t in sub.gathered()])
+                worst = max(worst, (mixed[rows].cpu() - ref).abs().max().item())
+    finally:
+        table.enable_cache(False)
+    print(f"config 5, mixed-f16 cache rows: max |score - fp32 rows| over {B * N} scores {err:.2e}, top-1 flips {flips}, vs oracle {worst:.2e}")
+    assert err <= 2e-6 and flips == 0 and worst <= 1e-5

@@ -343,3 +343,110 @@ def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
         TripletLoss(cfg.triplet_margin)(batch[14][:64], m([t[:64] for t in batch[:14]])).backward()
         g.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     assert all(torch.equal(g[0][k], g[1][k]) for k in g[0])
+
+
+# ---- precision by storage: the per-entity cache's DRIN_CACHE_MIXED_F16 rows ---------------------------------------------
+TINY = dict(bert_embed_dim=64, gcn_embed_dim=64, resnet_embed_dim=128, max_mention_sentence_len=12, resnet_num_region=5)
+
+
+def _table_case(cfg, E, B, seed):
+    from drin_amd.model import EntityTable, IndexedBatch
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, seed)
+    table = EntityTable(tab[7][0], tab[8][0] if cfg.token_level_entities else None, tab[9][0], tab[10][0], tab[11][0]).to(DEV)
+    men = [t.to(DEV) for t in synth.make_batch(cfg, B, seed + 1)]
+    cand = torch.randint(0, E, (B, cfg.num_candidates_model), generator=torch.Generator().manual_seed(seed)).to(DEV)
+    return table, IndexedBatch(men[:7], table, cand, men[12], men[13])
+
+
+@pytest.mark.parametrize("kw", [
+    dict(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY),
+    dict(num_candidates_data=20, **TINY),
+    dict(num_candidates_data=20, gcn_edge_type="static", **TINY),
+    dict(dataset_name="wikimel", num_candidates_data=36, max_entity_attr_token_len=7, gcn_edge_enabled=(1, 0, 1, 1), **TINY),
+    dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16, resnet_num_region=4),
+    dict(num_candidates_data=20, gcn_vertex_activation="silu", gcn_edge_activation="tanh", **TINY),
+    dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16, resnet_num_region=4,
+         gcn_vertex_activation="relu", gcn_edge_activation="relu"),
+    dict(dataset_name="wikimel", num_candidates_data=100, max_entity_attr_token_len=8, max_mention_sentence_len=16, resnet_num_region=4,
+         bert_embed_dim=512, gcn_embed_dim=512, resnet_embed_dim=1024),
+], ids=["tiny_tokens", "tiny_pooled", "tiny_static", "tiny_mask", "wikimel_dims", "tiny_silu_tanh", "wikimel_dims_relu", "guarded_512_1024"])
+def test_mixed_f16_cache_rows_against_the_fp32_rows_and_the_oracle(kw):
+    """Every instantiation of `k_cached_pairs<..., MIXED>` (tiny / exact / guarded widths, default and by-name activations,
+    static edges, an edge switched off): scores from the 16.4 KB-class rows against the fp32 rows (the storage format's own
+    effect) and against the oracle on the gathered 14-sequence; same bits on a second call; the cache buffer has the mixed
+    format's size; switching formats rebuilds it."""
+    cfg = DrinConfig(**kw)
+    sd = synth.make_state_dict(cfg, 8)
+    E, B = 83, 5
+    table, ib = _table_case(cfg, E, B, 71)
+    D, R = cfg.gcn_embed_dim, cfg.resnet_embed_dim
+    ref = O.forward(sd, [t.cpu() for t in ib.gathered()], **O.config_kwargs(cfg))
+    for precision in ("bf16x3_all", "f32"):
+        model = Model(cfg, precision=precision).to(DEV).eval()
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            table.enable_cache(True)
+            full = model(ib)
+            assert table._cache.numel() == E * (5 * D + R + 4) * 4
+            table.enable_cache(True, format="mixed_f16")
+            assert table._cache is None                                # another format: the fp32 rows are dropped
+            mixed = model(ib)
+            assert table._cache.numel() == E * (4 * D + R // 2 + 4) * 4
+            assert torch.equal(mixed, model(ib))
+        d_fmt, d_ref = (mixed - full).abs().max().item(), (mixed.cpu() - ref).abs().max().item()
+        print(f"{precision}: mixed-f16 rows vs fp32 rows {d_fmt:.2e}, vs oracle {d_ref:.2e} (N = {cfg.num_candidates_model})")
+        # the fp16 operands' rounding is averaged over the D (R) columns of a dot: 64 (128) columns at the tiny widths - and a
+        # tanh edge passes it on at slope 1 where the sigmoid has 1/4 - against 512-768 (1 024-2 048) at the full ones
+        assert d_fmt <= (2e-5 if D < 256 else 3e-6) and d_ref <= (2.5e-5 if D < 256 else 1e-5)
+        assert (mixed[:, :-1].argmax(1).cpu() == ref[:, :-1].argmax(1)).all()
+    table.enable_cache(False)
+    with pytest.raises(ValueError):
+        table.enable_cache(True, format="f8")
+
+
+def test_mixed_f16_cache_rows_hold_rows_of_any_magnitude():
+    """fp16 holds 6e-5 .. 65 504; the cached edge-update rows follow the scale of the entity's image row (fv_i = W_v1(W_ei x_i +
+    b) + b).  One power-of-two scale per row and field keeps every row inside fp16 whatever its magnitude: entities whose
+    image rows are scaled by 1e-6 and 1e-30, an all-zero image row and an all-zero object score, next to ordinary ones - the
+    mixed rows against the fp32 rows on the SAME tables, every score within 1e-5.  Rows scaled UP by 1e6 and to 3e37 (fv_i
+    ~ 5e5 .. 1e37: inf as plain fp16) come out finite and equal too - except where an edge logit mean_d(W_u(u) W_v(v)) of
+    magnitude ~1e5 happens to land inside the sigmoid's unsaturated few units: there 11 bits and 24 bits of a 1e5-sized
+    number are both noise (the fp32 rows' own logit is then good to 1e-2), so for those mentions the test asks for agreement
+    on 99 % of the scores, not on all."""
+    from drin_amd.model import EntityTable, IndexedBatch
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    E, B, N = 600, 64, cfg.num_candidates_model
+    g = torch.Generator(device=DEV).manual_seed(3)
+    img = torch.randn(E, cfg.resnet_embed_dim, device=DEV, generator=g)
+    img[0:50] *= 1e6
+    img[150] *= 3e37 / img[150].abs().max()
+    img[50:100] *= 1e-6
+    img[100:149] *= 1e-30
+    img[151] = 0.0
+    score = torch.rand(E, 1, device=DEV, generator=g)
+    score[152] = 0.0
+    table = EntityTable(torch.randn(E, 4, cfg.bert_embed_dim, device=DEV, generator=g), torch.ones(E, 4, dtype=torch.int64, device=DEV),
+                        img, torch.randn(E, 1, cfg.resnet_embed_dim, device=DEV, generator=g), score)
+    men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 12, DEV)
+    cand = torch.randint(50, E, (B, N), device=DEV, generator=g)                       # rows 0-49 (x 1e6) only where planted
+    cand[cand == 150] = 153
+    cand[:, :5] = torch.tensor([60, 120, 151, 152, 300], device=DEV)                   # every mention: small, tiny, zero rows
+    cand[B // 2:, 5:9] = torch.tensor([0, 17, 49, 150], device=DEV)                    # second half: the huge rows as well
+    sims = 20.0 + 5.0 * torch.randn(2, B, N, device=DEV, generator=g)
+    ib = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        table.enable_cache(True)
+        full = model(ib)
+        table.enable_cache(True, format="mixed_f16")
+        mixed = model(ib)
+    table.enable_cache(False)
+    assert torch.isfinite(mixed).all() and torch.isfinite(full).all()
+    d = (mixed - full).abs()
+    small, huge = d[:B // 2].max().item(), d[B // 2:]
+    print(f"entity image rows x 1e-6 / 1e-30 / zero: mixed-f16 rows vs fp32 rows {small:.2e}; with rows x 1e6 / up to 3e37 among the "
+          f"candidates: finite, {(huge <= 1e-5).float().mean().item():.4f} of the scores within 1e-5 (max {huge.max().item():.2e})")
+    assert small <= 1e-5 and (mixed[:B // 2, :-1].argmax(1) == full[:B // 2, :-1].argmax(1)).all()
+    assert (huge <= 1e-5).float().mean().item() >= 0.99

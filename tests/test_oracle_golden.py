@@ -169,3 +169,32 @@ def test_precision_by_contraction_emulation():
     # the same single pass on fp16's 11-bit operands (rows scaled by a power of two into range: `bf16x3_if16`): an eighth of the
     # bf16 pass's error - the level of the split product itself; a D x D contraction would still cost a third of the bar
     assert err["image:one_f16"]["max"] <= 4e-6 and err["text:one_f16"]["max"] >= 2e-5
+
+
+def test_precision_by_storage_emulation_of_the_mixed_cache_rows():
+    """The evidence `DRIN_CACHE_MIXED_F16` (`EntityTable.enable_cache(format="mixed_f16")`) is built on: the oracle in fp64 with
+    single fields of the per-entity cache row stored as fp16 under a power-of-two row scale.  The three fields that are operands
+    of per-pair SCALARS (`fv_t`, `fv_i`: mean over D inside the edge sigmoid, `model.py:148-153`; the object row: the
+    image-image edge, `:84-92`) cost ~2e-7 together at N = 101 and ~6e-7 at N = 11 - below the split-bf16 contractions' own
+    1.3e-6.  `h_i` would cost 2.3e-6 on a homogeneous table (and far more when one entity's row dwarfs the others': the cached
+    path sums e h_i over the candidates for the mention vertices); `h_t` and the normalised CLS row enter the score directly
+    and cost 1-2e-5 each: the format keeps all three fp32."""
+    import torch
+    from drin_amd import synth
+    from drin_amd.config import wikidiverse_config, wikimel_config
+    from oracle.precision_emulation import MIXED_F16_FIELDS, cache_field_errors, scores_with_rounded_cache_fields
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    batch = synth.make_device_batch(cfg, 12, 5, "cpu")
+    assert (scores_with_rounded_cache_fields(sd, batch) - O.forward(sd, batch[:14], dtype=torch.float64)).abs().max().item() <= 1e-12
+    err = cache_field_errors(sd, batch, cases=(("h_i",), ("fv_t",), ("fv_i",), ("ohat",), MIXED_F16_FIELDS, ("chat",), ("h_t",)))
+    print(err)
+    mixed = err["+".join(MIXED_F16_FIELDS)]
+    assert mixed["max"] <= 5e-7 and mixed["top1_flips"] == 0
+    assert err["fv_t"]["max"] <= 5e-7 and err["fv_i"]["max"] <= 5e-8 and err["ohat"]["max"] <= 5e-7
+    assert err["h_i"]["max"] > 4 * mixed["max"] and err["chat"]["max"] >= 5e-6 and err["h_t"]["max"] >= 1e-5
+    cfg = wikidiverse_config()
+    sd = synth.make_state_dict(cfg, 7)
+    err = cache_field_errors(sd, synth.make_device_batch(cfg, 64, 5, "cpu"), cases=(MIXED_F16_FIELDS,))
+    print(err)
+    assert err["+".join(MIXED_F16_FIELDS)]["max"] <= 2e-6

@@ -1,0 +1,135 @@
+"""-m gpu: seeded differential sweep.  The hand-picked cases of the other files pin the reference's goldens and the timed
+instantiations; this one draws CONFIGURATIONS at random (fixed seeds: the same 48 cases every run) over everything
+`common/args.py:24-36,57,72,83-101` lets a caller change - dataset layout, candidate / object / token counts down to 1,
+layer count, static / dynamic and scalar / vector edges, the edge switch, activations by name - and batch shapes (B = 1,
+spans of one token, token counts at the Python-slice corners of `ghmfc.py:245-249`), and checks every path the product
+offers for that configuration against the CPU oracle on the same inputs: inference (the folded path where it applies, else
+layer by layer), the training-mode forward, the table form and the per-entity cache in both row formats, and the parameter
+gradients of the triplet loss against autograd through the oracle, including WHICH gradients are None."""
+import numpy as np
+import pytest
+import torch
+
+from drin_amd import synth
+from drin_amd.config import DrinConfig
+from drin_amd.metrics import TripletLoss
+from drin_amd.model import EntityTable, IndexedBatch, Model
+from oracle import drin_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CASES = 48
+
+
+def _draw(i: int):
+    g = np.random.Generator(np.random.Philox(key=[2026, i]))
+    pick = lambda xs: xs[int(g.integers(0, len(xs)))]   # noqa: E731
+    wikimel = bool(g.integers(0, 2))
+    D = pick([64, 64, 96, 128])
+    vector = g.random() < 0.2
+    if vector and D % 8:
+        D = 64
+    kw = dict(
+        dataset_name="wikimel" if wikimel else "wikidiverse",
+        num_candidates_data=int(pick([0, 1, 2, 5, 10, 15, 16, 17, 33, 47])),
+        bert_embed_dim=D, gcn_embed_dim=D, resnet_embed_dim=pick([64, 128, 192]),
+        resnet_num_region=int(pick([1, 3, 7])), max_mention_sentence_len=int(pick([6, 9, 24])),
+        max_entity_attr_token_len=int(pick([1, 2, 3, 5, 9])),
+        object_topk_mention=int(pick([1, 2, 3, 4])), object_topk_entity=int(pick([1, 1, 2, 3])),
+        num_gcn_layers=int(pick([1, 2, 2, 2, 3])),
+        gcn_edge_type=pick(["dynamic", "dynamic", "static"]),
+        gcn_edge_feature="vector" if vector else "scaler",
+        gcn_edge_enabled=tuple(float(x) for x in (g.random(4) < 0.8)),
+        gcn_vertex_activation=pick(["gelu", "gelu", "gelu", "relu", "tanh", "silu", "sigmoid"]),
+        gcn_edge_activation=pick(["sigmoid", "sigmoid", "sigmoid", "tanh", "relu", "gelu", "silu"]),
+    )
+    cfg = DrinConfig(**kw)
+    cfg.validate()
+    B = int(pick([1, 2, 3, 5, 8]))
+    precision = pick(["f32", "bf16x3_all"])
+    return cfg, B, precision, int(g.integers(0, 1 << 30))
+
+
+def _oracle_kwargs(cfg):
+    return O.config_kwargs(cfg)
+
+
+@pytest.mark.parametrize("i", range(CASES))
+def test_random_configuration_every_path_against_the_oracle(i):
+    cfg, B, precision, seed = _draw(i)
+    sd = synth.make_state_dict(cfg, 3 + i)
+    T = cfg.max_entity_attr_token_len
+    batch = synth.make_batch(cfg, B, seed % 100000, min_span=1, max_span=3, min_tokens=min(3, T))
+    if cfg.token_level_entities and T >= 3:
+        # Python-slice corners of the token mean: an entity with every token (ntok = T) and one with exactly one kept token
+        batch[8][0, 0, :] = 1
+        batch[8][-1, -1, :] = 0
+        batch[8][-1, -1, :3] = 1
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.forward(ref_p, batch[:14], **_oracle_kwargs(cfg))
+    tol = 2e-5 if precision == "bf16x3_all" else 1e-5
+    finite = torch.isfinite(ref)
+    model = Model(cfg, precision=precision).to(DEV)
+    model.load_state_dict(sd)
+    dbatch = [t.to(DEV) for t in batch]
+
+    def check(got, what):
+        got = got.detach().cpu()
+        assert got.shape == ref.shape, what
+        assert torch.equal(torch.isnan(got), torch.isnan(ref.detach())), f"case {i} {what}: NaN pattern differs ({cfg})"
+        err = (got - ref.detach())[finite].abs().max().item() if finite.any() else 0.0
+        assert err <= tol, f"case {i} {what}: {err:.2e} > {tol} ({cfg}, B={B}, {precision})"
+        return err
+
+    model.eval()
+    with torch.no_grad():
+        e_inf = check(model(dbatch[:14]), "inference")
+    model.train()
+    out = model(dbatch[:14])
+    e_trn = check(out, "training forward")
+    # gradients of the caller's loss (train.py:33-34, common/utils.py:26-43)
+    if finite.all():
+        if cfg.num_candidates_data == 0:      # a lone answer slot: the triplet loss has no column left (utils.py:36-37); any functional does
+            w = torch.linspace(-1.0, 1.0, B)[:, None]
+            loss, ref_loss = (out * w.to(DEV)).sum(), (ref * w).sum()
+        else:
+            loss = TripletLoss(cfg.triplet_margin)(dbatch[14], out)
+            ref_loss = O.triplet_loss(batch[14], ref, cfg.triplet_margin)
+        loss.backward()
+        ref_g = torch.autograd.grad(ref_loss, list(ref_p.values()), allow_unused=True)
+        assert abs(loss.item() - ref_loss.item()) <= 2e-5
+        for (k, p), r in zip(model.named_parameters(), ref_g):
+            assert k in ref_p
+            got = p.grad
+            # a gradient the reference leaves None may come back None or exactly zero-free: the product mirrors None
+            assert (got is None) == (r is None), f"case {i}: grad of {k} is {'None' if got is None else 'set'}, reference {'None' if r is None else 'set'} ({cfg})"
+            if r is not None and r.norm().item() > 1e-10:
+                rel = (got.cpu() - r).norm().item() / r.norm().item()
+                assert rel <= (5e-4 if precision == "bf16x3_all" else 5e-5), f"case {i}: grad of {k} off by {rel:.2e} ({cfg}, B={B}, {precision})"
+    # table form + per-entity cache (inference; the library says so when a geometry has no table form)
+    model.eval()
+    e_tab = e_cache = None
+    if cfg.num_gcn_layers == 2 and cfg.gcn_edge_feature == "scaler" and cfg.num_candidates_data >= 1:
+        N, E = cfg.num_candidates_model, 23
+        tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, seed % 1000 + 7)
+        table = EntityTable(tab[7][0], tab[8][0] if cfg.token_level_entities else None, tab[9][0], tab[10][0], tab[11][0]).to(DEV)
+        cand = torch.randint(0, E, (B, N), generator=torch.Generator().manual_seed(i)).to(DEV)
+        ib = IndexedBatch(dbatch[:7], table, cand, dbatch[12], dbatch[13])
+        ref_t = O.forward(sd, [t.cpu() for t in ib.gathered()], **_oracle_kwargs(cfg))
+        fin_t = torch.isfinite(ref_t)
+        with torch.no_grad():
+            for fmt in (None, "f32", "mixed_f16"):
+                if fmt == "mixed_f16" and (cfg.gcn_embed_dim % 8 or cfg.resnet_embed_dim % 8):
+                    continue
+                table.enable_cache(fmt is not None, format=fmt or "f32")
+                got = model(ib).cpu()
+                assert torch.equal(torch.isnan(got), torch.isnan(ref_t)), f"case {i} table form ({fmt}): NaN pattern"
+                err = (got - ref_t)[fin_t].abs().max().item() if fin_t.any() else 0.0
+                # (mixed rows at D = 64: the fp16 operands' rounding is averaged over 64 columns only)
+                assert err <= (3e-5 if fmt == "mixed_f16" else tol), f"case {i} table form (cache {fmt}): {err:.2e} ({cfg}, B={B}, {precision})"
+                e_tab, e_cache = (err, e_cache) if fmt is None else (e_tab, err)
+        table.enable_cache(False)
+    print(f"case {i}: {cfg.dataset_name} N={cfg.num_candidates_model} D={cfg.gcn_embed_dim} R={cfg.resnet_embed_dim} L={cfg.num_gcn_layers} "
+          f"{cfg.gcn_edge_type}/{cfg.gcn_edge_feature} {cfg.gcn_vertex_activation}/{cfg.gcn_edge_activation} mask={cfg.gcn_edge_enabled} "
+          f"Km={cfg.object_topk_mention} Ke={cfg.object_topk_entity} T={T} B={B} {precision}: inference {e_inf:.1e} training {e_trn:.1e} "
+          f"table {e_tab} cache {e_cache}")

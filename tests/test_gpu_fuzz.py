@@ -19,6 +19,7 @@ from oracle import drin_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 CASES = 48
+FULL_WIDTH_CASES = 16     # the same draw at D = 768 / R = 2048: the exact-width instantiations of every row / stream / GEMM kernel
 
 
 def _draw(i: int):
@@ -29,10 +30,13 @@ def _draw(i: int):
     vector = g.random() < 0.2
     if vector and D % 8:
         D = 64
+    R = pick([64, 128, 192])
+    if i >= CASES:
+        D, R = 768, 2048
     kw = dict(
         dataset_name="wikimel" if wikimel else "wikidiverse",
         num_candidates_data=int(pick([0, 1, 2, 5, 10, 15, 16, 17, 33, 47])),
-        bert_embed_dim=D, gcn_embed_dim=D, resnet_embed_dim=pick([64, 128, 192]),
+        bert_embed_dim=D, gcn_embed_dim=D, resnet_embed_dim=R,
         resnet_num_region=int(pick([1, 3, 7])), max_mention_sentence_len=int(pick([6, 9, 24])),
         max_entity_attr_token_len=int(pick([1, 2, 3, 5, 9])),
         object_topk_mention=int(pick([1, 2, 3, 4])), object_topk_entity=int(pick([1, 1, 2, 3])),
@@ -54,7 +58,7 @@ def _oracle_kwargs(cfg):
     return O.config_kwargs(cfg)
 
 
-@pytest.mark.parametrize("i", range(CASES))
+@pytest.mark.parametrize("i", range(CASES + FULL_WIDTH_CASES))
 def test_random_configuration_every_path_against_the_oracle(i):
     cfg, B, precision, seed = _draw(i)
     sd = synth.make_state_dict(cfg, 3 + i)
@@ -97,15 +101,27 @@ def test_random_configuration_every_path_against_the_oracle(i):
             ref_loss = O.triplet_loss(batch[14], ref, cfg.triplet_margin)
         loss.backward()
         ref_g = torch.autograd.grad(ref_loss, list(ref_p.values()), allow_unused=True)
+        # the yardstick is the oracle in fp64; how far the fp32 ORACLE's own gradient is from it measures the conditioning of the
+        # case (a sigmoid vertex activation squeezes all scores into a 2e-4 band: the fp32 oracle is then 7e-4 from the fp64
+        # one - tools/probes/fuzz_grad_case.py, profiles/r4_fuzz_grad_cases.txt) and scales the bound; a relu vertex meets its
+        # kink: a split-bf16 product moves a pre-activation by 1e-6 and one element in ten thousand flips its derivative
+        p64 = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+        out64 = O.forward(p64, batch[:14], dtype=torch.float64, **_oracle_kwargs(cfg))
+        loss64 = ((out64 * w.double()).sum() if cfg.num_candidates_data == 0
+                  else O.triplet_loss(batch[14].double(), out64, cfg.triplet_margin))
+        g64 = torch.autograd.grad(loss64, list(p64.values()), allow_unused=True)
         assert abs(loss.item() - ref_loss.item()) <= 2e-5
-        for (k, p), r in zip(model.named_parameters(), ref_g):
+        base = 5e-4 if precision == "bf16x3_all" else 5e-5
+        if cfg.gcn_vertex_activation == "relu" and precision == "bf16x3_all":
+            base *= 4
+        for (k, p), r, r64 in zip(model.named_parameters(), ref_g, g64):
             assert k in ref_p
             got = p.grad
-            # a gradient the reference leaves None may come back None or exactly zero-free: the product mirrors None
             assert (got is None) == (r is None), f"case {i}: grad of {k} is {'None' if got is None else 'set'}, reference {'None' if r is None else 'set'} ({cfg})"
-            if r is not None and r.norm().item() > 1e-10:
-                rel = (got.cpu() - r).norm().item() / r.norm().item()
-                assert rel <= (5e-4 if precision == "bf16x3_all" else 5e-5), f"case {i}: grad of {k} off by {rel:.2e} ({cfg}, B={B}, {precision})"
+            if r is not None and r64.norm().item() > 1e-10:
+                cond = (r.double() - r64).norm().item() / r64.norm().item()          # the fp32 oracle's own distance
+                rel = (got.cpu().double() - r64).norm().item() / r64.norm().item()
+                assert rel <= max(base, 3 * cond), f"case {i}: grad of {k} off by {rel:.2e} (fp32 oracle itself: {cond:.2e}) ({cfg}, B={B}, {precision})"
     # table form + per-entity cache (inference; the library says so when a geometry has no table form)
     model.eval()
     e_tab = e_cache = None
@@ -126,7 +142,7 @@ def test_random_configuration_every_path_against_the_oracle(i):
                 assert torch.equal(torch.isnan(got), torch.isnan(ref_t)), f"case {i} table form ({fmt}): NaN pattern"
                 err = (got - ref_t)[fin_t].abs().max().item() if fin_t.any() else 0.0
                 # (mixed rows at D = 64: the fp16 operands' rounding is averaged over 64 columns only)
-                assert err <= (3e-5 if fmt == "mixed_f16" else tol), f"case {i} table form (cache {fmt}): {err:.2e} ({cfg}, B={B}, {precision})"
+                assert err <= ((3e-5 if cfg.gcn_embed_dim < 256 else tol) if fmt == "mixed_f16" else tol), f"case {i} table form (cache {fmt}): {err:.2e} ({cfg}, B={B}, {precision})"
                 e_tab, e_cache = (err, e_cache) if fmt is None else (e_tab, err)
         table.enable_cache(False)
     print(f"case {i}: {cfg.dataset_name} N={cfg.num_candidates_model} D={cfg.gcn_embed_dim} R={cfg.resnet_embed_dim} L={cfg.num_gcn_layers} "

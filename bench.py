@@ -1193,6 +1193,23 @@ def main(argv=None):
         extra["train_step"] = leg_guard("train_step", lambda: bench_train(ctx, cfg, sd, 64, 20, 30))
         if world == 1 and rank == 0 and not args.no_cpu_baseline and "error" not in extra["train_step"]:
             extra["train_step"]["train_parity"] = leg_guard("train_parity", lambda: train_parity(dev))
+
+            def dw_leg():
+                # EXPERIMENT, reported, not adopted: the pair-sized weight-gradient products in ONE bf16 pass
+                # (drin_set_weight_gradient_passes(1)) - the same step timed, the same 10-step trajectory against the oracle's loop
+                from drin_amd import _lib
+                lib = _lib.load()
+                _lib.check(lib.drin_set_weight_gradient_passes(1))
+                try:
+                    r = bench_train(ctx, cfg, sd, 64, 20, 30)
+                    out = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps") if k in r}
+                    out["train_parity"] = train_parity(dev)
+                finally:
+                    lib.drin_set_weight_gradient_passes(-1)
+                out["note"] = ("weight gradients 2.5e-3 from the fp64 oracle's instead of 1.2e-5; 60 / 200-step trajectories: "
+                               "profiles/r4_dw_one_pass.txt - off by default")
+                return out
+            extra["train_step"]["experiment_weight_gradients_one_pass"] = leg_guard("dw_one_pass", dw_leg)
         if world == 1:
             def rccl_leg():
                 # BASELINE config 4's collective code path as far as ONE GPU can run it: an RCCL process group of one rank, the

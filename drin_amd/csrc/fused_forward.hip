@@ -738,6 +738,15 @@ int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs) {
   return DRIN_OK;
 }
 
+int drin_set_weight_gradient_passes(int32_t passes) {
+  if (passes != 1 && passes != 3 && passes >= 0) {
+    set_error("drin_set_weight_gradient_passes: %d (1 = one bf16 pass, 3 = the split product, -1 = default)", passes);
+    return DRIN_E_SHAPE;
+  }
+  set_weight_gradient_passes(passes < 0 ? -1 : passes);
+  return DRIN_OK;
+}
+
 int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached) {
   if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
   if (cached) return cached_chunks_per_mention(*cfg);

@@ -19,6 +19,10 @@
 // y in order: reproducible bit for bit.  (An atomic epilogue was the first version: 65 536 fp32 atomics per workgroup
 // cost ~50 us whatever the slice length - MI355X_MICROARCH.md: one 256-byte atomic wave-instruction per ~50 ns per
 // CU - more than the MFMA work at M ~ 10^4, and left the last bits of dW run-order dependent.  It is gone.)
+#include <stdlib.h>
+
+#include <atomic>
+
 #include "device_utils.h"
 #include "internal.h"
 
@@ -93,6 +97,7 @@ struct TransposeStager {
   }
   // the sum over m of this thread's four columns, of everything staged so far (rows past m_end were loaded as zeros)
   __device__ __forceinline__ void add_to(float4& s) const { s = s + ((v[0] + v[1]) + (v[2] + v[3])); }
+  template <bool WITH_LO = true>
   __device__ __forceinline__ void store(char* __restrict__ hi_plane, char* __restrict__ lo_plane) const {
     const float col[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x},
                              {v[0].y, v[1].y, v[2].y, v[3].y},
@@ -104,11 +109,11 @@ struct TransposeStager {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         hi[i] = (__bf16)col[j][i];
-        lo[i] = (__bf16)(col[j][i] - (float)hi[i]);
+        if (WITH_LO) lo[i] = (__bf16)(col[j][i] - (float)hi[i]);
       }
       const int off = lds_off(4 * cg + j, mg >> 1) + ((mg & 1) << 3);
       *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
-      *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+      if (WITH_LO) *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
     }
   }
 };
@@ -131,6 +136,10 @@ struct GroupArgs {
   int n;
 };
 
+// ONE_PASS (drin_set_weight_gradient_passes(1), an EXPERIMENT - off by default): both operands rounded to bf16, one MFMA pass,
+// no lo planes.  A weight gradient is a sum over >= 6 464 pair rows, which averages the rounding of its terms; what that does
+// to a training trajectory is measured, not assumed: profiles/r4_dw_one_pass.txt.
+template <bool ONE_PASS>
 __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  All
@@ -177,8 +186,8 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
   const bool sums = P.colsum_partial != nullptr && k0 == 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (sums) sa.add_to(csum);
-  sa.store(smem, smem + PLANE);
-  sb.store(smem + 2 * PLANE, smem + 3 * PLANE);
+  sa.template store<!ONE_PASS>(smem, smem + PLANE);
+  sb.template store<!ONE_PASS>(smem + 2 * PLANE, smem + 3 * PLANE);
   if (nkb > 1) {
     sa.load(m_begin + BK, m_end);
     sb.load(m_begin + BK, m_end);
@@ -191,7 +200,7 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
     for (int j = 0; j < NI; ++j) {
       const int off = lds_off(wn * 64 + j * 16 + r, c);
       bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * PLANE + off);
-      bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE + off);
+      if (!ONE_PASS) bl[j] = *reinterpret_cast<const bf16x8*>(buf + 3 * PLANE + off);
     }
   };
   auto row_tiles = [&](const char* buf, int i0, int i1) {
@@ -200,12 +209,15 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
       if (i < i0 || i >= i1) continue;
       const int off = lds_off(wm * 128 + i * 16 + r, c);
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + PLANE + off);
+      bf16x8 al;
+      if (!ONE_PASS) al = *reinterpret_cast<const bf16x8*>(buf + PLANE + off);
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         // the k-side fragment is the FIRST operand: a lane then holds four consecutive k of one n - one 16-byte store
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+        if (!ONE_PASS) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
       }
     }
@@ -223,8 +235,8 @@ __global__ void __launch_bounds__(THREADS, 1) k_gemm_tn_bf16x3(const GroupArgs g
     row_tiles(buf, 0, MI / 2);
     if (more) {
       if (sums) sa.add_to(csum);
-      sa.store(nb, nb + PLANE);
-      sb.store(nb + 2 * PLANE, nb + 3 * PLANE);
+      sa.template store<!ONE_PASS>(nb, nb + PLANE);
+      sb.template store<!ONE_PASS>(nb + 2 * PLANE, nb + 3 * PLANE);
       if (kb + 2 < nkb) {
         sa.load(m_begin + (int64_t)(kb + 2) * BK, m_end);
         sb.load(m_begin + (int64_t)(kb + 2) * BK, m_end);
@@ -371,18 +383,38 @@ int launch_gemm_tn_group(const TnGroup& grp, hipStream_t st, float* scratch, siz
     set_error("gemm_tn_bf16x3: %lld work items exceed the grid limit", (long long)items);
     return DRIN_E_SHAPE;
   }
+  const bool one_pass = weight_gradient_passes() == 1;
   {
-    static DynLdsOptIn opt_in;
-    DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3), x3tn::LDS_BYTES,
-                                "hipFuncSetAttribute(gemm_tn_bf16x3)"));
+    static DynLdsOptIn opt_in3, opt_in1;
+    if (one_pass)
+      DRIN_TRY(ensure_dynamic_lds(opt_in1, reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<true>), x3tn::LDS_BYTES,
+                                  "hipFuncSetAttribute(gemm_tn_bf16x3)"));
+    else
+      DRIN_TRY(ensure_dynamic_lds(opt_in3, reinterpret_cast<const void*>(x3tn::k_gemm_tn_bf16x3<false>), x3tn::LDS_BYTES,
+                                  "hipFuncSetAttribute(gemm_tn_bf16x3)"));
   }
   {
     KernelTimer timer(DRIN_KC_GEMM_X3, st);
-    hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3, dim3((unsigned)items), dim3(x3tn::THREADS), x3tn::LDS_BYTES, st, ga);
+    if (one_pass)
+      hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3<true>, dim3((unsigned)items), dim3(x3tn::THREADS), x3tn::LDS_BYTES, st, ga);
+    else
+      hipLaunchKernelGGL(x3tn::k_gemm_tn_bf16x3<false>, dim3((unsigned)items), dim3(x3tn::THREADS), x3tn::LDS_BYTES, st, ga);
     DRIN_CHECK_LAUNCH("k_gemm_tn_bf16x3");
   }
   return defer != nullptr ? DRIN_OK : launch_slice_sum(local, st);
 }
+
+// 3 (default) or 1 bf16 MFMA passes for the pair-sized weight-gradient products: -1 = environment DRIN_DW_PASSES / default
+static std::atomic<int> g_dw_passes{-1};
+int weight_gradient_passes() {
+  int v = g_dw_passes.load(std::memory_order_relaxed);
+  if (v < 0) {
+    static const char* env = getenv("DRIN_DW_PASSES");
+    v = (env != nullptr && env[0] == '1') ? 1 : 3;
+  }
+  return v;
+}
+void set_weight_gradient_passes(int passes) { g_dw_passes.store(passes); }
 
 int launch_gemm_tn_bf16x3(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t M,
                           int N, int K, hipStream_t st, float* scratch, size_t scratch_floats, const int64_t* b_index) {

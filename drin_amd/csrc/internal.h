@@ -184,6 +184,9 @@ struct TnGroup {
 int launch_gemm_tn_group(const TnGroup& g, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer = nullptr,
                          int64_t target_rows = 0);
 int64_t tn_group_target(const TnGroup& g, size_t scratch_floats);
+// bf16 MFMA passes of those products: 3 (split-bf16, default) or 1 (drin_set_weight_gradient_passes: an experiment)
+int weight_gradient_passes();
+void set_weight_gradient_passes(int passes);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
 // (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,

@@ -337,6 +337,14 @@ DRIN_API int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cac
  * between calls, not between the size query and its call.  No reference counterpart (the reference runs one stream). */
 DRIN_API int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs);
 
+/* EXPERIMENT, off by default: matrix passes of the pair-sized weight-gradient products dW = dY^T X of drin_backward
+ * (`loss.backward()` of train.py:33-34 through model.py:164-209) in split-bf16 precision.  3 = the split product (hi hi + hi lo
+ * + lo hi: fp32-equivalent, the default); 1 = both operands rounded to bf16, one pass - a weight gradient is a sum over
+ * >= 6 464 pair rows, which averages the rounding of its terms (measured against the oracle's Adam loop:
+ * profiles/r4_dw_one_pass.txt); -1 = the default (also: environment DRIN_DW_PASSES=1).  Process-wide; change it between
+ * steps.  No reference counterpart. */
+DRIN_API int drin_set_weight_gradient_passes(int32_t passes);
+
 /* ---- per-entity precompute cache for table-form inference ---------------------- *
  * With frozen weights, what the first GCN layer takes from an entity (its rows of the entity_* tables,
  * `drin/data.py:87-93`) does not depend on the mention: `W_h1 W_et x_t`, `W_h1 W_ei x_i`, `W_v1(et0)`,

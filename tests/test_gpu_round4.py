@@ -450,3 +450,34 @@ def test_mixed_f16_cache_rows_hold_rows_of_any_magnitude():
           f"candidates: finite, {(huge <= 1e-5).float().mean().item():.4f} of the scores within 1e-5 (max {huge.max().item():.2e})")
     assert small <= 1e-5 and (mixed[:B // 2, :-1].argmax(1) == full[:B // 2, :-1].argmax(1)).all()
     assert (huge <= 1e-5).float().mean().item() >= 0.99
+
+
+def test_weight_gradient_one_pass_experiment_is_off_by_default_and_within_its_stated_error():
+    """`drin_set_weight_gradient_passes(1)` (measured, not adopted - profiles/r4_dw_one_pass.txt): the switch
+    changes the pair-sized weight gradients by ~2.5e-3 relative and nothing else (biases, LayerNorm and the mention-sized
+    products keep their bits); setting it back restores the default's bits."""
+    cfg = wikimel_config(max_entity_attr_token_len=4, batch_size=64)
+    sd = synth.make_state_dict(cfg, 7)
+    batch = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 64, 50, "cpu"), 0.15)]
+    lib = _lib.load()
+
+    def grads():
+        m = Model(cfg).to(DEV)
+        m.load_state_dict(sd)
+        TripletLoss(cfg.triplet_margin)(batch[14], m(batch[:14])).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    base = grads()
+    assert lib.drin_set_weight_gradient_passes(2) == _lib.E_SHAPE
+    try:
+        _lib.check(lib.drin_set_weight_gradient_passes(1))
+        one = grads()
+    finally:
+        _lib.check(lib.drin_set_weight_gradient_passes(-1))
+    again = grads()
+    assert all(torch.equal(base[k], again[k]) for k in base)
+    moved = {k: ((one[k] - base[k]).norm() / base[k].norm()).item() for k in base}
+    pair_sized = [k for k in base if k.endswith("weight") and "layer_norm" not in k and "mention" not in k]
+    print({k: f"{v:.1e}" for k, v in moved.items()})
+    assert max(moved[k] for k in pair_sized) <= 6e-3 and max(moved[k] for k in pair_sized) >= 1e-4
+    assert all(v <= 6e-3 for v in moved.values())

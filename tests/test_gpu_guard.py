@@ -1,0 +1,168 @@
+"""-m gpu: no kernel writes outside the buffers it was given.  There is no GPU AddressSanitizer on this pool, and an
+out-of-bounds store of a hand-written kernel usually lands in somebody else's live tensor without faulting - so every device
+buffer the host side allocates while a path runs (workspaces sized by the library's own `*_bytes` queries, folded weights,
+per-entity caches, score and gradient tensors) gets a poisoned guard band in FRONT of and BEHIND it, and the bands are checked
+after the call.  Paths: folded inference at the headline's own width (whole-mention and 16-candidate workgroups) and at the
+tiny widths, WikiDiverse layout, bf16-stored features, the fp16 image contraction, table form, the per-entity cache in both row
+formats (build + scoring), training forward + backward + library Adam + the loss / metric kernels, vector edges."""
+import math
+
+import pytest
+import torch
+
+from drin_amd import synth
+from drin_amd.config import DrinConfig, wikimel_config
+from drin_amd.metrics import DeviceLossMetric, TripletLoss
+from drin_amd.model import EntityTable, IndexedBatch, Model
+from drin_amd.train import make_adam
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GUARD = 8192                       # bytes on each side (a multiple of every alignment the library asks for)
+TINY = dict(bert_embed_dim=64, gcn_embed_dim=64, resnet_embed_dim=128, max_mention_sentence_len=12, resnet_num_region=5)
+
+
+class Guarded:
+    """Replaces torch.empty / torch.zeros / torch.empty_like for CUDA tensors: the tensor handed out is the middle of a larger
+    byte buffer whose first and last GUARD bytes hold a pattern.  (Anything with arguments beyond size / dtype / device /
+    requires_grad, and every CPU allocation, goes to the real function.)"""
+
+    def __init__(self, monkeypatch):
+        self.bufs = []
+        self._orig = {name: getattr(torch, name) for name in ("empty", "zeros", "empty_like")}
+        for name in ("empty", "zeros"):
+            monkeypatch.setattr(torch, name, self._wrap(name))
+        monkeypatch.setattr(torch, "empty_like", self._empty_like)
+
+    def _guarded(self, shape, dtype, dev, zero):
+        item = self._orig["empty"]((), dtype=dtype).element_size()
+        nbytes = math.prod(shape) * item
+        raw = self._orig["empty"](GUARD + nbytes + GUARD, dtype=torch.uint8, device=dev)
+        raw[:GUARD] = 0xA5
+        raw[GUARD + nbytes:] = 0x5A
+        self.bufs.append((raw, nbytes, shape, str(dtype)))
+        t = raw[GUARD:GUARD + nbytes].view(dtype).view(shape)
+        return t.zero_() if zero else t
+
+    def _wrap(self, name):
+        orig = self._orig[name]
+
+        def alloc(*size, **kw):
+            dev = kw.get("device")
+            if dev is None or torch.device(dev).type != "cuda" or set(kw) - {"dtype", "device", "requires_grad"}:
+                return orig(*size, **kw)
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(int(x) for x in size)
+            t = self._guarded(shape, kw.get("dtype") or torch.get_default_dtype(), torch.device(dev), name == "zeros")
+            return t.requires_grad_(True) if kw.get("requires_grad") else t
+        return alloc
+
+    def _empty_like(self, t, **kw):
+        dev = torch.device(kw.get("device", t.device))
+        if dev.type != "cuda" or set(kw) - {"dtype", "device"} or not t.is_contiguous():
+            return self._orig["empty_like"](t, **kw)
+        return self._guarded(tuple(t.shape), kw.get("dtype", t.dtype), dev, False)
+
+    def check(self, what):
+        torch.cuda.synchronize()
+        bufs, self.bufs = self.bufs, []
+        for raw, nbytes, shape, dtype in bufs:
+            assert bool((raw[:GUARD] == 0xA5).all()), f"{what}: a kernel wrote in FRONT of a {dtype}{list(shape)} buffer ({nbytes} bytes)"
+            assert bool((raw[GUARD + nbytes:] == 0x5A).all()), f"{what}: a kernel wrote BEHIND a {dtype}{list(shape)} buffer ({nbytes} bytes)"
+        return len(bufs)
+
+
+@pytest.fixture
+def guarded(monkeypatch):
+    return Guarded(monkeypatch)
+
+
+def _dev_batch(cfg, B, seed, dtype=torch.float32):
+    return synth.make_device_batch(cfg, B, seed, DEV, dtype=dtype)
+
+
+@pytest.mark.parametrize("name,cfg,B,precision,features", [
+    ("headline_whole_mention", wikimel_config(max_entity_attr_token_len=4), 2048, "bf16x3", "f32"),
+    ("headline_48_candidates", wikimel_config(max_entity_attr_token_len=4), 1024, "bf16x3", "f32"),
+    ("headline_small_call", wikimel_config(max_entity_attr_token_len=7), 5, "bf16x3", "f32"),
+    ("ragged_last_tile", wikimel_config(max_entity_attr_token_len=3, num_candidates_data=36), 77, "bf16x3", "f32"),
+    ("f16_image_contraction", wikimel_config(max_entity_attr_token_len=4), 2048, "bf16x3_if16", "f32"),
+    ("one_pass_image_contraction", wikimel_config(max_entity_attr_token_len=4), 2048, "bf16x3_i1", "f32"),
+    ("bf16_features", wikimel_config(max_entity_attr_token_len=5), 600, "bf16x3", "bf16"),
+    ("exact_f32", wikimel_config(max_entity_attr_token_len=4), 130, "f32", "f32"),
+    ("wikidiverse", DrinConfig(), 3000, "bf16x3", "f32"),
+    ("wikidiverse_b1", DrinConfig(), 1, "bf16x3", "f32"),
+    ("tiny_tokens", DrinConfig(dataset_name="wikimel", num_candidates_data=20, max_entity_attr_token_len=10, **TINY), 9, "bf16x3_all", "f32"),
+    ("tiny_static", DrinConfig(num_candidates_data=17, gcn_edge_type="static", **TINY), 33, "f32", "f32"),
+])
+def test_inference_paths_stay_inside_their_buffers(guarded, name, cfg, B, precision, features):
+    batch = _dev_batch(cfg, B, 5, torch.bfloat16 if features == "bf16" else torch.float32)[:14]
+    guarded.check("batch generation")
+    model = Model(cfg, precision=precision).to(DEV).eval()
+    with torch.no_grad():
+        out = model(batch)
+        n = guarded.check(f"{name}: first call (weight folds + forward)")
+        assert n >= 2 and out.shape == (B, cfg.num_candidates_model)
+        again = model(batch)
+        guarded.check(f"{name}: second call")
+    assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(again))
+
+
+@pytest.mark.parametrize("name,cfg,E,B", [
+    ("full_width", DrinConfig(num_candidates_data=100), 3001, 130),
+    ("full_width_tokens", wikimel_config(max_entity_attr_token_len=5), 777, 40),
+    ("tiny", DrinConfig(num_candidates_data=20, **TINY), 83, 5),
+    ("tiny_tokens_gelu_edges", DrinConfig(dataset_name="wikimel", num_candidates_data=33, max_entity_attr_token_len=6, gcn_edge_activation="gelu", **TINY), 50, 7),
+])
+def test_table_form_and_both_cache_formats_stay_inside_their_buffers(guarded, name, cfg, E, B):
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, 71)
+    table = EntityTable(tab[7][0], tab[8][0] if cfg.token_level_entities else None, tab[9][0], tab[10][0], tab[11][0]).to(DEV)
+    men = [t.to(DEV) for t in synth.make_batch(cfg, B, 72)]
+    cand = torch.randint(0, E, (B, cfg.num_candidates_model), generator=torch.Generator().manual_seed(3)).to(DEV)
+    cand[0, 0], cand[-1, -1] = 0, E - 1
+    ib = IndexedBatch(men[:7], table, cand, men[12], men[13])
+    model = Model(cfg).to(DEV).eval()
+    with torch.no_grad():
+        for fmt in (None, "f32", "mixed_f16"):
+            table.enable_cache(fmt is not None, format=fmt or "f32")
+            out = model(ib)
+            n = guarded.check(f"{name}: table form, cache {fmt}")
+            assert n >= 2 and torch.isfinite(out).all()
+    table.enable_cache(False)
+
+
+@pytest.mark.parametrize("name,cfg,B,precision", [
+    ("reference_batch", wikimel_config(max_entity_attr_token_len=6), 64, "bf16x3"),
+    ("odd_batch_f32", wikimel_config(max_entity_attr_token_len=3, num_candidates_data=36), 19, "f32"),
+    ("wikidiverse", DrinConfig(), 70, "bf16x3"),
+    ("three_layers_vector_edges", DrinConfig(num_candidates_data=12, num_gcn_layers=3, gcn_edge_feature="vector", **TINY), 6, "bf16x3_all"),
+    ("tiny_static_one_layer", DrinConfig(num_candidates_data=9, num_gcn_layers=1, gcn_edge_type="static", **TINY), 4, "f32"),
+])
+def test_training_step_stays_inside_its_buffers(guarded, name, cfg, B, precision):
+    batch = _dev_batch(cfg, B, 9)
+    guarded.check("batch generation")
+    model = Model(cfg, precision=precision).to(DEV)
+    opt = make_adam(model, cfg.learning_rate)
+    metric = DeviceLossMetric(cfg.triplet_margin, cfg.metrics_topk[:2], DEV)
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        scores = model(batch[:14])
+        loss = metric(batch[14], scores) if step else TripletLoss(cfg.triplet_margin)(batch[14], scores)
+        loss.backward()
+        opt.step()
+        n = guarded.check(f"{name}: training step {step} (forward, loss, backward, Adam)")
+        assert n >= 3 and math.isfinite(float(loss.detach()))
+
+
+def test_the_guard_bands_do_catch_a_stray_store(guarded):
+    """The harness itself: one float stored one element past the end (and one before the start) of a guarded tensor is reported."""
+    t = torch.empty(100, dtype=torch.float32, device=DEV)
+    torch.as_strided(t, (101,), (1,))[100] = 1.0
+    with pytest.raises(AssertionError, match="BEHIND"):
+        guarded.check("stray store behind")
+    t = torch.zeros((4, 8), dtype=torch.float32, device=DEV)
+    raw = guarded.bufs[-1][0]
+    raw[GUARD - 4:GUARD].view(torch.float32)[0] = 2.0
+    with pytest.raises(AssertionError, match="FRONT"):
+        guarded.check("stray store in front")
+    ws = torch.empty(64, dtype=torch.uint8, device=DEV)
+    assert guarded.check("clean") == 1 and ws.numel() == 64

@@ -20,9 +20,19 @@ namespace drin {
 // the bytes of this HBM-bound pass; all arithmetic stays fp32)
 // XSCALE: also hand over a power-of-two scale per image row (DRIN_PREC_BF16X3_IF16) - a separate instantiation, so that the
 // code (and the register allocation: 230 VGPRs) of every other call is what it was
+#ifdef DRIN_STREAM_STAMPS   // probe build (tools/stream_stamps_probe.py): cycle stamps of 64 workgroups, wave 0
+__device__ unsigned long long g_stream_stamps[64 * 8];
+#define STREAM_STAMP(i)                                                                                        \
+  if (threadIdx.x == 0 && blockIdx.x == 0 && (blockIdx.y % (gridDim.y / 64 ? gridDim.y / 64 : 1)) == 0 &&       \
+      blockIdx.y / (gridDim.y / 64 ? gridDim.y / 64 : 1) < 64)                                                   \
+  g_stream_stamps[(blockIdx.y / (gridDim.y / 64 ? gridDim.y / 64 : 1)) * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define STREAM_STAMP(i)
+#endif
 template <int DV, int RV, bool TOKENS, bool EXACT, typename FT, bool XSCALE = false>
 __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  STREAM_STAMP(0);
   const FT* const f_text = static_cast<const FT*>(a.entity_text);
   const FT* const f_image = static_cast<const FT*>(a.entity_image);
   const FT* const f_object = static_cast<const FT*>(a.entity_object);
@@ -61,7 +71,12 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       st4(l_mt + D + i * 4, ld4(a.q + ((int64_t)which * a.B + b) * a.ldq + c4 * 4));
     }
   }
+  // (Measured in round 4 and dropped - profiles/r4_stream_stamps.txt: these four load -> store loops as ONE index space with eight
+  //  16-byte loads per thread in flight before the first LDS store.  Cycle stamps of a WikiDiverse workgroup: this stage 16.5 k ->
+  //  22.7 k cycles of 82 k, the kernel 1.16 -> 1.23 ms.  The stage does not wait for dependent round trips: its loads queue behind
+  //  the ~100 KB the CU's other workgroup keeps in flight, and a burst of 2 048 of them queues longer.)
   __syncthreads();
+  STREAM_STAMP(1);
   for (int i = wave; i < a.Km; i += 4) {  // |mobj_i| (model.py:88: every pair re-normalises the same rows)
     float s = 0.f;
     for (int c4 = lane; c4 < R4; c4 += 64) {
@@ -86,7 +101,9 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     kap_it = wave_sum(dot_rows<DV>(fu_i, k_t));
     kap_ii = wave_sum(dot_rows<DV>(fu_i, k_i));
   }
+  STREAM_STAMP(2);
   __syncthreads();
+  STREAM_STAMP(3);
 
   Row<DV> S_tt = zero_row<DV>(), S_it = zero_row<DV>();
   Row<RV> S_ti = zero_row<RV>(), S_ii = zero_row<RV>();
@@ -283,6 +300,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     sg_ii += e_ii;
   }
 
+  STREAM_STAMP(4);
   // ---- fixed-order cross-wave reduction through LDS, then one partial per (mention, chunk) -----------
   for (int w = 0; w < 4; ++w) {
     __syncthreads();
@@ -317,6 +335,7 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     }
   }
   __syncthreads();
+  STREAM_STAMP(5);
   if (a.chunks == 1) {
     // short candidate lists (N <= 16, WikiDiverse): the workgroup holds the whole mention - write the layout
     // the mention-side GEMMs read and skip the partial buffer and its reduction pass
@@ -329,12 +348,21 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
       st4(a.s_img + ((int64_t)which * a.B + b) * R + c4 * 4, ld4(l_red + 2 * D + i * 4));
     }
     if (threadIdx.x < 4) a.sig[(int64_t)threadIdx.x * a.B + b] = l_small[a.Km + threadIdx.x];
+    STREAM_STAMP(6);
     return;
   }
   float* out = a.s_part + (b * a.chunks + blockIdx.x) * (int64_t)(2 * D + 2 * R + 4);
   for (int i = threadIdx.x; i < (2 * D + 2 * R) / 4; i += 256) st4(out + i * 4, ld4(l_red + i * 4));
   if (threadIdx.x < 4) out[2 * D + 2 * R + threadIdx.x] = l_small[a.Km + threadIdx.x];
 }
+
+#ifdef DRIN_STREAM_STAMPS
+}  // namespace drin
+extern "C" __attribute__((visibility("default"))) int drin_debug_stream_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(drin::g_stream_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+namespace drin {
+#endif
 
 size_t entity_stream_lds_bytes(const StreamArgs& a) {
   const size_t D = (size_t)a.D4 * 4, R = (size_t)a.R4 * 4;

@@ -528,8 +528,9 @@ class Model(nn.Module):
         pair-sized contractions of the fused inference path in ONE bf16 MFMA pass - score error ~6e-4, outside the
         1e-4 bar; training and every other path then run "bf16x3") or "bf16x3_i1" (precision by contraction: split-bf16 except
         the folded entity-image contraction, which runs one bf16 pass where the candidate list is long enough - N >= 64 - for
-        the mean over candidates behind it to average its rounding noise down: <= 2.5e-5 on the scores at N = 101, inside the
-        1e-4 bar; shorter lists and every other path run "bf16x3") or "bf16x3_if16" (the same one pass on the FP16 matrix
+        the mean over candidates behind it to average its rounding noise down: <= 2.5e-5 on the scores at N = 101 with freshly
+        initialised weights, but 1.6e-4 - outside the 1e-4 bar - once the weights are trained (DESIGN.md 4.3): a benchmark mode;
+        shorter lists and every other path run "bf16x3") or "bf16x3_if16" (the same one pass on the FP16 matrix
         instruction, every image row scaled by a power of two into fp16's range: <= 4e-6 on the scores at N = 101, <= 8e-6 at
         N = 11 - the level of "bf16x3" itself - for the per-pair fp32 image rows of large inference calls; else "bf16x3");
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;

@@ -57,8 +57,10 @@ typedef enum {
                               ONE bf16 MFMA pass (operands rounded, no lo planes).  Its result feeds only the layer-1
                               entity IMAGE vertex, which reaches the score through mean_n(ti' ei') in the layer-2
                               mention vertex alone (model.py:124-129,143-144; vertex graph :105): the rounding noise is
-                              averaged over the N candidates before it meets the score.  Measured at N = 101: max
-                              |score - fp32 reference| <= 2.5e-5 (bar 1e-4), top-1 unchanged; taken only for
+                              averaged over the N candidates before it meets the score.  Measured at N = 101 with
+                              freshly initialised weights: max |score - fp32 reference| <= 2.5e-5 (bar 1e-4), top-1
+                              unchanged - but 0.5-1.6e-4 once the weights are TRAINED (the vertex -> score map steepens;
+                              profiles/r4_precision_on_trained_weights.txt): a benchmark mode, not a serving one; taken only for
                               num_candidates >= 64 - shorter lists (N = 11: 5-10e-5, no margin) keep three passes and
                               equal BF16X3 bit for bit.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
   DRIN_PREC_BF16X3_IF16 = 5 /* drin_forward_prepared only: as BF16X3_I1, but the one pass of the entity-image contraction runs
@@ -66,7 +68,8 @@ typedef enum {
                               fp16's range is made a non-issue by scaling every image row by a power of two (its max |x|
                               into [0.5, 1): exact) before the conversion and the output row back afterwards; the folded
                               weight is converted once by drin_prepare.  Measured: <= 4e-6 on the scores at N = 101 and <= 8e-6
-                              at N = 11 - the level of BF16X3 itself - so there is no candidate-count gate.  Taken for the
+                              at N = 11 with freshly initialised weights, <= 2e-5 with trained ones (BF16X3 itself: 2e-6 /
+                              6e-6) - inside the bar either way - so there is no candidate-count gate.  Taken for the
                               per-pair fp32 image rows of large calls (the benchmark's form); bf16-stored features, the table
                               form and small calls run BF16X3.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
 } drin_precision;

@@ -481,3 +481,55 @@ def test_weight_gradient_one_pass_experiment_is_off_by_default_and_within_its_st
     print({k: f"{v:.1e}" for k, v in moved.items()})
     assert max(moved[k] for k in pair_sized) <= 6e-3 and max(moved[k] for k in pair_sized) >= 1e-4
     assert all(v <= 6e-3 for v in moved.values())
+
+
+def test_precision_modes_on_trained_weights():
+    """Every other precision test scores with freshly initialised weights.  Here the weights are TRAINED first - 40 Adam steps of
+    the reference's loop (`train.py:30-56`) on the learnable synthetic stream at the reference's width and batch (D = 768, R = 2048,
+    N = 101, B = 64), loss 0.25 -> ~0.03 - and 512 held-out mentions (a call large enough for the one-pass image contraction to
+    run) are scored in the exact-fp32 arithmetic, the default split-bf16 one and both precision-by-contraction modes with the same
+    weights.  Training steepens the map from the vertices to the score (top-minus-median score 0.06 -> 0.7) and every mode's
+    absolute error grows with it (`profiles/r4_precision_on_trained_weights.txt`, 0 .. 400 steps): the default stays under the
+    1e-5 guard (4e-6), the fp16 pass inside the 1e-4 bar with a margin of five (2e-5), and the bf16 pass `bf16x3_i1` - 2e-5 at
+    initialisation - LEAVES the bar (1.6e-4): that mode is inside the bar near initialisation only, and this test pins the fact.
+    Rankings do not move: the same top-1 / top-5 counts and arg-max as the exact path for every mode."""
+    from drin_amd.train import make_adam
+    cfg = wikimel_config(max_entity_attr_token_len=8, batch_size=64)
+    torch.manual_seed(0)
+    model = Model(cfg).to(DEV)
+    opt = make_adam(model, cfg.learning_rate)
+    loss_fn = TripletLoss(cfg.triplet_margin)
+    first = last = None
+    for i in range(40):
+        b = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 64, 50 + i, "cpu"), 0.15)]
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(b[14], model(b[:14]))
+        loss.backward()
+        opt.step()
+        first, last = (float(loss.detach()) if first is None else first), float(loss.detach())
+    assert last < 0.35 * first, (first, last)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    held = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 512, 999, "cpu"), 0.15)]
+    y = held[14].cpu()
+    scores = {}
+    for prec in ("f32", "bf16x3", "bf16x3_if16", "bf16x3_i1"):
+        m = Model(cfg, precision=prec).to(DEV).eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            _lib.profile_begin()
+            scores[prec] = m(held[:14]).cpu()
+            prof = _lib.profile_end()
+        if prec in ("bf16x3_if16", "bf16x3_i1"):
+            assert prof["gemm_x3"][1] >= 1                       # (the one-pass product is of this class; 512 x 101 pairs fill the grid)
+    ref = scores["f32"]
+    counts = {p: {k: O.topk_counts(s, y, k)[0] for k in (1, 5)} for p, s in scores.items()}
+    errs = {p: (s - ref).abs().max().item() for p, s in scores.items()}
+    agree = {p: (scores[p][:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean().item() for p in scores}
+    print(f"trained weights (loss {first:.3f} -> {last:.3f}); 512 held-out mentions: max |score - exact fp32| {errs}; top-k {counts}; top-1 agreement {agree}")
+    assert counts["f32"][1] >= 150                                # of 512: learnt
+    assert errs["bf16x3"] <= 1e-5, errs                           # the default: under the suite's guard on trained weights too
+    assert errs["bf16x3_if16"] <= 5e-5, errs                      # the fp16 pass: inside the bar (measured 2.0e-5)
+    assert 5e-5 <= errs["bf16x3_i1"] <= 5e-4, errs                # the bf16 pass: measured 1.6e-4 - outside the 1e-4 bar (documented)
+    for p in ("bf16x3", "bf16x3_if16", "bf16x3_i1"):
+        assert all(abs(counts[p][k] - counts["f32"][k]) <= 1 for k in (1, 5)), (p, counts)
+        assert agree[p] >= 0.996, (p, agree)

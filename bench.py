@@ -1128,7 +1128,10 @@ def main(argv=None):
             ln["parity"] = parity_of_timed_batch(cfg, sd, batch, o, n_slices=8, width=8)
             ln["parity"]["max_abs_diff_vs_headline_scores_all"] = float((o - out).abs().max())
             ln["parity"]["top1_agreement_vs_headline_all_mentions"] = float((o[:, :-1].argmax(1) == out[:, :-1].argmax(1)).float().mean())
-            return compact(ln)
+            res = compact(ln)
+            res["note"] = ("parity above is at the benchmark's random-init weights; with TRAINED weights this mode reaches 0.5-1.6e-4 against the "
+                           "exact-fp32 path - outside the 1e-4 bar (profiles/r4_precision_on_trained_weights.txt): a benchmark mode")
+            return res
         extra["wikimel_mixed_bf16"] = leg_guard("wikimel_mixed_bf16", mixed_leg)
     if "wikimel_mixed_f16" in legs and world == 1:
         def f16_leg():
@@ -1141,7 +1144,10 @@ def main(argv=None):
             ln["parity"] = parity_of_timed_batch(cfg, sd, batch, o, n_slices=8, width=8)
             ln["parity"]["max_abs_diff_vs_headline_scores_all"] = float((o - out).abs().max())
             ln["parity"]["top1_agreement_vs_headline_all_mentions"] = float((o[:, :-1].argmax(1) == out[:, :-1].argmax(1)).float().mean())
-            return compact(ln)
+            res = compact(ln)
+            res["note"] = ("parity above is at the benchmark's random-init weights; with TRAINED weights 0.6-2.0e-5 against the exact-fp32 path "
+                           "(split-bf16: 4-6e-6) - inside the 1e-4 bar (profiles/r4_precision_on_trained_weights.txt)")
+            return res
         extra["wikimel_mixed_f16"] = leg_guard("wikimel_mixed_f16", f16_leg)
     if "wikimel_bf16_features" in legs and world == 1:
         def bf16_leg():

@@ -1,0 +1,41 @@
+"""Do the arithmetic modes' errors depend on the DISTRIBUTION of the features?  The benchmark draws N(0, 1); real encoders do not:
+ResNet features are non-negative (post-ReLU average pool), BERT features carry a few dimensions of very large magnitude.  Same
+weights (seed-0 init), 512 WikiMEL-shaped mentions, every mode against the exact-fp32 path."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from drin_amd import synth
+from drin_amd.config import wikimel_config
+from drin_amd.model import Model
+DEV = "cuda"
+cfg = wikimel_config(max_entity_attr_token_len=8)
+sd = synth.make_state_dict(cfg, 7)
+base = synth.make_device_batch(cfg, 512, 5, DEV)[:14]
+g = torch.Generator(device=DEV).manual_seed(1)
+
+def variant(name):
+    b = [t.clone() for t in base]
+    if name in ("relu_images", "both"):
+        for i in (4, 5, 9, 10):                      # mention image / object, entity image / object: non-negative, mean ~0.8
+            b[i] = torch.relu(b[i]) * 2.0
+    if name in ("bert_outliers", "both"):
+        cols = torch.randperm(cfg.bert_embed_dim, generator=torch.Generator().manual_seed(2))[:4].to(DEV)
+        for i in (0, 7):                             # mention / entity text: four dimensions 20 x larger, with a common offset
+            b[i][..., cols] = b[i][..., cols] * 5.0 + 20.0
+    if name == "scaled_x30":
+        for i in (0, 4, 5, 7, 9, 10):
+            b[i] = b[i] * 30.0
+    return b
+
+for name in ("gaussian", "relu_images", "bert_outliers", "both", "scaled_x30"):
+    b = variant(name)
+    out = {}
+    for prec in ("f32", "bf16x3", "bf16x3_if16", "bf16x3_i1"):
+        m = Model(cfg, precision=prec).to(DEV).eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            out[prec] = m(b)
+    ref = out["f32"]
+    spread = float((ref[:, :-1].max(1).values - ref[:, :-1].median(1).values).mean())
+    print(f"{name:14s} scores in [{float(ref.min()):+.3f}, {float(ref.max()):+.3f}] top-minus-median {spread:.3f}: " +
+          "  ".join(f"{p} {float((out[p] - ref).abs().max()):.2e} (top-1 {float((out[p][:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean()):.4f})" for p in ("bf16x3", "bf16x3_if16", "bf16x3_i1")), flush=True)

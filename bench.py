@@ -1244,12 +1244,9 @@ def main(argv=None):
             e, pr, o, pf = run_score(ctx, m, b16, st, 3)
             l16 = score_line(ctx, wd, args, Bw, b16, e, pr, pf, st, 3, "bf16x3", "bf16", "wikidiverse", False, True)
             l16["parity"] = parity_of_timed_batch(wd, wsd, b16, o, n_slices=8, width=16, fp32_batch=b32)
-            # fp32 features with the image contraction in one FP16 pass (`bf16x3_if16`: no candidate-count gate - 8e-6 at N = 11)
-            mf = make_model(wd, wsd, dev, "bf16x3_if16")
-            e, pr, o, pf = run_score(ctx, mf, b32, st, 3)
-            lf = score_line(ctx, wd, args, Bw, b32, e, pr, pf, st, 3, "bf16x3_if16", "f32", "wikidiverse", False, True)
-            lf["parity"] = parity_of_timed_batch(wd, wsd, b32, o, n_slices=8, width=16)
-            return {"fp32_features": compact(l32), "bf16_features": compact(l16), "fp32_features_f16_image_contraction": compact(lf)}
+            # (the one-pass image contraction is gated on N >= 64: at N = 11 the fp16 pass measured 28.2-28.6 M pairs/s and 8e-6 at
+            #  initialisation, but 1.2e-4 on trained weights - profiles/r4_precision_on_trained_weights.txt - so this shape runs split-bf16)
+            return {"fp32_features": compact(l32), "bf16_features": compact(l16)}
         extra["wikidiverse"] = leg_guard("wikidiverse", wd_leg)
 
     if "table_cache" in legs and world == 1:

@@ -282,7 +282,11 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   const bool xi_planes = planes && (indexed || (xi_env != nullptr && xi_env[0] == '1' && cfg->feature_dtype == DRIN_FEAT_F32));
   // DRIN_PREC_BF16X3_IF16: x_i C_i^T in one FP16 pass, image rows scaled by a power of two each (k_entity_stream hands the
   // scales over).  For the per-pair fp32 image rows of a call that fills whole 256 x 256 grids; everything else: three passes.
+  // (the candidate-count gate of DRIN_PREC_BF16X3_I1 holds for this mode too: with freshly initialised weights the fp16 pass costs
+  //  8e-6 at N = 11, but once the weights are TRAINED the vertex -> score map steepens and 11 candidates average too little - 1.2e-4
+  //  after 200 Adam steps, outside the bar; at N = 101 the same weights give 2e-5: profiles/r4_precision_on_trained_weights.txt)
   const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !xi_planes && cfg->feature_dtype == DRIN_FEAT_F32 &&
+                    cfg->num_candidates >= kMixedMinCandidates &&
                     D == 768 && R == 2048 &&   // (the stream kernel's row-scale hand-over is an instantiation of the exact widths)
                     gemm_nt_f16_scaled_fits(b->entity_image, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
   if (b->entity_text_cls) {

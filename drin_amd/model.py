@@ -531,8 +531,9 @@ class Model(nn.Module):
         the mean over candidates behind it to average its rounding noise down: <= 2.5e-5 on the scores at N = 101 with freshly
         initialised weights, but 1.6e-4 - outside the 1e-4 bar - once the weights are trained (DESIGN.md 4.3): a benchmark mode;
         shorter lists and every other path run "bf16x3") or "bf16x3_if16" (the same one pass on the FP16 matrix
-        instruction, every image row scaled by a power of two into fp16's range: <= 4e-6 on the scores at N = 101, <= 8e-6 at
-        N = 11 - the level of "bf16x3" itself - for the per-pair fp32 image rows of large inference calls; else "bf16x3");
+        instruction, every image row scaled by a power of two into fp16's range: <= 4e-6 on the scores at N = 101 with freshly
+        initialised weights, <= 2e-5 with trained ones - inside the bar either way; same N >= 64 gate (N = 11 on trained weights:
+        1.2e-4) - for the per-pair fp32 image rows of large inference calls; else "bf16x3");
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;
         `grad_bucket`: backward writes every gradient into one flat bucket the `.grad`s are views of (like DDP's
         `gradient_as_bucket_view`: a `.grad` kept across `zero_grad(set_to_none=True)` + `backward()` is overwritten)."""

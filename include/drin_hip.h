@@ -67,9 +67,10 @@ typedef enum {
                               on the FP16 matrix instruction (11-bit operands: an eighth of the bf16 pass's rounding error).
                               fp16's range is made a non-issue by scaling every image row by a power of two (its max |x|
                               into [0.5, 1): exact) before the conversion and the output row back afterwards; the folded
-                              weight is converted once by drin_prepare.  Measured: <= 4e-6 on the scores at N = 101 and <= 8e-6
-                              at N = 11 with freshly initialised weights, <= 2e-5 with trained ones (BF16X3 itself: 2e-6 /
-                              6e-6) - inside the bar either way - so there is no candidate-count gate.  Taken for the
+                              weight is converted once by drin_prepare.  Measured at N = 101: <= 4e-6 on the scores with freshly
+                              initialised weights, <= 2e-5 with trained ones (BF16X3 itself: 2e-6 / 6e-6) - inside the bar
+                              either way.  Same candidate-count gate as BF16X3_I1 (num_candidates >= 64): at N = 11 the
+                              pass costs 8e-6 at initialisation but 1.2e-4 on trained weights.  Taken for the
                               per-pair fp32 image rows of large calls (the benchmark's form); bf16-stored features, the table
                               form and small calls run BF16X3.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
 } drin_precision;
@@ -120,7 +121,8 @@ typedef struct {
  * normalised object row (the image-image edge, model.py:84-92, which feeds mi' and ei' alone) - are stored as fp16 with one
  * power-of-two scale per field and row (exact to apply; the row may have any magnitude): [4 D + R / 2 + 4] floats per
  * entity, 16 400 B instead of 23 568 at D = 768, R = 2 048.  Effect on the scores: 2e-7 at N = 101, 6e-7 at N = 11
- * (oracle/precision_emulation.py; measured: tests/test_gpu_round4.py) - below the split-bf16 contractions' own 1.3e-6.
+ * (oracle/precision_emulation.py; measured: tests/test_gpu_round4.py) - below the split-bf16 contractions' own 1.3e-6; with
+ * TRAINED weights <= 3e-6 at N = 101 and <= 1.7e-5 at N = 11 against the fp32 rows (profiles/r4_precision_on_trained_weights.txt).
  * Needs embed_dim % 8 == 0 and image_dim % 8 == 0. */
 typedef enum {
   DRIN_CACHE_F32 = 0,

@@ -14,15 +14,21 @@ from oracle import drin_oracle as O
 
 DEV = "cuda"
 strength = float(sys.argv[1]) if len(sys.argv) > 1 else 0.15
-cfg = wikimel_config(max_entity_attr_token_len=8, batch_size=64)
+dataset = sys.argv[2] if len(sys.argv) > 2 else "wikimel"
+if dataset == "wikidiverse":
+    from drin_amd.config import DrinConfig
+    cfg = DrinConfig(batch_size=64)
+else:
+    cfg = wikimel_config(max_entity_attr_token_len=8, batch_size=64)
+HELD = 512 if dataset == "wikimel" else 2048          # enough pairs for the one-pass kernel's whole 256 x 256 grids
 torch.manual_seed(0)
 model = Model(cfg).to(DEV)
 opt = make_adam(model, cfg.learning_rate)
 loss_fn = TripletLoss(cfg.triplet_margin)
-held = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 512, 999, "cpu"), strength)]
+held = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, HELD, 999, "cpu"), strength)]
 y = held[14].cpu()
 modes = ("bf16x3", "bf16x3_if16", "bf16x3_i1", "bf16")
-print(f"gold signal strength {strength}; columns: max |score - exact fp32| over 512 x 101 held-out scores (top-1 agreement with the exact path)")
+print(f"gold signal strength {strength}; columns: max |score - exact fp32| over the held-out scores (top-1 agreement with the exact path)")
 step, loss = 0, float("nan")
 for upto in (0, 20, 40, 100, 200, 400):
     while step < upto:
@@ -41,10 +47,10 @@ for upto in (0, 20, 40, 100, 200, 400):
             out[prec] = m(held[:14]).cpu()
     # the per-entity cache's two row formats on the same weights: the held-out pairs' entity rows as a table (one entity per pair)
     from drin_amd.model import EntityTable, IndexedBatch
-    E = 512 * cfg.num_candidates_model
-    table = EntityTable(held[7].reshape(E, *held[7].shape[2:]), held[8].reshape(E, -1), held[9].reshape(E, *held[9].shape[2:]),
+    E = HELD * cfg.num_candidates_model
+    table = EntityTable(held[7].reshape(E, *held[7].shape[2:]), (held[8].reshape(E, -1) if cfg.token_level_entities else None), held[9].reshape(E, *held[9].shape[2:]),
                         held[10].reshape(E, *held[10].shape[2:]), held[11].reshape(E, -1))
-    ib = IndexedBatch(held[:7], table, torch.arange(E, device=DEV).view(512, -1), held[12], held[13])
+    ib = IndexedBatch(held[:7], table, torch.arange(E, device=DEV).view(HELD, -1), held[12], held[13])
     m = Model(cfg).to(DEV).eval()
     m.load_state_dict(sd)
     with torch.no_grad():
@@ -60,4 +66,4 @@ for upto in (0, 20, 40, 100, 200, 400):
     spread = float(ref[:, :-1].max(1).values.sub(ref[:, :-1].median(1).values).mean())
     wn = float(torch.cat([v.flatten() for k, v in sd.items() if k.endswith("weight") and v.dim() == 2]).norm())
     cells = "  ".join(f"{p} {float((out[p] - ref).abs().max()):.2e} ({float((out[p][:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean()):.4f})" for p in modes)
-    print(f"after {step:3d} steps (train loss {loss:.4f}, held-out top-1 {top1}/512, mean top-minus-median score {spread:.3f}, |W| {wn:.1f}):  {cells}  {cache_cells}", flush=True)
+    print(f"after {step:3d} steps (train loss {loss:.4f}, held-out top-1 {top1}/{HELD}, mean top-minus-median score {spread:.3f}, |W| {wn:.1f}):  {cells}  {cache_cells}", flush=True)

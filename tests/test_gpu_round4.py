@@ -538,3 +538,20 @@ def test_precision_modes_on_trained_weights():
     for p in ("bf16x3", "bf16x3_if16", "bf16x3_i1"):
         assert all(abs(counts[p][k] - counts["f32"][k]) <= 1 for k in (1, 5)), (p, counts)
         assert agree[p] >= 0.996, (p, agree)
+    # the per-entity cache's two row formats on the same trained weights (the held-out pairs' entity rows as a table)
+    from drin_amd.model import EntityTable, IndexedBatch
+    E = 512 * cfg.num_candidates_model
+    table = EntityTable(held[7].reshape(E, *held[7].shape[2:]), held[8].reshape(E, -1), held[9].reshape(E, *held[9].shape[2:]),
+                        held[10].reshape(E, *held[10].shape[2:]), held[11].reshape(E, -1))
+    ib = IndexedBatch(held[:7], table, torch.arange(E, device=DEV).view(512, -1), held[12], held[13])
+    m = Model(cfg).to(DEV).eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        table.enable_cache(True)
+        c32 = m(ib).cpu()
+        table.enable_cache(True, format="mixed_f16")
+        c16 = m(ib).cpu()
+    table.enable_cache(False)
+    d_fmt, d32, d16 = (c16 - c32).abs().max().item(), (c32 - ref).abs().max().item(), (c16 - ref).abs().max().item()
+    print(f"per-entity cache on the trained weights: fp32 rows {d32:.2e} / mixed-f16 rows {d16:.2e} from the exact path, {d_fmt:.2e} from each other")
+    assert d32 <= 1e-5 and d16 <= 1e-5 and d_fmt <= 5e-6          # measured 4.2e-6 / 4.1e-6 / 1.3e-6

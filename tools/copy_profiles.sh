@@ -27,9 +27,9 @@ cp $O/summary.txt $P/${R}_mfma_pmc_summary.txt
 cp "$(stats tabm)" $P/${R}_table_cache_mixed_f16_b4096_kernel_stats.csv
 cp $O/table_cache_mixed_f16_bench_under_rocprof.json $P/${R}_table_cache_mixed_f16_b4096_bench_under_rocprof.json
 cp "$(stats wd)" $P/${R}_wikidiverse_b16384_kernel_stats.csv
-cp "$(stats wd_if16)" $P/${R}_wikidiverse_b16384_if16_kernel_stats.csv
+cp "$(stats if16)" $P/${R}_wikimel_b4096_mixed_bf16x3_if16_kernel_stats.csv
 cp $O/wd_bench_under_rocprof.json $P/${R}_wikidiverse_b16384_bench_under_rocprof.json
-cp $O/wd_if16_bench_under_rocprof.json $P/${R}_wikidiverse_b16384_if16_bench_under_rocprof.json
+cp $O/if16_bench_under_rocprof.json $P/${R}_wikimel_b4096_mixed_bf16x3_if16_bench_under_rocprof.json
 # the default line three times (one JSON line each)
 cat $O/wm_bench.json $O/wm_bench_1.json $O/wm_bench_2.json > $P/${R}_wikimel_b4096_bench_all_legs.json
 ls -la $P | grep ${R}_ | wc -l

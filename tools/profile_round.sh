@@ -34,9 +34,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tabm -- python3 b
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_tabm -- python3 bench.py $TABM --steps 2 --warmup 1 $HEAD > $O/pmc_write_tabm.log 2>&1
 python3 tools/collect_pmc.py $O/pmc_fetch_tabm $O/pmc_write_tabm $O/hbm_traffic.json kernels_table_cache_mixed_f16 "python3 bench.py $TABM --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
 echo "[profile_round] table cache done"
-# WikiDiverse-shaped (BASELINE config 2): kernel stats of the default arithmetic and of the fp16 image contraction
+# WikiDiverse-shaped (BASELINE config 2): kernel stats of the default arithmetic (the one-pass image contraction is gated on N >= 64)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wd -- python3 bench.py --workload wikidiverse --steps 10 --warmup 3 $HEAD > $O/wd_bench_under_rocprof.json 2> $O/wd.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/wd_if16 -- python3 bench.py --workload wikidiverse --precision bf16x3_if16 --steps 10 --warmup 3 $HEAD > $O/wd_if16_bench_under_rocprof.json 2> $O/wd_if16.err
+# the fp16 image contraction at the headline's shape (the mode's own kernel stats)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/if16 -- python3 bench.py --precision bf16x3_if16 --steps 10 --warmup 3 $HEAD > $O/if16_bench_under_rocprof.json 2> $O/if16.err
 echo "[profile_round] wikidiverse done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 > $O/train64_bench_under_rocprof.json 2> $O/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train512 -- python3 bench.py --mode train --batch 512 --steps 20 --warmup 30 > $O/train512_bench_under_rocprof.json 2> $O/train512.err

@@ -1,7 +1,7 @@
 """How the precision modes' score errors move as the weights are TRAINED (every other precision measurement uses freshly initialised
 weights): the reference's loop (train.py:30-56: TripletLoss, Adam lr 1e-3, batch 64) on the learnable synthetic stream at the
 reference's width (D = 768, R = 2048, N = 101, T = 8); after 0 / 20 / 40 / 100 / 200 / 400 steps, 512 held-out mentions are scored in
-the exact-fp32 arithmetic and in each mode with the SAME weights.   python tools/precision_on_trained_weights.py [strength]"""
+the exact-fp32 arithmetic and in each mode with the SAME weights.   python tools/precision_on_trained_weights.py [strength] [wikimel|wikidiverse] [steps,steps,...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,7 +30,8 @@ y = held[14].cpu()
 modes = ("bf16x3", "bf16x3_if16", "bf16x3_i1", "bf16")
 print(f"gold signal strength {strength}; columns: max |score - exact fp32| over the held-out scores (top-1 agreement with the exact path)")
 step, loss = 0, float("nan")
-for upto in (0, 20, 40, 100, 200, 400):
+CHECKPOINTS = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 20, 40, 100, 200, 400)
+for upto in CHECKPOINTS:
     while step < upto:
         b = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 64, 50 + step, "cpu"), strength)]
         opt.zero_grad(set_to_none=True)
@@ -38,6 +39,8 @@ for upto in (0, 20, 40, 100, 200, 400):
         l.backward()
         opt.step()
         loss, step = float(l.detach()), step + 1
+        if step % 100 == 0:
+            print(f"  ... step {step}, train loss {loss:.4f}", flush=True)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     out = {}
     for prec in ("f32",) + modes:

@@ -240,6 +240,10 @@ struct CachedPairRow<DV, RV, true> {
   u32x4_t fv[DV];       // per float4 column: fv_t (two dwords), fv_i (two dwords)
   u32x4_t oh[RV / 2];   // o^ in the PAIR layout: eight consecutive columns per lane and load
   float sg, s_fvt, s_fvi, s_o, mtei, miet;
+  // the vertex-phase operands travel a whole step ahead too: the fp16 units leave the registers for it (256 VGPRs, no scratch;
+  // same box, alternating: k_cached_pairs 15.0-15.9 -> 14.9 ms and steadier - profiles/r4_mixed_cache_ab.txt 4).  The fp32
+  // format's rows request them at the top of their own step: its 255 registers leave no room.
+  Row<DV> ht, hi;
 };
 
 // MIXED: rows in the DRIN_CACHE_MIXED_F16 format (RV even)
@@ -319,6 +323,8 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
         if (dyn && c4 < D4) r.fv[j] = ld16_stream(fp + (size_t)c4 * 16);
         else r.fv[j] = u32x4_t{0u, 0u, 0u, 0u};
       }
+      r.ht = load_row_stream<DV>(row, lane, D4);
+      r.hi = load_row_stream<DV>(row + D, lane, D4);
     } else {
       r.chat = load_row_stream<DV>(row + 4 * D, lane, D4);
       r.ohat = load_row_stream<RV>(row + 5 * D, lane, R4);
@@ -388,8 +394,14 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     const PairRow& r = cur;
     __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later pairs' loads into this one (spills)
     // the vertex-phase operands of THIS pair: requested now, needed after the edge phase
-    const Row<DV> ht = load_row_stream<DV>(a.cache + e_cur * a.ldc, lane, D4);
-    const Row<DV> hi = load_row_stream<DV>(a.cache + e_cur * a.ldc + D, lane, D4);   // (same offset in both formats)
+    Row<DV> ht, hi;
+    if constexpr (MIXED) {   // (arrived with the edge-phase operands, one step ahead)
+      ht = r.ht;
+      hi = r.hi;
+    } else {
+      ht = load_row_stream<DV>(a.cache + e_cur * a.ldc, lane, D4);
+      hi = load_row_stream<DV>(a.cache + e_cur * a.ldc + D, lane, D4);
+    }
     // ---- static edges (model.py:71-92, 201-204) ------------------------------------------------------------
     const float e_tt = wave_sum(dot_row_lds<DV>(r.chat, l_s, lane, D4)) * a.mask[0];
     const float e_ti = (r.mtei / a.clip) * a.mask[1];

@@ -44,12 +44,16 @@ PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 def _latest(name):
-    """The newest round's committed counter file (profiles/rN_<name>), as a repo-relative path."""
-    for r in (4, 3):
-        rel = os.path.join("profiles", f"r{r}_{name}")
-        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel)):
-            return rel
-    return os.path.join("profiles", f"r3_{name}")
+    """The newest round's committed counter file (profiles/rN_<name>, highest N), as a repo-relative path."""
+    import glob
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    best = None
+    for path in glob.glob(os.path.join(here, "profiles", f"r*_{name}")):
+        m = re.fullmatch(rf"r(\d+)_{re.escape(name)}", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best):
+            best = int(m.group(1))
+    return os.path.join("profiles", f"r{best}_{name}") if best is not None else os.path.join("profiles", f"r0_{name}")
 
 
 TRAFFIC_FILE = _latest("hbm_traffic.json")
@@ -445,9 +449,9 @@ def cpu_baseline(cfg, sd, seconds=10.0):
             "reference_style_loops_value": it_r * B * N / el_r,
             "wikidiverse_b64_value": it_w * 64 * wd.num_candidates_model / el_w,
             "headline_shape_b64_value": b64,
-            "sample": f"{it} forwards of the CPU oracle on {cfg.dataset_name}-shaped B={B} N={N} fp32, torch "
-                      f"{torch.get_num_threads()} threads, {el:.1f} s; reference-style loops {it_r} forwards {el_r:.1f} s; "
-                      f"wikidiverse-shaped B=64 N={wd.num_candidates_model}: {it_w} forwards {el_w:.1f} s"}
+            "sample": f"{it} CPU-oracle forwards, {cfg.dataset_name}-shaped B={B} N={N} fp32, {torch.get_num_threads()} torch threads, {el:.1f} s",
+            "other_samples": f"reference-style loops {it_r} forwards {el_r:.1f} s; wikidiverse-shaped B=64 N={wd.num_candidates_model}: "
+                             f"{it_w} forwards {el_w:.1f} s"}
 
 
 def slice_batch(batch, rows):
@@ -966,6 +970,9 @@ def parse_args(argv=None):
     ap.add_argument("--legs", default="auto",
                     help="secondary legs of the default run, comma separated: f32_exact,wikimel_mixed_bf16,wikimel_bf16_features,wikidiverse_b4,train_step,train_b512,wikidiverse,table_cache | all | none "
                          "(auto: all for the default headline at N = 1, train_step at N > 1, none when a non-default workload / mode / batch is asked for)")
+    ap.add_argument("--legs-file", default=LEGS_FILE,
+                    help="where the FULL record goes (every leg, scaling model, step floors, provenance); stdout carries the <= 4 KB headline "
+                         "line only; '' = do not write the file")
     ap.add_argument("--stub", action="store_true", help="CPU + gloo stand-in step (no GPU, no library): exercises the launcher and the timing plumbing only")
     args = ap.parse_args(argv)
     if args.warmup is None:
@@ -1021,14 +1028,119 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
-def emit(line):
+LEGS_FILE = os.path.join(REPO, "bench_legs.json")
+LINE_LIMIT = 4096                 # bytes of the stdout line (the driver keeps an 8 KB tail; round 4's 32 KB line was not parsed)
+
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms",
+              "algorithmic_bytes_per_launch", "executed_frac", "mfma_busy")
+_HEAD_KEYS = ("metric", "stub", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "rank_ms_per_step", "roofline", "cpu_baseline", "parity", "hbm_fraction_whole_path",
+              "mfma_fraction_whole_path", "hbm_traffic_whole_path_over_algorithmic", "path", "launch", "collectives_issued",
+              "allreduce_ms", "allreduce_exposed_ms", "allreduce_bytes", "collective", "collective_error",
+              "rank_roofline_avg_launch_ms", "scaling_model", "step_floor_ms", "final_loss", "kernel_ms_per_step")
+
+
+def _strict(x, digits=6):
+    """JSON-safe copy: non-finite floats -> None (strict JSON has no NaN / Infinity token), floats to `digits` significant."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}") if digits else x
+    if isinstance(x, dict):
+        return {str(k): _strict(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d} if isinstance(d, dict) else d
+
+
+def _leg_summary(leg, out, name):
+    """<= ~150 bytes per leg: value, ms_per_step, the dominant kernel's roofline fraction (nested legs flattened as a.b)."""
+    if not isinstance(leg, dict):
+        return
+    if "error" in leg:
+        out[name] = {"error": str(leg["error"])[:100]}
+        return
+    if "value" in leg:
+        s = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step", leg.get("ms_per_call"))}
+        roof = leg.get("roofline")
+        if isinstance(roof, dict):
+            s["frac"], s["bound"] = roof.get("frac"), roof.get("bound")
+        par = leg.get("parity") or (leg.get("train_parity") or {}).get("held_out")
+        if isinstance(par, dict):
+            err = par.get("max_abs_score_err", par.get("max_abs_score_diff"))
+            if err is not None:
+                s["err"] = err
+        out[name] = s
+    for k, v in leg.items():
+        if isinstance(v, dict) and ("value" in v or "error" in v) and k not in ("roofline", "cpu_baseline", "parity"):
+            _leg_summary(v, out, f"{name}.{k}")
+
+
+def headline_only(line, legs_file=None):
+    """The stdout line: the contract fields of the headline, its `roofline`, `cpu_baseline`, `parity`, a one-entry summary of
+    every other leg, and where the full record went - nothing else (everything this drops is in `legs_file`)."""
+    head = _pick(line, _HEAD_KEYS)
+    if isinstance(head.get("roofline"), dict):
+        head["roofline"] = _pick(head["roofline"], _ROOF_KEYS)
+    if isinstance(head.get("cpu_baseline"), dict):
+        head["cpu_baseline"] = _pick(head["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+    if isinstance(head.get("parity"), dict):
+        head["parity"] = _pick(head["parity"], ("max_abs_score_err", "top1_agreement", "mentions"))
+    if isinstance(head.get("collective"), dict):
+        head["collective"] = _pick(head["collective"], ("backend", "world", "forced_world_of_one", "overlap", "pieces", "collectives_issued",
+                                                        "serial_ms_per_step", "no_collective_ms_per_step", "rank_gemm_avg_launch_ms"))
+    sm = head.get("scaling_model")
+    if isinstance(sm, dict):
+        small = _pick(sm, ("collectives_in_the_scoring_path", "step_ms_without_collective", "allreduce_bytes", "hideable_ms"))
+        if "by_world" in sm:
+            small["expected_weak_scaling_efficiency"] = {n: v["expected_weak_scaling_efficiency"] for n, v in sm["by_world"].items()}
+        head["scaling_model"] = small
+    legs = {}
+    for name, leg in (line.get("legs") or {}).items():
+        _leg_summary(leg, legs, name)
+    if legs:
+        head["legs"] = legs
+    if legs_file:
+        head["legs_file"] = os.path.relpath(legs_file, REPO) if legs_file.startswith(REPO) else legs_file
+    head = _strict(head)
+    # never past the limit: drop the optional entries, least important first, until the line fits
+    for k in ("kernel_ms_per_step", "scaling_model", "collective", "legs", "rank_roofline_avg_launch_ms", "path", "launch"):
+        if len(json.dumps(head, allow_nan=False)) <= LINE_LIMIT:
+            break
+        head.pop(k, None)
+    return head
+
+
+def emit(line, legs_file=""):
+    """ONE strict-JSON line <= LINE_LIMIT bytes on stdout (the headline only); the full record - every leg with its roofline,
+    scaling model, step floor and provenance sentences - goes to `legs_file` and to stderr."""
+    legs_file = LEGS_FILE if legs_file == "" else legs_file
+    full = json.dumps(_strict(line, digits=0), allow_nan=False)
+    wrote = None
+    if legs_file:
+        try:
+            with open(legs_file, "w") as f:
+                f.write(full + "\n")
+            wrote = legs_file
+        except OSError as e:
+            sys.stderr.write(f"bench.py: could not write {legs_file}: {e}\n")
+    sys.stderr.write("[bench.py full record] " + full + "\n")
+    sys.stderr.flush()
+    text = json.dumps(headline_only(line, wrote), allow_nan=False)
+    assert len(text) <= LINE_LIMIT, len(text)
     out = _REAL_STDOUT or sys.stdout
-    out.write(json.dumps(line) + "\n")
+    out.write(text + "\n")
     out.flush()
 
 
 def main(argv=None):
+    global LEGS_FILE
     args = parse_args(argv)
+    LEGS_FILE = os.path.abspath(args.legs_file) if args.legs_file else None
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_children(args))                     # before anything touches the GPU in this process
     quiet_stdout()

@@ -63,3 +63,60 @@ def test_force_collective_runs_the_allreduce_in_a_world_of_one():
     assert line["n_gpus"] == 1 and line["collectives_issued"] == 4
     r = _run("--stub", "--mode", "train", "--steps", "3", "--warmup", "1")
     assert json.loads(r.stdout.strip().splitlines()[-1])["collectives_issued"] == 0
+
+
+def _reject_constant(tok):
+    raise ValueError(f"non-strict JSON token {tok}")
+
+
+@pytest.mark.parametrize("argv", [("--stub", "--steps", "2", "--warmup", "0"),
+                                  ("--gpus", "2", "--stub", "--steps", "2", "--warmup", "0", "--mode", "train")])
+def test_stdout_line_is_small_strict_json_and_the_full_record_goes_to_the_legs_file(argv, tmp_path):
+    """The driver parses ONE stdout line and keeps an 8 KB tail: the line carries the headline only (<= 4 KB, no NaN /
+    Infinity tokens); everything else is in --legs-file (round 4's 32 KB line left BENCH_r04.json with parsed = null)."""
+    legs = tmp_path / "full.json"
+    r = _run(*argv, "--legs-file", str(legs))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    assert len(lines[0].encode()) < 4096
+    line = json.loads(lines[0], parse_constant=_reject_constant)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+        assert k in line, k
+    assert "workload" in line["config"] and "model" not in line["config"]
+    full = json.loads(legs.read_text(), parse_constant=_reject_constant)
+    assert full["value"] == pytest.approx(line["value"], rel=1e-5) and line["legs_file"] == str(legs)
+
+
+def test_headline_of_a_full_round4_record_fits_and_keeps_roofline_cpu_baseline_parity():
+    """headline_only() on the largest record this repository has produced (round 4's 32 KB default line with 11 legs)."""
+    sys.path.insert(0, REPO)
+    import bench
+    path = os.path.join(REPO, "profiles", "r4_wikimel_b4096_bench_all_legs.json")
+    rec = json.loads(open(path).readline())
+    rec["roofline"]["traffic"] = float("nan")                        # a non-finite value must come out as null, never NaN
+    rec["legs"]["f32_exact"]["value"] = float("inf")
+    text = json.dumps(bench.headline_only(rec, os.path.join(REPO, "bench_legs.json")), allow_nan=False)
+    assert len(text) <= bench.LINE_LIMIT < 8192
+    head = json.loads(text, parse_constant=_reject_constant)
+    assert head["roofline"]["traffic"] is None and head["legs"]["f32_exact"]["value"] is None
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms",
+            "algorithmic_bytes_per_launch"} <= set(head["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(head["cpu_baseline"])
+    assert {"max_abs_score_err", "top1_agreement", "mentions"} == set(head["parity"])
+    assert head["legs_file"] == "bench_legs.json" and set(head["legs"]) >= {"train_step", "table_cache", "wikidiverse.fp32_features"}
+    assert all(len(json.dumps(v)) <= 150 for v in head["legs"].values())
+    # a record ten times fatter still fits: optional entries are dropped, the contract fields never
+    rec["legs"] = {f"leg{i}": dict(rec["legs"]["train_step"]) for i in range(200)}
+    text = json.dumps(bench.headline_only(rec, None), allow_nan=False)
+    assert len(text) <= bench.LINE_LIMIT and "roofline" in json.loads(text) and "cpu_baseline" in json.loads(text)
+
+
+def test_latest_counter_file_is_found_by_round_number_not_a_hard_coded_list(tmp_path, monkeypatch):
+    sys.path.insert(0, REPO)
+    import bench
+    assert bench._latest("hbm_traffic.json").startswith("profiles/r")
+    n = int(bench._latest("hbm_traffic.json").split("/r")[1].split("_")[0])
+    existing = sorted(int(f.split("_")[0][1:]) for f in os.listdir(os.path.join(REPO, "profiles"))
+                      if f.endswith("_hbm_traffic.json") and f[1:].split("_")[0].isdigit())
+    assert n == existing[-1]

@@ -4,8 +4,8 @@
 V=${1:?variant}; LEG=${2:?leg}; N=${3:-3}
 for i in $(seq $N); do
   for v in "" $V; do
-    if [ -z "$v" ]; then python bench.py --legs $LEG --no-cpu-baseline --steps 10 2>/dev/null > /tmp/x.json; else
-      DRIN_LIB_PATH=$PWD/drin_amd/libdrin_hip_$v.so python bench.py --legs $LEG --no-cpu-baseline --steps 10 2>/dev/null > /tmp/x.json; fi
+    if [ -z "$v" ]; then python bench.py --legs $LEG --no-cpu-baseline --steps 10 --legs-file /tmp/x.json 2>/dev/null > /dev/null; else
+      DRIN_LIB_PATH=$PWD/drin_amd/libdrin_hip_$v.so python bench.py --legs $LEG --no-cpu-baseline --steps 10 --legs-file /tmp/x.json 2>/dev/null > /dev/null; fi
     python - "${v:-shipped}" "$LEG" <<'PY'
 import json, sys
 l = json.load(open('/tmp/x.json'))

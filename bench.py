@@ -1117,7 +1117,7 @@ def headline_only(line, legs_file=None):
 
 def emit(line, legs_file=""):
     """ONE strict-JSON line <= LINE_LIMIT bytes on stdout (the headline only); the full record - every leg with its roofline,
-    scaling model, step floor and provenance sentences - goes to `legs_file` and to stderr."""
+    scaling model, step floor and provenance sentences - goes to `legs_file` (one short pointer line on stderr)."""
     legs_file = LEGS_FILE if legs_file == "" else legs_file
     full = json.dumps(_strict(line, digits=0), allow_nan=False)
     wrote = None
@@ -1128,7 +1128,9 @@ def emit(line, legs_file=""):
             wrote = legs_file
         except OSError as e:
             sys.stderr.write(f"bench.py: could not write {legs_file}: {e}\n")
-    sys.stderr.write("[bench.py full record] " + full + "\n")
+    # (the full record is NOT copied to stderr: the driver keeps one 8 KB tail of stdout followed by stderr, and 30 KB of stderr
+    #  would push the stdout line out of it)
+    sys.stderr.write(f"[bench.py] full record ({len(full)} bytes): {wrote or 'not written'}\n")
     sys.stderr.flush()
     text = json.dumps(headline_only(line, wrote), allow_nan=False)
     assert len(text) <= LINE_LIMIT, len(text)

@@ -298,7 +298,7 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
     dom = max(prof, key=lambda k: prof[k][0])
     ms, launches = prof[dom]
     per_launch_ms = ms / max(launches, 1)
-    x3 = precision in ("bf16x3", "bf16", "bf16x3_i1", "bf16x3_if16")
+    x3 = precision in ("bf16x3", "bf16x3_if16")
     flops_pair = path_flops_per_pair(D, R, cfg.num_gcn_layers, cfg.gcn_edge_type == "dynamic", fused)
     ab = algorithmic_bytes(cfg, batch)
     stream_bytes_pair = ab["entity"] + ab["mention_stream"]          # what k_entity_stream itself has to read
@@ -331,7 +331,7 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
         # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
         if dom == "gemm_planes":
             step_flops = pairs * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
-            if not cached and (workload == "table" or features == "bf16"):
+            if not cached and (workload == "table" or features == "bf16") and not if16_taken(precision, cfg, workload, B):
                 step_flops += pairs * 2.0 * R * D   # x_i C_i^T runs on this kernel too (gathered / bf16 image planes)
         elif dom == "gemm_x3" and fused:
             # x_i C_i^T plus the mention-sized products, which run on the same kernel from 256 rows up
@@ -344,8 +344,7 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(launches),
                 "avg_launch_ms": per_launch_ms}
         if dom != "gemm":
-            passes = 1 if (precision == "bf16" or (precision == "bf16x3_i1" and dom == "gemm_x3" and N >= 64)
-                           or (precision == "bf16x3_if16" and dom == "gemm_x3")) else 3
+            passes = 1 if (dom == "gemm_x3" and if16_taken(precision, cfg, workload, B)) else 3
             roof["executed_bf16_tflops"] = passes * achieved
             roof["executed_frac"] = passes * achieved / peak
             section = None
@@ -355,13 +354,21 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
     return roof, ab, stream_bytes_pair, flops_pair
 
 
-def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision):
+def if16_taken(precision, cfg, workload, B):
+    """Whether a call takes the one-pass fp16 image contraction: the library's own gate (csrc/fused_forward.hip: N >= 64, the exact
+    widths, per-pair rows, at least 128 tiles of 256 x 256) - a `bf16x3_if16` line of any other shape ran split-bf16 and says so."""
+    D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
+    tiles = -(-B * N // 256) * -(-D // 256)
+    return precision == "bf16x3_if16" and N >= 64 and D == 768 and R == 2048 and workload != "table" and tiles >= 128
+
+
+def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision, workload="wikimel", B=1 << 20):
     D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
-    x3 = precision in ("bf16x3", "bf16", "bf16x3_i1", "bf16x3_if16")
+    x3 = precision in ("bf16x3", "bf16x3_if16")
     peak = (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12
     ref_flops = 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D
-    executed = ((1 if precision == "bf16" else 3) if x3 else 1) * flops_pair
-    if (precision == "bf16x3_i1" and cfg.num_candidates_model >= 64) or precision == "bf16x3_if16":
+    executed = (3 if x3 else 1) * flops_pair
+    if if16_taken(precision, cfg, workload, B):
         executed -= 2 * 2.0 * R * D                       # the image contraction in one pass instead of three
     return {
         "hbm_fraction_whole_path": ab["whole_path"] * rate_per_gpu / (PEAK_HBM_GBS * 1e9),
@@ -541,7 +548,7 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
     cache_format = cache_format or getattr(args, "cache_format", "f32")
     roof, ab, stream_bytes_pair, flops_pair = score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused, cache_format)
     value = pairs * ctx.world * steps / elapsed
-    fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision)
+    fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision, workload, B)
     # the one HBM-bound pass over the entity bytes, whichever class is the longest of this leg
     s_ms, s_n = prof.get("stream", (0.0, 0))
     hbm_kernel = None
@@ -579,8 +586,9 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
         "hbm_traffic_whole_path_source": (f"{TRAFFIC_FILE} whole_path: launches per call x FETCH_SIZE / WRITE_SIZE bytes per launch of every "
                                           "kernel of the call (tools/collect_pmc.py), replayed - not re-measured in this run") if whole_traffic else None,
         "launch": "hipGraph replay" if graph else "eager",
-        "path": ((f"per-entity cache ({cache_format} rows) + layer 2") if cached else "fused two-layer" if fused else "layer-by-layer") + ", " + precision
-                + (", features stored as bf16" if features == "bf16" else ""),
+        "path": ((f"per-entity cache ({cache_format} rows) + layer 2") if cached else "fused two-layer" if fused else "layer-by-layer") + ", "
+                + ("bf16x3 (the fp16 image contraction is not taken at this shape)" if (precision == "bf16x3_if16" and not if16_taken(precision, cfg, workload, B))
+                   else precision) + (", features stored as bf16" if features == "bf16" else ""),
         "algorithmic": {"bytes_per_pair": ab["whole_path"], "dominant_kernel_bytes_per_pair": stream_bytes_pair,
                         "bytes_per_pair_split": ab, "flops_per_pair_executed": flops_pair, "flops_per_pair_reference": ref_flops},
     }
@@ -659,7 +667,7 @@ def train_roofline(cfg, B, N, prof, steps, precision):
     if ms <= 0:
         return None
     tf = (fwd + bwd) * B * N * steps / (ms * 1e-3) / 1e12
-    x3 = precision in ("bf16x3", "bf16")
+    x3 = precision == "bf16x3"
     peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS
     out = {"bound": "mfma", "kernel": "k_gemm_bf16x3 + k_gemm_tn_bf16x3", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
            "frac": tf / peak, "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
@@ -944,9 +952,10 @@ def parse_args(argv=None):
                          "--mentions 1000000 --chunk 4096); a step is one chunk")
     ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=0, help="mentions per step per GPU (default 4096 wikimel / 16384 wikidiverse / 512 table)")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16", "bf16x3_i1", "bf16x3_if16"],
-                    help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate; "
-                         "max score error vs the fp32 reference 1.4e-6, tests/test_gpu_parity.py)")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16x3_if16"],
+                    help="contraction arithmetic: exact fp32 MFMA, split-bf16 (3 bf16 MFMAs, fp32 accumulate; max score error vs the fp32 "
+                         "reference 1.4e-6, tests/test_gpu_parity.py), or split-bf16 with the entity-image contraction in one fp16 pass "
+                         "(<= 2e-5 on trained weights; N >= 64 only)")
     ap.add_argument("--features", default="f32", choices=["f32", "bf16"],
                     help="storage type of the six feature tensors (BASELINE configs 2-3 name bf16): bf16 halves the bytes "
                          "of the HBM-bound pass; arithmetic stays fp32-equivalent and the scores equal the reference "
@@ -968,7 +977,7 @@ def parse_args(argv=None):
                          "gradient all-reduce in it - the real collective code path on a one-GPU box; allreduce_ms is then non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--legs", default="auto",
-                    help="secondary legs of the default run, comma separated: f32_exact,wikimel_mixed_bf16,wikimel_bf16_features,wikidiverse_b4,train_step,train_b512,wikidiverse,table_cache | all | none "
+                    help="secondary legs of the default run, comma separated: f32_exact,wikimel_mixed_f16,wikimel_bf16_features,wikidiverse_b4,train_step,train_b512,wikidiverse,table_cache | all | none "
                          "(auto: all for the default headline at N = 1, train_step at N > 1, none when a non-default workload / mode / batch is asked for)")
     ap.add_argument("--legs-file", default=LEGS_FILE,
                     help="where the FULL record goes (every leg, scaling model, step floors, provenance); stdout carries the <= 4 KB headline "
@@ -981,7 +990,7 @@ def parse_args(argv=None):
 
 
 def wanted_legs(args, world):
-    names = ("f32_exact", "wikimel_mixed_bf16", "wikimel_mixed_f16", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "train_b512", "wikidiverse", "table_cache")
+    names = ("f32_exact", "wikimel_mixed_f16", "wikimel_bf16_features", "wikidiverse_b4", "train_step", "train_b512", "wikidiverse", "table_cache")
     default_headline = (args.workload == "wikimel" and args.mode == "score" and not args.batch and not args.generic
                         and args.precision == "bf16x3" and args.features == "f32" and not args.graph)
     if args.legs == "auto":
@@ -1040,7 +1049,7 @@ _HEAD_KEYS = ("metric", "stub", "value", "unit", "n_gpus", "steps", "warmup", "m
               "rank_roofline_avg_launch_ms", "scaling_model", "step_floor_ms", "final_loss", "kernel_ms_per_step")
 
 
-def _strict(x, digits=6):
+def _strict(x, digits=9):
     """JSON-safe copy: non-finite floats -> None (strict JSON has no NaN / Infinity token), floats to `digits` significant."""
     if isinstance(x, float):
         if x != x or x in (float("inf"), float("-inf")):
@@ -1229,28 +1238,13 @@ def main(argv=None):
             return compact(ln, keep=("value", "unit", "ms_per_step", "steps", "dtype", "path", "roofline", "kernel_ms_per_step",
                                      "parity", "max_abs_diff_vs_headline_scores"))
         extra["f32_exact"] = leg_guard("f32_exact", f32_leg)
-    if "wikimel_mixed_bf16" in legs and world == 1:
-        def mixed_leg():
-            # BASELINE's "bf16 inference" INSIDE the 1e-4 bar: precision by contraction (`bf16x3_i1`) - only the folded entity-image
-            # contraction x_i (W_h1 W_ei)^T, 57 % of the path's FLOPs, runs one bf16 MFMA pass; its result reaches the score
-            # through a mean over the 101 candidates alone (model.py:124-129,143-144).  Same batch as the headline; every score
-            # against the headline's (split-bf16, itself within 1.4e-6 of the oracle), slices against the oracle
-            m = make_model(cfg, sd, dev, "bf16x3_i1")
-            st = min(args.steps, 10)
-            e, pr, o, pf = run_score(ctx, m, batch, st, 2)
-            ln = score_line(ctx, cfg, args, B, batch, e, pr, pf, st, 2, "bf16x3_i1", args.features, args.workload, False, fused)
-            ln["parity"] = parity_of_timed_batch(cfg, sd, batch, o, n_slices=8, width=8)
-            ln["parity"]["max_abs_diff_vs_headline_scores_all"] = float((o - out).abs().max())
-            ln["parity"]["top1_agreement_vs_headline_all_mentions"] = float((o[:, :-1].argmax(1) == out[:, :-1].argmax(1)).float().mean())
-            res = compact(ln)
-            res["note"] = ("parity above is at the benchmark's random-init weights; with TRAINED weights this mode reaches 0.5-1.6e-4 against the "
-                           "exact-fp32 path - outside the 1e-4 bar (profiles/r4_precision_on_trained_weights.txt): a benchmark mode")
-            return res
-        extra["wikimel_mixed_bf16"] = leg_guard("wikimel_mixed_bf16", mixed_leg)
     if "wikimel_mixed_f16" in legs and world == 1:
         def f16_leg():
-            # the same one pass on the FP16 matrix instruction (`bf16x3_if16`): 11-bit operands, every image row scaled by a power
-            # of two into fp16's range and back - an eighth of the bf16 pass's rounding error, i.e. the split product's own level
+            # BASELINE's "bf16 inference" INSIDE the 1e-4 bar: precision by contraction (`bf16x3_if16`) - only the folded entity-image
+            # contraction x_i (W_h1 W_ei)^T, 57 % of the path's FLOPs, runs ONE pass of the FP16 matrix instruction (11-bit operands) on
+            # the fp16 plane the stream kernel writes under a power-of-two scale per row; its result reaches the score through a mean
+            # over the 101 candidates alone (model.py:124-129,143-144).  Same batch as the headline; every score against the
+            # headline's (split-bf16, itself within 1.4e-6 of the oracle), slices against the oracle
             m = make_model(cfg, sd, dev, "bf16x3_if16")
             st = min(args.steps, 10)
             e, pr, o, pf = run_score(ctx, m, batch, st, 2)
@@ -1273,11 +1267,11 @@ def main(argv=None):
             ln = score_line(ctx, cfg, args, B, b16, e, pr, pf, st, 2, args.precision, "bf16", args.workload, False, fused)
             ln["parity"] = parity_of_timed_batch(cfg, sd, b16, o, n_slices=4, width=8, fp32_batch=batch)
             res = compact(ln)
-            # the same stored features with the image contraction in ONE bf16 pass (`bf16x3_i1`): the bf16 image rows are exact in
-            # their plane, so only the folded weight is rounded - the two-pass form above drops to one MFMA per tile pair
-            mm = make_model(cfg, sd, dev, "bf16x3_i1")
+            # the same stored features with the image contraction in ONE fp16 pass (`bf16x3_if16`): a bf16 image row is exact in fp16
+            # under its row scale, so only the folded weight is rounded (11 bits) - the two-pass form above drops to one MFMA per tile pair
+            mm = make_model(cfg, sd, dev, "bf16x3_if16")
             e, pr, o2, pf = run_score(ctx, mm, b16, st, 2)
-            l2 = score_line(ctx, cfg, args, B, b16, e, pr, pf, st, 2, "bf16x3_i1", "bf16", args.workload, False, fused)
+            l2 = score_line(ctx, cfg, args, B, b16, e, pr, pf, st, 2, "bf16x3_if16", "bf16", args.workload, False, fused)
             l2["parity"] = parity_of_timed_batch(cfg, sd, b16, o2, n_slices=4, width=8)
             l2["parity"]["max_abs_diff_vs_three_pass_scores_all"] = float((o2 - o).abs().max())
             l2["parity"]["top1_agreement_vs_three_pass_all_mentions"] = float((o2[:, :-1].argmax(1) == o[:, :-1].argmax(1)).float().mean())
@@ -1314,22 +1308,6 @@ def main(argv=None):
         if world == 1 and rank == 0 and not args.no_cpu_baseline and "error" not in extra["train_step"]:
             extra["train_step"]["train_parity"] = leg_guard("train_parity", lambda: train_parity(dev))
 
-            def dw_leg():
-                # EXPERIMENT, reported, not adopted: the pair-sized weight-gradient products in ONE bf16 pass
-                # (drin_set_weight_gradient_passes(1)) - the same step timed, the same 10-step trajectory against the oracle's loop
-                from drin_amd import _lib
-                lib = _lib.load()
-                _lib.check(lib.drin_set_weight_gradient_passes(1))
-                try:
-                    r = bench_train(ctx, cfg, sd, 64, 20, 30)
-                    out = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps") if k in r}
-                    out["train_parity"] = train_parity(dev)
-                finally:
-                    lib.drin_set_weight_gradient_passes(-1)
-                out["note"] = ("weight gradients 2.5e-3 from the fp64 oracle's instead of 1.2e-5; 60 / 200-step trajectories: "
-                               "profiles/r4_dw_one_pass.txt - off by default")
-                return out
-            extra["train_step"]["experiment_weight_gradients_one_pass"] = leg_guard("dw_one_pass", dw_leg)
         if world == 1:
             def rccl_leg():
                 # BASELINE config 4's collective code path as far as ONE GPU can run it: an RCCL process group of one rank, the

@@ -156,7 +156,7 @@ int validate_config(const drin_config* c) {
     return DRIN_E_UNSUPPORTED;
   }
   if (c->precision != DRIN_PREC_F32 && c->precision != DRIN_PREC_BF16X3 && c->precision != DRIN_PREC_BF16X3_ALL &&
-      c->precision != DRIN_PREC_BF16 && c->precision != DRIN_PREC_BF16X3_I1 && c->precision != DRIN_PREC_BF16X3_IF16) {
+      c->precision != DRIN_PREC_BF16X3_IF16) {
     set_error("config: precision %d is not a drin_precision", c->precision);
     return DRIN_E_UNSUPPORTED;
   }
@@ -172,8 +172,8 @@ static int validate_batch(const drin_config* c, const drin_batch* b) {
     set_error("bf16 feature storage is read by drin_forward_prepared only; widen the features to fp32 for this entry point");
     return DRIN_E_UNSUPPORTED;
   }
-  if (c->precision == DRIN_PREC_BF16 || c->precision == DRIN_PREC_BF16X3_I1 || c->precision == DRIN_PREC_BF16X3_IF16) {
-    set_error("DRIN_PREC_BF16 / DRIN_PREC_BF16X3_I1 / _IF16 (one-pass contractions) are inference modes of drin_forward_prepared; use DRIN_PREC_BF16X3 here");
+  if (c->precision == DRIN_PREC_BF16X3_IF16) {
+    set_error("DRIN_PREC_BF16X3_IF16 (the entity-image contraction in one fp16 pass) is an inference mode of drin_forward_prepared; use DRIN_PREC_BF16X3 here");
     return DRIN_E_UNSUPPORTED;
   }
   const void* req[] = {b->mention_text,  b->mention_start,        b->mention_end,     b->mention_image,
@@ -497,7 +497,7 @@ int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, 
       const size_t used = ((size_t)n_out * k + 63) & ~(size_t)63;
       float* tail = scratch_floats > used ? scratch + used : nullptr;
       DRIN_TRY(launch_gemm_nt_bf16x3(dy, n_out, scratch, n_out, nullptr, dx, k, rows, k, n_out, st, nullptr, nullptr, false,
-                                     false, tail, tail ? scratch_floats - used : 0));
+                                     tail, tail ? scratch_floats - used : 0));
     } else {
       DRIN_TRY(launch_gemm_nn(dy, n_out, w, k, dx, k, rows, k, n_out, false, precision, st));
     }
@@ -608,9 +608,9 @@ int drin_forward_staged(const drin_config* cfg, const drin_batch* batch, const d
     const __bf16* pt = reinterpret_cast<const __bf16*>(wp(L.wp_enc[2]));
     const __bf16* pi = reinterpret_cast<const __bf16*>(wp(L.wp_enc[3]));
     DRIN_TRY(launch_gemm_nt_bf16x3(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, st,
-                                   pt, pt ? pt + (size_t)D * D : nullptr, false, false, tl, tlf, eidx));
+                                   pt, pt ? pt + (size_t)D * D : nullptr, false, tl, tlf, eidx));
     DRIN_TRY(launch_gemm_nt_bf16x3(P.entity_image, R, params->w_entity_image, R, params->b_entity_image, ve0 + (size_t)M * D,
-                                   D, M, D, R, st, pi, pi ? pi + (size_t)D * R : nullptr, false, false, tl, tlf, eidx));
+                                   D, M, D, R, st, pi, pi ? pi + (size_t)D * R : nullptr, false, tl, tlf, eidx));
   } else {
     DRIN_TRY(launch_gemm_nt(P.entity_text, D, params->w_entity_text, D, params->b_entity_text, ve0, D, M, D, D, false,
                             prec, st, tl, tlf, wp(L.wp_enc[2])));
@@ -879,7 +879,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
       if (w_t != nullptr) {
         const __bf16* hi = reinterpret_cast<const __bf16*>(w_t);
         return launch_gemm_nt_bf16x3(dy, lddy, nullptr, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, hi, hi + (size_t)k_red * n_out,
-                                     accumulate, false, tnp, tnf);
+                                     accumulate, tnp, tnf);
       }
       if (w_t == nullptr) {
         float* wt = ws + L.wt + (size_t)2 * nl * D * D;   // the scratch slot: never one of the pre-transposed weights
@@ -887,7 +887,7 @@ int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const 
         w_t = wt;
       }
       return launch_gemm_nt_bf16x3(dy, lddy, w_t, k_red, nullptr, dx, lddx, rows, n_out, k_red, st, nullptr, nullptr, accumulate,
-                                   false, tnp, tnf);
+                                   tnp, tnf);
     }
     return launch_gemm_nn(dy, lddy, w, n_out, dx, lddx, rows, n_out, k_red, accumulate, prec, st,
                           L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);

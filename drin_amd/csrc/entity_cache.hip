@@ -616,9 +616,8 @@ static int cache_supported(const drin_config* c) {
     set_error("entity cache: at most 8 mention objects (got %d)", c->mention_objects);
     return DRIN_E_UNSUPPORTED;
   }
-  if (c->feature_dtype != DRIN_FEAT_F32 || c->precision == DRIN_PREC_BF16 || c->precision == DRIN_PREC_BF16X3_I1 ||
-      c->precision == DRIN_PREC_BF16X3_IF16) {
-    set_error("entity cache: bf16 feature storage / DRIN_PREC_BF16 / DRIN_PREC_BF16X3_I1 belong to drin_forward_prepared only");
+  if (c->feature_dtype != DRIN_FEAT_F32 || c->precision == DRIN_PREC_BF16X3_IF16) {
+    set_error("entity cache: bf16 feature storage / DRIN_PREC_BF16X3_IF16 belong to drin_forward_prepared only");
     return DRIN_E_UNSUPPORTED;
   }
   if (cache_mixed(*c) && (c->embed_dim % 8 || c->image_dim % 8)) {

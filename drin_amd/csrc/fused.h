@@ -13,7 +13,8 @@ struct Prepared {  // offsets in floats
   size_t wcat1, bcat1, ecat, etmp, k_t, k_i, c_txt, c_img, cb_t, cb_i, total;
   size_t p_ctxt, p_cimg, p_wh2;  // bf16 (hi, lo) planes of the three pair-sized GEMM weights; lo follows hi
   size_t p_wmt, p_wmi, p_wcat1, p_ecat, p_wet, p_wei, p_wh1;  // the same for the mention-sized GEMM weights
-  size_t p_cimg_f16;             // W_h1 W_ei as ONE fp16 plane [D, R] (DRIN_PREC_BF16X3_IF16)
+  size_t p_cimg_f16;             // W_h1 W_ei as ONE fp16 plane [D, R] under one power-of-two scale (DRIN_PREC_BF16X3_IF16)
+  size_t cimg_f16_scale;         // [2]: that scale, and the scratch word of its reduction
   void build(const drin_config& c) {
     const size_t D = c.embed_dim, R = c.image_dim;
     size_t off = 0;
@@ -43,6 +44,7 @@ struct Prepared {  // offsets in floats
     p_wei = take(D * R);          // W_ei
     p_wh1 = take(D * D);          // W_h1
     p_cimg_f16 = take(D * R / 2 + 2);   // D R halves
+    cimg_f16_scale = take(2);
     total = off;
   }
 };
@@ -77,7 +79,8 @@ struct StreamArgs {
   void* xt_lo;
   void* xi_hi;                       // optional bf16 hi / lo planes of the entity image rows [M, R]
   void* xi_lo;
-  float* xi_scale;                   // optional [M]: 2^ceil(log2 max |image row|) per pair (1 for an all-zero row) - DRIN_PREC_BF16X3_IF16
+  float* xi_scale;                   // optional [M]: 2^ceil(log2 max |image row|) per pair (1 for an all-zero row) - DRIN_PREC_BF16X3_IF16 -
+  void* xi_f16;                      //   and with it [M, R] fp16: the image row divided by that scale (the one plane of its contraction)
   float* e0m;                        // [4][M] layer-1 edges (already multiplied by the edge switch)
   float* e1m;                        // [4][M] layer-2 edges (ditto)
   float* s_part;                     // [B][chunks][2 D + 2 R + 4]

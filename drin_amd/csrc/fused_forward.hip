@@ -17,14 +17,10 @@
 // 5.5 MFLOP - plus ONE streaming pass over the entity bytes (k_entity_stream) and two row kernels.
 // The folded matrices depend only on the weights: drin_prepare computes them once per weight version
 // into a caller-owned buffer.
-#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
-#include <atomic>
-#include <mutex>
-#include <vector>
 
 #include "fused.h"
 #include "internal.h"
@@ -32,9 +28,7 @@
 
 namespace drin {
 
-// side-by-side phases (below): off until measured; DRIN_PIPE / drin_set_pipeline choose
-constexpr int kPipeDefaultStreamCus = 0, kPipeDefaultChunkPairs = 51712;
-// DRIN_PREC_BF16X3_I1: the shortest candidate list whose mean averages the one-pass image contraction's noise far enough
+// DRIN_PREC_BF16X3_IF16: the shortest candidate list whose mean averages the one-pass image contraction's noise far enough
 constexpr int kMixedMinCandidates = 64;
 
 struct FusedLayout {  // workspace offsets in floats
@@ -85,10 +79,9 @@ struct FusedLayout {  // workspace offsets in floats
     s2_part = take(B * chunks * 2 * D);
     agg2 = take(B * D);
     mt2 = take(B * D);
-    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16 ||
-                        c.precision == DRIN_PREC_BF16X3_I1 || c.precision == DRIN_PREC_BF16X3_IF16;
+    const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16X3_IF16;
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
-    p_xi = take(planes ? M * R : 0);   // used by the table form only
+    p_xi = take(planes ? M * R : 0);   // the table form's (hi, lo) image planes; DRIN_PREC_BF16X3_IF16: the one fp16 plane (its first half)
     p_et1 = take(planes ? M * D : 0);
     xi_scale = take(c.precision == DRIN_PREC_BF16X3_IF16 ? M : 0);   // per-pair power-of-two scale of the image row
     // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
@@ -221,7 +214,8 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
     DRIN_TRY(launch_split_planes(pb + P.c_txt, q, q + dd, dd, st));
     q = reinterpret_cast<__bf16*>(pb + P.p_cimg);
     DRIN_TRY(launch_split_planes(pb + P.c_img, q, q + dr, dr, st));
-    DRIN_TRY(launch_to_f16(pb + P.c_img, pb + P.p_cimg_f16, (int64_t)dr, st));   // DRIN_PREC_BF16X3_IF16: one fp16 plane
+    // DRIN_PREC_BF16X3_IF16: one fp16 plane under one power-of-two scale (weights of any magnitude stay inside fp16's range)
+    DRIN_TRY(launch_to_f16_scaled(pb + P.c_img, pb + P.p_cimg_f16, (int64_t)dr, pb + P.cimg_f16_scale, st));
     q = reinterpret_cast<__bf16*>(pb + P.p_wh2);
     DRIN_TRY(launch_split_planes(params->layer[1].w_h, q, q + dd, dd, st));
     // mention-sized GEMM weights (they matter for short candidate lists: at N = 11 the mention side is a third
@@ -243,12 +237,11 @@ int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepar
 
 namespace drin {
 
-// The call in two halves.  kPhaseStream: everything up to and including the one pass over the entity bytes (HBM-bound);
-// kPhaseContract: the contractions and row kernels behind it (MFMA-bound).  Together: the whole forward on one stream.
-enum { kPhaseStream = 1, kPhaseContract = 2, kPhaseAll = 3 };
-
-static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
-                                   void* workspace, float* scores, hipStream_t st, const int phases) {
+// The whole forward on the caller's stream: the one pass over the entity bytes (HBM-bound), then the contractions and row kernels
+// behind it (MFMA-bound).  (Running the two halves of consecutive mention chunks side by side - two streams, forced co-residency,
+// disjoint CU masks - was built in round 3 and measured slower every time; removed in round 5: profiles/r3_pipeline_probe.txt.)
+static int forward_prepared_on_stream(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
+                                      void* workspace, float* scores, hipStream_t st) {
   FusedLayout L;
   L.build(*cfg);
   Prepared P;
@@ -258,17 +251,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   const int B = cfg->batch, N = cfg->num_candidates, D = cfg->embed_dim, R = cfg->image_dim;
   const int64_t M = (int64_t)B * N;
   if (B == 0) return DRIN_OK;
-  // DRIN_PREC_BF16: the three pair-sized contractions run one bf16 MFMA pass (operands rounded to bf16, no lo planes);
-  // everything mention-sized keeps the split-bf16 / exact-fp32 arithmetic of DRIN_PREC_BF16X3
-  const bool one_pass = cfg->precision == DRIN_PREC_BF16;
-  // DRIN_PREC_BF16X3_I1, precision by contraction: only x_i C_i^T runs one pass - its result, the layer-1 entity image
-  // vertex, reaches the score through a mean over the N candidates alone (model.py:124-129,143-144), which averages the
-  // rounding noise down: 1.7-2.5e-5 on the scores at N = 101 against 3e-4 for either D x D contraction (oracle/
-  // precision_emulation.py; tests/test_gpu_round4.py).  At N = 11 the averaging is sqrt(11): 5-10e-5, no margin under the
-  // 1e-4 bar - lists shorter than kMixedMinCandidates keep three passes (then the mode IS split-bf16, bit for bit).
-  const bool i1 = cfg->precision == DRIN_PREC_BF16X3_I1 && cfg->num_candidates >= kMixedMinCandidates;
-  const int prec = (one_pass || cfg->precision == DRIN_PREC_BF16X3_I1 || cfg->precision == DRIN_PREC_BF16X3_IF16) ? (int)DRIN_PREC_BF16X3
-                                                                                                                  : cfg->precision;
+  const int prec = cfg->precision == DRIN_PREC_BF16X3_IF16 ? (int)DRIN_PREC_BF16X3 : cfg->precision;
   const bool dyn = cfg->dynamic_edges != 0;
   const bool tokens = cfg->entity_tokens > 0;
   // split-bf16 precision: the producers write bf16 hi / lo planes and the three pair-sized contractions
@@ -278,17 +261,18 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   // The image rows are read in place by their contraction (fp32, split on the fly): writing 8 KB/pair of
   // planes from the stream kernel costs it more (measured twice on one box: +1.0 ms at B = 4096) than the LDS-DMA
   // kernel gains on that GEMM (-0.35 ms).  Only the table form, which has to gather the rows anyway, writes them.
-  static const char* xi_env = getenv("DRIN_XI_PLANES");   // probe switch: image rows as planes in the gathered form too
-  const bool xi_planes = planes && (indexed || (xi_env != nullptr && xi_env[0] == '1' && cfg->feature_dtype == DRIN_FEAT_F32));
-  // DRIN_PREC_BF16X3_IF16: x_i C_i^T in one FP16 pass, image rows scaled by a power of two each (k_entity_stream hands the
-  // scales over).  For the per-pair fp32 image rows of a call that fills whole 256 x 256 grids; everything else: three passes.
-  // (the candidate-count gate of DRIN_PREC_BF16X3_I1 holds for this mode too: with freshly initialised weights the fp16 pass costs
-  //  8e-6 at N = 11, but once the weights are TRAINED the vertex -> score map steepens and 11 candidates average too little - 1.2e-4
-  //  after 200 Adam steps, outside the bar; at N = 101 the same weights give 2e-5: profiles/r4_precision_on_trained_weights.txt)
-  const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !xi_planes && cfg->feature_dtype == DRIN_FEAT_F32 &&
-                    cfg->num_candidates >= kMixedMinCandidates &&
-                    D == 768 && R == 2048 &&   // (the stream kernel's row-scale hand-over is an instantiation of the exact widths)
-                    gemm_nt_f16_scaled_fits(b->entity_image, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
+  const bool xi_planes = planes && indexed;
+  // DRIN_PREC_BF16X3_IF16: x_i C_i^T in ONE pass of the fp16 matrix instruction on single planes.  k_entity_stream, which holds every
+  // image row in registers anyway, writes it as fp16(x / 2^ceil(log2 max|x|)) - 4 KB per pair, fp32- and bf16-stored rows alike
+  // (a bf16 value is exact in fp16 under the row scale) - with the scale beside it; the folded weight is one fp16 plane under one
+  // scale (drin_prepare); the all-DMA four-phase kernel multiplies both back in its epilogue.  For gathered (per-pair) rows at the
+  // exact widths in calls of at least half a round of 256 x 256 tiles; everything else runs the three passes, bit for bit.
+  // (the candidate-count gate: with freshly initialised weights the fp16 pass costs 8e-6 at N = 11, but once the weights are
+  //  TRAINED the vertex -> score map steepens and 11 candidates average too little - 1.2e-4 after 200 Adam steps, outside the bar;
+  //  at N = 101 the same weights give 2e-5: profiles/r4_precision_on_trained_weights.txt)
+  const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !indexed && cfg->num_candidates >= kMixedMinCandidates &&
+                    D == 768 && R == 2048 &&   // (the stream kernel's fp16 hand-over is an instantiation of the exact widths)
+                    gemm_f16_planes_fits(ws + L.p_xi, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
   if (b->entity_text_cls) {
     set_error("drin_forward_prepared: entity_text_cls (text pooled ahead of time) is a form of the training entry points");
     return DRIN_E_UNSUPPORTED;
@@ -321,7 +305,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
                  const float* bias, float* y, int64_t ldy, int64_t rows, int n_out, int k) -> int {
     if (planes && (rows >= 256 || prec == DRIN_PREC_BF16X3_ALL) && (k % 32) == 0 && (ldw % 8) == 0) {
       const __bf16* hi = reinterpret_cast<const __bf16*>(pb + plane_off);
-      return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, st, hi, hi + plane_elems, false, false,
+      return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, st, hi, hi + plane_elems, false,
                                    L.splitk_floats ? ws + L.splitk : nullptr, L.splitk_floats);
     }
     return launch_gemm_nt(x, ldx, w, ldw, bias, y, ldy, rows, n_out, k, false, prec, st,
@@ -363,7 +347,6 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   float* hmfu = ws + L.hmfu;
   // pooled entity text stored as bf16 is exact in its hi plane: no lo plane, two MFMAs per tile pair
   const bool xt_exact = bf16_feat && !tokens;
-  if (phases & kPhaseStream) {
   // (1) mention-side pooling (ghmfc.py:54-60, model.py:41) and vertex-encoder Linears
   if (bf16_feat) {
     DRIN_TRY(launch_span_mean_bf16(b->mention_text, b->mention_start, b->mention_end, ws + L.span_mean, B,
@@ -406,13 +389,14 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   sa.xt_out = planes ? nullptr : ws + L.xt;
   if (planes) {
     sa.xt_hi = xt_hi;
-    sa.xt_lo = (xt_exact || one_pass) ? nullptr : xt_hi + MD;
+    sa.xt_lo = xt_exact ? nullptr : xt_hi + MD;
     if (xi_planes) {
       sa.xi_hi = xi_hi;
-      sa.xi_lo = (bf16_feat || one_pass || i1) ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
+      sa.xi_lo = bf16_feat ? nullptr : xi_hi + MR;  // bf16 image rows are their own hi plane: nothing left for lo
     }
   }
   sa.xi_scale = if16 ? ws + L.xi_scale : nullptr;
+  sa.xi_f16 = if16 ? static_cast<void*>(xi_hi) : nullptr;
   sa.e0m = ws + L.e0m;
   sa.e1m = ws + L.e1m;
   sa.s_part = ws + L.s_part;
@@ -437,8 +421,6 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   DRIN_TRY(launch_entity_stream(sa, st));
   if (L.chunks > 1)
     DRIN_TRY(launch_reduce_stream_partials(ws + L.s_part, ws + L.s_text, ws + L.s_img, ws + L.sig, B, D, R, L.chunks, st));
-  }
-  if (!(phases & kPhaseContract)) return DRIN_OK;
   // (4) layer-1 mention vertices: T = S_text W_et^T + S_img W_ei^T, then the W_h input, W_h, LN, GELU
   DRIN_TRY(lin_pair({ws + L.s_text, D, params->w_entity_text, D, P.p_wet, DD, nullptr, ws + L.tm, D, 2 * (int64_t)B, D, D},
                     {ws + L.s_img, R, params->w_entity_image, R, P.p_wei, DR, nullptr, ws + L.tm2, D, 2 * (int64_t)B, D, R}));
@@ -455,21 +437,20 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   if (planes) {
     const __bf16* ct = reinterpret_cast<const __bf16*>(pb + P.p_ctxt);
     const __bf16* ci = reinterpret_cast<const __bf16*>(pb + P.p_cimg);
-    DRIN_TRY(launch_gemm_x3_planes(xt_hi, (xt_exact || one_pass) ? nullptr : xt_hi + MD, D, ct,
-                                   one_pass ? nullptr : ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D, D, st, psk, pskf));
-    const bool xi_one = one_pass || i1;   // x_i C_i^T in one pass
-    if (xi_planes)
-      DRIN_TRY(launch_gemm_x3_planes(xi_hi, (bf16_feat || xi_one) ? nullptr : xi_hi + MR, R, ci,
-                                     xi_one ? nullptr : ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st, psk, pskf));
+    DRIN_TRY(launch_gemm_x3_planes(xt_hi, xt_exact ? nullptr : xt_hi + MD, D, ct, ct + (size_t)D * D, D, nullptr, ws + L.h_text, D, M, D,
+                                   D, st, psk, pskf));
+    if (if16)        // one fp16 pass on the plane the stream kernel wrote
+      DRIN_TRY(launch_gemm_f16_planes(xi_hi, R, pb + P.p_cimg_f16, R, ws + L.xi_scale, pb + P.cimg_f16_scale, ws + L.h_image, D, M, D, R,
+                                      st, psk, pskf));
+    else if (xi_planes)
+      DRIN_TRY(launch_gemm_x3_planes(xi_hi, bf16_feat ? nullptr : xi_hi + MR, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M,
+                                     D, R, st, psk, pskf));
     else if (bf16_feat)  // the bf16 image rows are read in place as the (only) plane of the A operand
-      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, xi_one ? nullptr : ci + (size_t)D * R, R, nullptr,
-                                     ws + L.h_image, D, M, D, R, st, psk, pskf));
-    else if (if16)
-      DRIN_TRY(launch_gemm_nt_f16_scaled(b->entity_image, R, pb + P.p_cimg_f16, R, ws + L.xi_scale, ws + L.h_image, D, M, D, R, st));
+      DRIN_TRY(launch_gemm_x3_planes(b->entity_image, nullptr, R, ci, ci + (size_t)D * R, R, nullptr, ws + L.h_image, D, M, D, R, st, psk,
+                                     pskf));
     else
-      DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci,
-                                     ci + (size_t)D * R, false, xi_one && cdiv(M, 256) * cdiv(D, 256) >= 192,
-                                     psk, pskf));
+      DRIN_TRY(launch_gemm_nt_bf16x3(b->entity_image, R, pb + P.c_img, R, nullptr, ws + L.h_image, D, M, D, R, st, ci, ci + (size_t)D * R,
+                                     false, psk, pskf));
   } else {
     const float* x_t = tokens ? ws + L.xt : b->entity_text;
     DRIN_TRY(launch_gemm_nt(x_t, D, pb + P.c_txt, D, nullptr, ws + L.h_text, D, M, D, D, false, prec, st));
@@ -500,7 +481,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   pa.et1 = planes ? nullptr : ws + L.et1;
   if (planes) {
     pa.et1_hi = e1_hi;
-    pa.et1_lo = one_pass ? nullptr : e1_hi + MD;
+    pa.et1_lo = e1_hi + MD;
   }
   pa.s2_part = ws + L.s2_part;
   pa.B = B;
@@ -519,8 +500,7 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   float* h2 = ws + L.h_text;
   if (planes) {
     const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
-    DRIN_TRY(launch_gemm_x3_planes(e1_hi, one_pass ? nullptr : e1_hi + MD, D, w2, one_pass ? nullptr : w2 + (size_t)D * D, D,
-                                   nullptr, h2, D, M, D, D, st, psk, pskf));
+    DRIN_TRY(launch_gemm_x3_planes(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, nullptr, h2, D, M, D, D, st, psk, pskf));
   } else {
     DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
   }
@@ -544,212 +524,9 @@ static int forward_prepared_phases(const drin_config* cfg, const drin_batch* b, 
   return launch_pair_final(fa, st);
 }
 
-// ---- the two phases side by side on disjoint CU sets ------------------------------------------------------------------
-// k_entity_stream is HBM-bound, the contractions MFMA-bound; on the same CUs they do not overlap (the GEMM's tile loads queue
-// behind the stream kernel's ~100 KB per CU in flight), on DISJOINT CU sets they do, and a pass over 3 KB rows needs far
-// fewer than 256 CUs to keep HBM busy (tools/probes/partition_probe.hip: 96 CUs 4.6 TB/s, 128 CUs 5.6, 160 CUs 6.2 = what
-// all 256 reach).  A large batch is therefore cut into chunks of mentions; chunk c + 1's stream phase runs on the first
-// `stream_cus` CUs while chunk c's contraction phase runs on the others (two streams created with
-// hipExtStreamCreateWithCUMask, forked from and joined to the caller's stream by events).  Each chunk has its own workspace,
-// so no buffer is shared between chunks in flight.  A mention's score depends on its chunk's size only through the tile /
-// split-K choices of the mention-sized products (all inside the parity bar, and a deterministic function of the batch size).
-struct PipePlan {
-  int chunks = 1, chunk_mentions = 0, stream_cus = 0;
-};
-
-static std::atomic<int> g_pipe_stream_cus{-1}, g_pipe_chunk_pairs{-1};   // -1: environment / default
-
-static PipePlan pipe_plan(const drin_config& c) {
-  PipePlan p;
-  p.chunk_mentions = c.batch;
-  int cus = g_pipe_stream_cus.load(std::memory_order_relaxed);
-  int chunk_pairs = g_pipe_chunk_pairs.load(std::memory_order_relaxed);
-  if (cus < 0 || chunk_pairs < 0) {
-    // DRIN_PIPE = "off" | "<stream CUs>" | "<stream CUs>:<pairs per chunk>"
-    static const char* env = getenv("DRIN_PIPE");
-    int e_cus = kPipeDefaultStreamCus, e_pairs = kPipeDefaultChunkPairs;
-    if (env != nullptr && env[0] != 0) {
-      if (env[0] == 'o') e_cus = 0;
-      else {
-        e_cus = atoi(env);
-        const char* colon = strchr(env, ':');
-        if (colon) e_pairs = atoi(colon + 1);
-      }
-    }
-    if (cus < 0) cus = e_cus;
-    if (chunk_pairs < 0) chunk_pairs = e_pairs;
-  }
-  const bool planes = (c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16X3_I1 ||
-                       c.precision == DRIN_PREC_BF16X3_IF16) &&
-                      c.embed_dim % 32 == 0 && c.image_dim % 32 == 0;
-  if (cus <= 0 || cus >= 256 || chunk_pairs < 4096 || !planes) return p;
-  int per = (int)std::max<int64_t>(1, chunk_pairs / c.num_candidates);
-  if (per >= 256) per -= per % 256;   // whole 256-row tiles of the mention-sized products
-  const int n = (int)cdiv(c.batch, per);
-  if (n < 4) return p;                // fill and drain of a short pipeline cost what the overlap buys
-  p.chunks = n;
-  p.chunk_mentions = per;
-  p.stream_cus = cus;
-  return p;
-}
-
-struct PipeStreams {
-  hipStream_t a = nullptr, b = nullptr;
-  hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
-  std::vector<hipEvent_t> done;
-  int cus = 0;
-};
-static std::mutex g_pipe_mutex;
-static PipeStreams g_pipe[16][2];   // per device: the configured split, and one spare for a second setting (probes)
-
-static int pipe_streams(int stream_cus, int chunks, PipeStreams** out) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (dev < 0 || dev >= 16) {
-    set_error("pipelined forward: device %d outside the 16 per-device stream slots", dev);
-    return DRIN_E_UNSUPPORTED;
-  }
-  std::lock_guard<std::mutex> lock(g_pipe_mutex);
-  PipeStreams* ps = nullptr;
-  for (PipeStreams& q : g_pipe[dev])
-    if (q.cus == stream_cus || q.cus == 0) {
-      ps = &q;
-      break;
-    }
-  if (!ps) {  // a third setting in one process: rebuild the spare
-    ps = &g_pipe[dev][1];
-    (void)hipStreamSynchronize(ps->a);
-    (void)hipStreamSynchronize(ps->b);
-    (void)hipStreamDestroy(ps->a);
-    (void)hipStreamDestroy(ps->b);
-    ps->a = ps->b = nullptr;
-    ps->cus = 0;
-  }
-  if (ps->cus == 0) {
-    int total = 0;
-    hipError_t e = hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
-    if (total > 256 || stream_cus >= total) {
-      set_error("pipelined forward: %d stream CUs of %d", stream_cus, total);
-      return DRIN_E_UNSUPPORTED;
-    }
-    // mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs): a prefix of the bits
-    // is spread evenly over the eight XCDs and their L2s
-    uint32_t ma[8] = {0}, mb[8] = {0};
-    for (int c = 0; c < total; ++c) (c < stream_cus ? ma : mb)[c / 32] |= 1u << (c % 32);
-    e = hipExtStreamCreateWithCUMask(&ps->a, 8, ma);
-    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ps->b, 8, mb);
-    if (e != hipSuccess) return hip_fail(e, "hipExtStreamCreateWithCUMask");
-    for (hipEvent_t* ev : {&ps->fork, &ps->join_a, &ps->join_b})
-      if (*ev == nullptr && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
-        return hip_fail(e, "hipEventCreate(pipeline)");
-    ps->cus = stream_cus;
-  }
-  while ((int)ps->done.size() < chunks) {
-    hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) return hip_fail(e, "hipEventCreate(pipeline)");
-    ps->done.push_back(ev);
-  }
-  *out = ps;
-  return DRIN_OK;
-}
-
-// mentions [m0, m0 + count) of a batch
-static drin_batch slice_batch(const drin_config& c, const drin_batch& b, int64_t m0) {
-  const size_t es = c.feature_dtype == DRIN_FEAT_BF16 ? 2 : 4;
-  auto feat = [&](const float* p, int64_t elems) -> const float* {
-    return p ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (size_t)elems * es) : nullptr;
-  };
-  auto inner = [](int v) { return (int64_t)(v > 1 ? v : 1); };
-  const int64_t N = c.num_candidates, D = c.embed_dim, R = c.image_dim, T = c.entity_tokens;
-  drin_batch s = b;
-  s.mention_text = feat(b.mention_text, m0 * c.mention_tokens * D);
-  s.mention_start = b.mention_start ? b.mention_start + m0 : nullptr;
-  s.mention_end = b.mention_end ? b.mention_end + m0 : nullptr;
-  s.mention_image = feat(b.mention_image, m0 * c.image_regions * R);
-  s.mention_object = feat(b.mention_object, m0 * c.mention_objects * inner(c.mention_object_inner) * R);
-  s.mention_object_score = b.mention_object_score ? b.mention_object_score + m0 * c.mention_objects : nullptr;
-  s.miet_similarity = b.miet_similarity ? b.miet_similarity + m0 * N : nullptr;
-  s.mtei_similarity = b.mtei_similarity ? b.mtei_similarity + m0 * N : nullptr;
-  if (b.entity_index) {   // the entity tensors are tables: only the index moves
-    s.entity_index = b.entity_index + m0 * N;
-    return s;
-  }
-  s.entity_text = feat(b.entity_text, T > 0 ? m0 * N * T * D : m0 * N * D);
-  s.entity_text_mask = (b.entity_text_mask && T > 0) ? b.entity_text_mask + m0 * N * T : b.entity_text_mask;
-  s.entity_image = feat(b.entity_image, m0 * N * inner(c.entity_image_inner) * R);
-  s.entity_object = feat(b.entity_object, m0 * N * c.entity_objects * inner(c.entity_object_inner) * R);
-  s.entity_object_score = b.entity_object_score ? b.entity_object_score + m0 * N * c.entity_objects : nullptr;
-  return s;
-}
-
-static size_t chunk_workspace_floats(const drin_config& c, const PipePlan& plan) {
-  drin_config cc = c;
-  cc.batch = plan.chunk_mentions;
-  FusedLayout L;
-  L.build(cc);
-  return L.total;
-}
-
-static int forward_prepared_pipelined(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
-                                      void* workspace, float* scores, hipStream_t st, const PipePlan& plan) {
-  PipeStreams* ps = nullptr;
-  DRIN_TRY(pipe_streams(plan.stream_cus, plan.chunks, &ps));
-  const size_t chunk_floats = chunk_workspace_floats(*cfg, plan);
-  hipError_t e = hipEventRecord(ps->fork, st);
-  if (e == hipSuccess) e = hipStreamWaitEvent(ps->a, ps->fork, 0);
-  if (e == hipSuccess) e = hipStreamWaitEvent(ps->b, ps->fork, 0);
-  if (e != hipSuccess) return hip_fail(e, "pipeline fork");
-  int rc = DRIN_OK;
-  for (int c = 0; c < plan.chunks && rc == DRIN_OK; ++c) {
-    const int64_t m0 = (int64_t)c * plan.chunk_mentions;
-    drin_config cc = *cfg;
-    cc.batch = (int)std::min<int64_t>(plan.chunk_mentions, cfg->batch - m0);
-    const drin_batch sb = slice_batch(*cfg, *b, m0);
-    float* ws = (float*)workspace + (size_t)c * chunk_floats;
-    float* sc = scores + m0 * cfg->num_candidates;
-    rc = forward_prepared_phases(&cc, &sb, params, prepared, ws, sc, ps->a, kPhaseStream);
-    if (rc != DRIN_OK) break;
-    e = hipEventRecord(ps->done[c], ps->a);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ps->b, ps->done[c], 0);
-    if (e != hipSuccess) {
-      rc = hip_fail(e, "pipeline hand-over");
-      break;
-    }
-    rc = forward_prepared_phases(&cc, &sb, params, prepared, ws, sc, ps->b, kPhaseContract);
-  }
-  // join in every case: the caller's stream never runs ahead of work already queued on the side streams
-  e = hipEventRecord(ps->join_a, ps->a);
-  if (e == hipSuccess) e = hipEventRecord(ps->join_b, ps->b);
-  if (e == hipSuccess) e = hipStreamWaitEvent(st, ps->join_a, 0);
-  if (e == hipSuccess) e = hipStreamWaitEvent(st, ps->join_b, 0);
-  if (e != hipSuccess && rc == DRIN_OK) rc = hip_fail(e, "pipeline join");
-  return rc;
-}
-
 }  // namespace drin
 
 extern "C" {
-
-int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs) {
-  if (stream_cus >= 256) {
-    set_error("drin_set_pipeline: stream_cus=%d (0 = one stream, -1 = default, else < 256)", stream_cus);
-    return DRIN_E_SHAPE;
-  }
-  g_pipe_stream_cus.store(stream_cus < 0 ? -1 : stream_cus);
-  g_pipe_chunk_pairs.store(chunk_pairs < 0 ? -1 : chunk_pairs);
-  return DRIN_OK;
-}
-
-int drin_set_weight_gradient_passes(int32_t passes) {
-  if (passes != 1 && passes != 3 && passes >= 0) {
-    set_error("drin_set_weight_gradient_passes: %d (1 = one bf16 pass, 3 = the split product, -1 = default)", passes);
-    return DRIN_E_SHAPE;
-  }
-  set_weight_gradient_passes(passes < 0 ? -1 : passes);
-  return DRIN_OK;
-}
 
 int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached) {
   if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
@@ -761,8 +538,6 @@ int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached) {
 
 size_t drin_fused_workspace_bytes(const drin_config* cfg) {
   if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
-  const PipePlan plan = pipe_plan(*cfg);
-  if (plan.chunks > 1) return (size_t)plan.chunks * chunk_workspace_floats(*cfg, plan) * sizeof(float);
   FusedLayout L;
   L.build(*cfg);
   return L.total * sizeof(float);
@@ -777,22 +552,14 @@ int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const dri
     set_error("drin_forward_prepared: NULL argument");
     return DRIN_E_NULL;
   }
-  hipStream_t st = (hipStream_t)stream;
-  PipePlan plan = pipe_plan(*cfg);
-  if (plan.chunks > 1) {   // a stream being captured into a graph stays on the one-stream schedule
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) plan = PipePlan();
-  }
   FusedLayout L;
   L.build(*cfg);
-  const size_t need = plan.chunks > 1 ? (size_t)plan.chunks * chunk_workspace_floats(*cfg, plan) : L.total;
-  if (workspace_bytes < need * sizeof(float) || !aligned16(workspace)) {
+  if (workspace_bytes < L.total * sizeof(float) || !aligned16(workspace)) {
     set_error("drin_forward_prepared: workspace has %zu bytes (needs %zu) or is not 16-byte aligned", workspace_bytes,
-              need * sizeof(float));
+              L.total * sizeof(float));
     return DRIN_E_WORKSPACE;
   }
-  if (plan.chunks > 1) return forward_prepared_pipelined(cfg, b, params, prepared, workspace, scores, st, plan);
-  return forward_prepared_phases(cfg, b, params, prepared, workspace, scores, st, kPhaseAll);
+  return forward_prepared_on_stream(cfg, b, params, prepared, workspace, scores, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -18,8 +18,8 @@ namespace drin {
 // EXACT: D = 256 DV and R = 256 RV exactly (768 / 2048): the column guards of the row helpers fold away
 // FT: storage type of the feature tensors (float, or __bf16 with drin_config.feature_dtype = DRIN_FEAT_BF16 - half
 // the bytes of this HBM-bound pass; all arithmetic stays fp32)
-// XSCALE: also hand over a power-of-two scale per image row (DRIN_PREC_BF16X3_IF16) - a separate instantiation, so that the
-// code (and the register allocation: 230 VGPRs) of every other call is what it was
+// XSCALE: also hand over the image row as ONE fp16 plane under a power-of-two scale per row (DRIN_PREC_BF16X3_IF16) - a separate
+// instantiation, so that the code (and the register allocation: 230 VGPRs) of every other call is what it was
 #ifdef DRIN_STREAM_STAMPS   // probe build (tools/stream_stamps_probe.py): cycle stamps of 64 workgroups, wave 0
 __device__ unsigned long long g_stream_stamps[64 * 8];
 #define STREAM_STAMP(i)                                                                                        \
@@ -255,13 +255,15 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     const Row<RV> xi = load_r(f_image + e * R);
     if (a.xi_hi) store_row_planes<RV, RP>(a.xi_hi, a.xi_lo, p * R, xi, lane, R4);
     if constexpr (XSCALE) {
-      // DRIN_PREC_BF16X3_IF16: the power of two that brings this row's largest |x| into [0.5, 1] - the contraction kernel
-      // divides the row by it (exact) before rounding to fp16 and multiplies its output row back
+      // DRIN_PREC_BF16X3_IF16: the power of two that brings this row's largest |x| into [0.5, 1] (its reciprocal a normal number
+      // whatever the row: cache_field_scale) - the row leaves as fp16(x / scale), 4 KB instead of the 8 KB the contraction would
+      // read again as fp32, and the contraction's epilogue multiplies its output row back (exact both ways)
       float m = 0.f;
 #pragma unroll
       for (int j = 0; j < RV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(xi.v[j].x), fabsf(xi.v[j].y)), fmaxf(fabsf(xi.v[j].z), fabsf(xi.v[j].w))));
-      m = wave_max(m);
-      if (lane == 0) a.xi_scale[p] = pow2_at_least(m);
+      const float sc = cache_field_scale(wave_max(m));
+      if (lane == 0) a.xi_scale[p] = sc;
+      store_row_f16_scaled<RV, RP>(a.xi_f16, p * R, xi, 1.0f / sc, lane);
     }
     const float e_tt = tt * a.mask[0];
     const float e_ti = (a.mtei[p] / a.clip) * a.mask[1];
@@ -384,11 +386,16 @@ static int launch_stream_ft(const StreamArgs& a, hipStream_t st) {
 
 template <int DV, int RV, bool TOKENS, bool EXACT>
 static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
-  if (a.xi_scale != nullptr) {   // fp32 features at the exact widths only (fused_forward.hip decides)
+  if (a.xi_scale != nullptr) {   // the exact widths only (fused_forward.hip decides)
     if constexpr (EXACT && DV == 3) {
-      if (!a.bf16_features) return launch_stream_ft<DV, RV, TOKENS, EXACT, float, true>(a, st);
+      if (a.xi_f16 == nullptr) {
+        set_error("entity_stream: xi_scale without xi_f16");
+        return DRIN_E_NULL;
+      }
+      return a.bf16_features ? launch_stream_ft<DV, RV, TOKENS, EXACT, __bf16, true>(a, st)
+                             : launch_stream_ft<DV, RV, TOKENS, EXACT, float, true>(a, st);
     }
-    set_error("entity_stream: row scales are built for fp32 features at D = 768, R = 2048");
+    set_error("entity_stream: the scaled fp16 image plane is built for D = 768, R = 2048");
     return DRIN_E_UNSUPPORTED;
   }
   return a.bf16_features ? launch_stream_ft<DV, RV, TOKENS, EXACT, __bf16>(a, st)

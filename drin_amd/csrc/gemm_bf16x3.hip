@@ -28,17 +28,11 @@ namespace drin {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace x3 {
 
 constexpr int BK = 32;
-#ifdef DRIN_X3_DRAIN
-constexpr bool kDrainEveryBlock = true;    // probe build (A/B): __syncthreads() at every K-block boundary, as up to round 3
-#else
-constexpr bool kDrainEveryBlock = false;
-#endif
 constexpr unsigned kCUs = 256;  // MI355X: the tail split below only changes how the last round of tiles is dealt
 
 // MFMA shape v_mfma_f32_16x16x32_bf16 (one k-step per K-block; +5 % over 32x32x16 at the clock the chip
@@ -52,16 +46,13 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) { split
 // ROWS x 32 floats staged by THREADS threads: thread t loads float4 #(t & 7) of rows (t >> 3) + (THREADS/8) i.
 // Loads are unconditional (no exec-masked branches in the K loop): rows past the end are clamped to the
 // last row - their products land in output rows / columns that are never stored - and K % 32 == 0.
-// KSUB = 2 (the one-pass kernel): a K-block is 64 floats per row - two sub-blocks of 32, loaded together (v, v2) and
-// stored ROUNDED to bf16 into what the split product calls the hi and the lo plane (see k_gemm_bf16x3 ONE_PASS).
-template <int ROWS, int THREADS, int KSUB = 1>
+template <int ROWS, int THREADS>
 struct Stager {
   static constexpr int RPP = THREADS / 8;  // rows per pass
   static constexpr int PASSES = (ROWS + RPP - 1) / RPP;   // (a last, partly used pass: its surplus rows are loaded clamped and not stored)
   static constexpr bool RAGGED = (ROWS % RPP) != 0;
   const float* p[PASSES];
   float4 v[PASSES];
-  float4 v2[KSUB == 2 ? PASSES : 1];
 
   // (index: row m of the operand is row index[m] of a table - table-form training gathers the vertex-encoder inputs here)
   __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
@@ -78,41 +69,6 @@ struct Stager {
   __device__ __forceinline__ void load(int k0) {
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) v[i] = ld4(p[i] + k0);
-    if (KSUB == 2) {
-#pragma unroll
-      for (int i = 0; i < PASSES; ++i) v2[i] = ld4(p[i] + k0 + BK);
-    }
-  }
-  // one FP16 pass: as store_rounded, every row multiplied by its (power-of-two: exact) factor first and rounded to fp16
-  __device__ __forceinline__ void store_f16(char* __restrict__ plane0, char* __restrict__ plane1, const float (&inv)[PASSES]) const {
-    const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-      if (RAGGED && r + RPP * i >= ROWS) continue;
-      const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
-      f16x4 a, b;
-      const float4 x = v[i], y = v2[KSUB == 2 ? i : 0];
-      const float f = inv[i];
-      a[0] = (_Float16)(x.x * f), a[1] = (_Float16)(x.y * f), a[2] = (_Float16)(x.z * f), a[3] = (_Float16)(x.w * f);
-      b[0] = (_Float16)(y.x * f), b[1] = (_Float16)(y.y * f), b[2] = (_Float16)(y.z * f), b[3] = (_Float16)(y.w * f);
-      *reinterpret_cast<f16x4*>(plane0 + off) = a;
-      *reinterpret_cast<f16x4*>(plane1 + off) = b;
-    }
-  }
-  // one-pass form: sub-block 0 rounded into the first plane, sub-block 1 into the second
-  __device__ __forceinline__ void store_rounded(char* __restrict__ plane0, char* __restrict__ plane1) const {
-    const int t = threadIdx.x, c4 = t & 7, r = t >> 3;
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-      if (RAGGED && r + RPP * i >= ROWS) continue;
-      const int off = swz(r + RPP * i, c4 >> 1) + ((c4 & 1) << 3);
-      bf16x4 a, b;
-      const float4 x = v[i], y = v2[KSUB == 2 ? i : 0];
-      a[0] = (__bf16)x.x, a[1] = (__bf16)x.y, a[2] = (__bf16)x.z, a[3] = (__bf16)x.w;
-      b[0] = (__bf16)y.x, b[1] = (__bf16)y.y, b[2] = (__bf16)y.z, b[3] = (__bf16)y.w;
-      *reinterpret_cast<bf16x4*>(plane0 + off) = a;
-      *reinterpret_cast<bf16x4*>(plane1 + off) = b;
-    }
   }
   // registers -> (hi plane, lo plane): float4 #c4 of a row is the 8-byte half (c4 & 1) of chunk c4 >> 1
   template <bool WITH_LO = true>
@@ -154,15 +110,13 @@ struct PlaneDma {
       lds_off[i] = plane * ROWS * 64 + pr * 1024;
     }
   }
-  // (KB_BYTES: bytes of one plane row a K-block advances by - 64, or 128 in the one-pass kernel, whose two "planes" are the
-  //  two 32-wide sub-blocks of a 64-wide K-block of the ONE weight plane: init(hi, hi + 32, ...))
-  template <bool WITH_LO = true, int KB_BYTES = BK * 2>
+  template <bool WITH_LO = true>
   __device__ __forceinline__ void issue(char* planes_base, int kb) const {
     const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       if (!WITH_LO && (wave * PIECES + i) >= ROWS / 16) continue;  // second half of the pieces is the lo plane
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)kb * KB_BYTES), (lptr_t)(planes_base + lds_off[i]), 16,
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)kb * (BK * 2)), (lptr_t)(planes_base + lds_off[i]), 16,
                                        0, 0);
     }
   }
@@ -177,27 +131,17 @@ struct Cfg {
   static constexpr int MI = BM / WM / 16, NI = BN / WN / 16;  // 16 x 16 MFMA tiles per wave
 };
 
-// ONE_PASS (DRIN_PREC_BF16, and the image contraction of DRIN_PREC_BF16X3_I1): operands rounded to bf16, one MFMA pass.  A
-// K-block is then 64 wide: its two 32-wide sub-blocks take the LDS planes the split product gives to hi and lo, and a
-// 16 x 16 tile takes two MFMAs per K-block (sub-block 0, sub-block 1 - the same k order as 32-wide blocks, the same bits).
-// With 32-wide blocks an iteration held a third of the split product's MFMAs but the same barrier and the same one-block
-// prefetch distance: ~1 000 cycles of matrix work to hide ~3 000 of HBM latency behind (x_i C_i^T: 2.7 ms against 3.9 in
-// three passes); at 64 the iteration is two thirds of the split product's, with twice the bytes in flight.
 // Tail split: the last, partly filled round of workgroups (tiles [full, tiles), fewer than half the CUs) is dealt as
 // `ksplit` work items per tile, each over 1 / ksplit of K.  Part 0 stores to C as usual, the others store raw
 // accumulators to `tail` ([tile - full][ksplit - 1][BM][BN]) and k_tail_add folds them in afterwards, in order.
 // (B = 512 training: 606 tiles on 256 CUs = 2.37 rounds ran as 3; with the 94 tail tiles halved, as 2.5:
 //  same-box A/B of the whole step 8.55 -> 8.44 ms.)
-// F16 (with ONE_PASS; DRIN_PREC_BF16X3_IF16): the one pass runs on v_mfma_f32_16x16x32_f16 - 11-bit operands.  w_hi is then the
-// weight as an fp16 plane; row m of A is multiplied by 1 / a_scale[m] (a power of two: exact) on its way into LDS and output row
-// m by a_scale[m] in the epilogue, so that fp16's range never matters.
-template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false, bool F16 = false>
+template <int BM, int BN, int WM, int WN, bool W_PLANES>
 __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
                   const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
                   int64_t ldc, int64_t M, int N, int K, int accumulate, unsigned col_tiles, unsigned full, int ksplit,
-                  float* __restrict__ tail, const int64_t* __restrict__ a_index, const float* __restrict__ a_scale) {
-  static_assert(!F16 || ONE_PASS, "the fp16 form is a one-pass form");
+                  float* __restrict__ tail, const int64_t* __restrict__ a_index) {
   using G = Cfg<BM, BN, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile order (as in gemm_x3_planes.hip): workgroups are dealt round-robin over the 8 XCDs, each with
@@ -233,8 +177,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
       W += k0;
     }
   }
-  static_assert(!ONE_PASS || W_PLANES, "the one-pass kernel streams its weight plane by LDS-DMA");
-  constexpr int KSTEP = ONE_PASS ? 2 * BK : BK;   // floats of K per iteration
+  constexpr int KSTEP = BK;   // floats of K per iteration
   const int nkb = K / KSTEP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;
@@ -248,35 +191,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
 
-  Stager<BM, G::THREADS, ONE_PASS ? 2 : 1> sa;
+  Stager<BM, G::THREADS> sa;
   Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;  // one dummy pass when the weights come by DMA
   PlaneDma<BN, WM * WN> dma;
   sa.init(A, lda, m0, M, a_index);
   if (W_PLANES)
-    dma.init(w_hi, ONE_PASS ? w_hi + BK : w_lo, ldw, n0, N);
+    dma.init(w_hi, w_lo, ldw, n0, N);
   else
     sb.init(W, ldw, n0, N);
-  float inv_s[decltype(sa)::PASSES];
-  if (F16) {
-#pragma unroll
-    for (int i = 0; i < decltype(sa)::PASSES; ++i) {
-      int64_t row = m0 + (threadIdx.x >> 3) + decltype(sa)::RPP * i;
-      row = row < M ? row : M - 1;
-      inv_s[i] = 1.0f / a_scale[row];
-    }
-  }
-  auto stage_a = [&](char* buf) {
-    if (F16)
-      sa.store_f16(buf, buf + G::A_PLANE, inv_s);
-    else if (ONE_PASS)
-      sa.store_rounded(buf, buf + G::A_PLANE);
-    else
-      sa.template store<true>(buf, buf + G::A_PLANE);
-  };
+  auto stage_a = [&](char* buf) { sa.template store<true>(buf, buf + G::A_PLANE); };
 
   sa.load(0);
   if (W_PLANES)
-    dma.template issue<true, KSTEP * 2>(smem + 2 * G::A_PLANE, 0);
+    dma.template issue<true>(smem + 2 * G::A_PLANE, 0);
   else
     sb.load(0);
   stage_a(smem);
@@ -309,17 +236,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
         // the WEIGHT fragment is the first operand: a lane's four accumulator registers of a 16 x 16 tile are then four
         // consecutive output COLUMNS of one row (row lane & 15, columns 4 (lane >> 4) + v) - the epilogue stores 16 bytes
         // per lane instead of four scattered dwords (as in gemm_x3_planes.hip, where it took the epilogue from 37 k to 24 k cycles)
-        if (!ONE_PASS) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
-        } else if (!F16) {   // (ah, bh): k sub-block 0 of the 64-wide block, (al, bl): sub-block 1
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], al, acc[i][j], 0, 0, 0);
-        } else {             // the same two sub-blocks as fp16 fragments (the planes hold fp16 bit patterns)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[j]), __builtin_bit_cast(f16x8, ah), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl[j]), __builtin_bit_cast(f16x8, al), acc[i][j], 0, 0, 0);
-        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -335,7 +254,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
     char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
     const bool more = kb + 1 < nkb;
 #ifndef DRIN_ABLATE_NO_LOADS   // timing ablations only (wrong results): the K-loop without its global traffic / without its MFMAs
-    if (W_PLANES && more) dma.template issue<true, KSTEP * 2>(nb + 2 * G::A_PLANE, kb + 1);
+    if (W_PLANES && more) dma.template issue<true>(nb + 2 * G::A_PLANE, kb + 1);
 #endif
     load_b(buf);
 #ifndef DRIN_ABLATE_NO_MFMA
@@ -346,10 +265,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
       if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
 #ifndef DRIN_ABLATE_NO_LOADS
       if (kb + 2 < nkb) {
-        __builtin_amdgcn_sched_barrier(0);   // (the counted wait at the end of the iteration relies on these being the newest)
         sa.load((kb + 2) * KSTEP);
         if (!W_PLANES) sb.load((kb + 2) * KSTEP);
-        __builtin_amdgcn_sched_barrier(0);
       }
 #endif
     }
@@ -358,24 +275,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
 #else
     row_tiles(buf, 0, 1);
 #endif
-    // End of the iteration: the stage stores (LDS) and the weight DMA of block kb + 1 must have landed before anybody reads
-    // the other buffer - the register loads of block kb + 2, issued BEHIND that DMA, need not.  __syncthreads() would drain
-    // them too (its fence waits vmcnt(0)): half an iteration to cover an HBM miss, every iteration.  A counted wait keeps
-    // the INFLIGHT newest vector-memory operations - exactly those loads - outstanding across the raw barrier; the compiler's
-    // own wait in front of their first use (the next iteration's stage store) retires them.  kDrainEveryBlock: the old form.
-    if (kDrainEveryBlock || !ONE_PASS) {   // (three passes: same-box A/B inside 1 % either way - profiles/r4_one_pass_ab.txt - kept as it was)
-      __syncthreads();
-    } else {
-      constexpr int INFLIGHT = decltype(sa)::PASSES * (ONE_PASS ? 2 : 1) + (W_PLANES ? 0 : decltype(sb)::PASSES);
-      static_assert(INFLIGHT <= 60, "vmcnt is a 6-bit counter");
-      __builtin_amdgcn_sched_barrier(0);
-      if (kb + 2 < nkb)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    // (a counted wait that keeps the register loads of block kb + 2 outstanding across a raw barrier measured inside 1 % of this
+    //  either way for the three-pass product - profiles/r4_one_pass_ab.txt)
+    __syncthreads();
   }
 
   if (kpart > 0) {  // raw partial tile into the tail scratch
@@ -393,15 +295,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
   for (int i = 0; i < G::MI; ++i) {
     const int64_t row = m0 + wm * (BM / WM) + i * 16 + r;  // C/D of a 16 x 16 tile: row lane & 15, columns 4 (lane >> 4) + v
     if (row >= M) continue;
-    const float rs = F16 ? a_scale[row] : 1.0f;
 #pragma unroll
     for (int j = 0; j < G::NI; ++j) {
       const int col = n0 + wn * (BN / WN) + j * 16 + c * 4;
       float* dst = C + row * ldc + col;
-      if (F16) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[i][j][v] *= rs;
-      }
       if (vec_ok && col + 3 < N) {
         float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         if (bias != nullptr) o = o + ld4(bias + col);
@@ -430,17 +327,17 @@ __global__ void __launch_bounds__(BN) k_tail_add(const float* __restrict__ tail,
   C[row * ldc + col] = s;
 }
 
-template <int BM, int BN, int WM, int WN, bool W_PLANES, bool ONE_PASS = false, bool F16 = false>
+template <int BM, int BN, int WM, int WN, bool W_PLANES>
 static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
                   const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate,
-                  float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr, const float* a_scale = nullptr) {
+                  float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr) {
   using G = Cfg<BM, BN, WM, WN>;
   const int64_t mt = cdiv(M, BM), nt = cdiv(N, BN);
   if (mt * nt > (int64_t)1 << 30) {
     set_error("gemm_bf16x3: %lld tiles exceed the grid limit; split the batch", (long long)(mt * nt));
     return DRIN_E_SHAPE;
   }
-  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES, ONE_PASS, F16>;
+  auto kern = k_gemm_bf16x3<BM, BN, WM, WN, W_PLANES>;
   static DynLdsOptIn opt_in;  // one per template instantiation
   DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), G::LDS_BYTES, "hipFuncSetAttribute(gemm_bf16x3)"));
   // tail split (one workgroup per CU tiles only): the last round holds `frac` tiles; split K so that it fills the chip
@@ -472,228 +369,13 @@ static int launch(const float* x, int64_t ldx, const float* w, const void* w_hi,
   const unsigned items = full + (tiles - full) * (unsigned)ksplit;
   KernelTimer timer(DRIN_KC_GEMM_X3, st);
   hipLaunchKernelGGL(kern, dim3(items), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
-                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail, a_index, a_scale);
+                     (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, full, ksplit, tail, a_index);
   DRIN_CHECK_LAUNCH("k_gemm_bf16x3");
   if (ksplit > 1) {
     hipLaunchKernelGGL((k_tail_add<BM, BN>), dim3(BM, tiles - full), dim3(BN), 0, st, tail, y, ldy, M, N, (unsigned)nt,
                        full, ksplit);
     DRIN_CHECK_LAUNCH("k_tail_add");
   }
-  return DRIN_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Stream-K form of the same product for problems whose tiles do not fill the chip in whole rounds (the B = 64 training
-// step: 6 464 / 12 928 rows x 768 columns are 0.6 / 1.2 rounds of 128 x 256 tiles on 256 CUs; as 64 x 128 tiles they fill it
-// but run at the L2 -> LDS bandwidth such a small tile needs: SQ counters 0.30 of the cycles with an MFMA executing, 0.51 of
-// the wave time parked - profiles/r3_mfma_pmc.json).  The work is the sequence of (tile, K-block) units, tile-major; the
-// launch has exactly as many workgroups as the chip keeps resident and workgroup w walks units [w U / G, (w + 1) U / G):
-// every CU gets the same number of K-blocks whatever the tile count.  A tile that lies inside one workgroup's range is
-// stored by it as usual; a tile cut by a range boundary has EVERY one of its segments stored raw to the scratch
-// (slot 2 w for a segment that starts inside the tile, 2 w + 1 for one that starts at its first K-block) and k_sk_fixup adds
-// the segments in workgroup order, with the bias: no atomics, the same bits every run.
-template <int BM, int BN, int WM, int WN, bool W_PLANES>
-__global__ void __launch_bounds__(64 * WM * WN, (64 * WM * WN) / 256)
-    k_gemm_bf16x3_sk(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const __bf16* __restrict__ w_hi,
-                     const __bf16* __restrict__ w_lo, int64_t ldw, const float* __restrict__ bias, float* __restrict__ C,
-                     int64_t ldc, int64_t M, int N, int K, int accumulate, unsigned col_tiles, unsigned tiles,
-                     float* __restrict__ partial, const int64_t* __restrict__ a_index) {
-  using G = Cfg<BM, BN, WM, WN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned nkb = (unsigned)(K / BK);
-  const uint64_t U = (uint64_t)tiles * nkb;
-  // XCD-contiguous ranges: consecutive tiles (column index fastest) share their A rows through one L2
-  unsigned w = blockIdx.x;
-  {
-    const unsigned total = gridDim.x, xcd = w & 7, k = w >> 3, q = total >> 3, rem = total & 7;
-    w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
-  }
-  uint64_t u = (uint64_t)w * U / gridDim.x;
-  const uint64_t u_end = (uint64_t)(w + 1) * U / gridDim.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 15, c = lane >> 4;
-
-  while (u < u_end) {
-    const unsigned t = (unsigned)(u / nkb);
-    const int kb0 = (int)(u - (uint64_t)t * nkb);
-    const int len = (int)((uint64_t)(nkb - kb0) < u_end - u ? (uint64_t)(nkb - kb0) : u_end - u);
-    const int kb1 = kb0 + len;
-    u += len;
-    const int n0 = (int)(t % col_tiles) * BN;
-    const int64_t m0 = (int64_t)(t / col_tiles) * BM;
-
-    f32x4 acc[G::MI][G::NI];
-#pragma unroll
-    for (int i = 0; i < G::MI; ++i)
-#pragma unroll
-      for (int j = 0; j < G::NI; ++j)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
-
-    Stager<BM, G::THREADS> sa;
-    Stager<W_PLANES ? G::THREADS / 8 : BN, G::THREADS> sb;
-    PlaneDma<BN, WM * WN> dma;
-    sa.init(A, lda, m0, M, a_index);
-    if (W_PLANES)
-      dma.init(w_hi, w_lo, ldw, n0, N);
-    else
-      sb.init(W, ldw, n0, N);
-    sa.load(kb0 * BK);
-    if (W_PLANES)
-      dma.issue(smem + 2 * G::A_PLANE, kb0);
-    else
-      sb.load(kb0 * BK);
-    sa.store(smem, smem + G::A_PLANE);
-    if (!W_PLANES) sb.store(smem + 2 * G::A_PLANE, smem + 2 * G::A_PLANE + G::B_PLANE);
-    if (len > 1) {
-      sa.load((kb0 + 1) * BK);
-      if (!W_PLANES) sb.load((kb0 + 1) * BK);
-    }
-    __syncthreads();
-
-    bf16x8 bh[G::NI], bl[G::NI];
-    auto load_b = [&](const char* buf) {
-#pragma unroll
-      for (int j = 0; j < G::NI; ++j) {
-        const int off = swz(wn * (BN / WN) + j * 16 + r, c);
-        bh[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + off);
-        bl[j] = *reinterpret_cast<const bf16x8*>(buf + 2 * G::A_PLANE + G::B_PLANE + off);
-      }
-    };
-    auto row_tiles = [&](const char* buf, int i0, int i1) {
-#pragma unroll
-      for (int i = 0; i < G::MI; ++i) {
-        if (i < i0 || i >= i1) continue;
-        const int off = swz(wm * (BM / WM) + i * 16 + r, c);
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + off);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::A_PLANE + off);
-#pragma unroll
-        for (int j = 0; j < G::NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
-        }
-      }
-    };
-    for (int kb = kb0; kb < kb1; ++kb) {  // the pipeline of k_gemm_bf16x3
-      const int cur = (kb - kb0) & 1;
-      const char* buf = smem + cur * G::BUF_BYTES;
-      char* nb = smem + (cur ^ 1) * G::BUF_BYTES;
-      const bool more = kb + 1 < kb1;
-      if (W_PLANES && more) dma.issue(nb + 2 * G::A_PLANE, kb + 1);
-      load_b(buf);
-      row_tiles(buf, 0, G::MI / 2);
-      if (more) {
-        sa.store(nb, nb + G::A_PLANE);
-        if (!W_PLANES) sb.store(nb + 2 * G::A_PLANE, nb + 2 * G::A_PLANE + G::B_PLANE);
-        if (kb + 2 < kb1) {
-          sa.load((kb + 2) * BK);
-          if (!W_PLANES) sb.load((kb + 2) * BK);
-        }
-      }
-      row_tiles(buf, G::MI / 2, G::MI);
-      __syncthreads();
-    }
-
-    if (kb0 != 0 || kb1 != (int)nkb) {  // a segment of a cut tile: raw accumulators, row-major [BM][BN]
-      float* part = partial + ((size_t)2 * w + (kb0 == 0 ? 1 : 0)) * (size_t)(BM * BN);
-#pragma unroll
-      for (int i = 0; i < G::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < G::NI; ++j)
-          st4(part + (wm * (BM / WM) + i * 16 + r) * BN + wn * (BN / WN) + j * 16 + c * 4,
-              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
-      continue;
-    }
-#pragma unroll
-    for (int i = 0; i < G::MI; ++i) {
-      const int64_t row = m0 + wm * (BM / WM) + i * 16 + r;
-      if (row >= M) continue;
-#pragma unroll
-      for (int j = 0; j < G::NI; ++j) {
-        const int col = n0 + wn * (BN / WN) + j * 16 + c * 4;
-        if (col >= N) continue;   // N % 4 == 0: a group of four columns is inside or outside as a whole
-        float* dst = C + row * ldc + col;
-        float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        if (bias != nullptr) o = o + ld4(bias + col);
-        if (accumulate) o = o + ld4(dst);
-        st4(dst, o);
-      }
-    }
-  }
-}
-
-// C[cut tile] (+)= bias + its segments, in workgroup order.  grid (BM * BN / 1024, tiles), 256 threads, a float4 each.
-template <int BM, int BN>
-__global__ void __launch_bounds__(256) k_sk_fixup(const float* __restrict__ partial, const float* __restrict__ bias,
-                                                  float* __restrict__ C, int64_t ldc, int64_t M, int N, unsigned col_tiles,
-                                                  unsigned tiles, unsigned nkb, unsigned G, int accumulate) {
-  const unsigned t = blockIdx.y;
-  const uint64_t U = (uint64_t)tiles * nkb, first = (uint64_t)t * nkb, last = first + nkb - 1;
-  const unsigned w_first = (unsigned)(((first + 1) * G - 1) / U), w_last = (unsigned)(((last + 1) * G - 1) / U);
-  if (w_first == w_last) return;   // the tile lay inside one workgroup's range and was stored by it
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int row = e / (BN / 4), c4 = e - row * (BN / 4);
-  const int64_t m = (int64_t)(t / col_tiles) * BM + row;
-  const int col = (int)(t % col_tiles) * BN + c4 * 4;
-  if (row >= BM || m >= M || col >= N) return;
-  float4 s = bias != nullptr ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const size_t off = (size_t)row * BN + (size_t)c4 * 4;
-  for (unsigned w = w_first; w <= w_last; ++w) {
-    const uint64_t start = (uint64_t)w * U / G;
-    s = s + ld4(partial + ((size_t)2 * w + (start <= first ? 1 : 0)) * (size_t)(BM * BN) + off);
-  }
-  float* dst = C + m * ldc + col;
-  if (accumulate) s = s + ld4(dst);
-  st4(dst, s);
-}
-
-template <int BM, int BN, int WM, int WN, bool W_PLANES>
-static int launch_sk(const float* x, int64_t ldx, const float* w, const void* w_hi, const void* w_lo, int64_t ldw,
-                     const float* bias, float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate,
-                     float* scratch, size_t scratch_floats, const int64_t* a_index, bool* done) {
-  using G = Cfg<BM, BN, WM, WN>;
-  *done = false;
-  const int64_t mt = cdiv(M, BM), nt = cdiv(N, BN);
-  const int64_t tiles = mt * nt, nkb = K / BK;
-  if (tiles > ((int64_t)1 << 24) || scratch == nullptr || (N % 4) || (ldy % 4) || !aligned16(y) || !aligned16(scratch)) return DRIN_OK;
-  auto kern = k_gemm_bf16x3_sk<BM, BN, WM, WN, W_PLANES>;
-  static DynLdsOptIn opt_in;
-  DRIN_TRY(ensure_dynamic_lds(opt_in, reinterpret_cast<const void*>(kern), G::LDS_BYTES, "hipFuncSetAttribute(gemm_bf16x3_sk)"));
-  // as many workgroups as the chip keeps resident (occupancy x CUs, asked once per device)
-  static std::atomic<int> resident[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  int g = resident[dev & 63].load(std::memory_order_relaxed);
-  if (g == 0) {
-    int per_cu = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, G::THREADS, G::LDS_BYTES);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(gemm_bf16x3_sk)");
-    g = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
-    resident[dev & 63].store(g, std::memory_order_relaxed);
-  }
-  const int64_t units = tiles * nkb;
-  int64_t groups = g;
-  if (groups * 4 > units) groups = units / 4;           // at least four K-blocks per workgroup
-  if (groups < 1) groups = 1;
-  while (groups > 1 && (size_t)2 * groups * BM * BN > scratch_floats) --groups;
-  if ((size_t)2 * groups * BM * BN > scratch_floats) return DRIN_OK;
-  {
-    KernelTimer timer(DRIN_KC_GEMM_X3, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(G::THREADS), G::LDS_BYTES, st, x, ldx, w, (const __bf16*)w_hi,
-                       (const __bf16*)w_lo, ldw, bias, y, ldy, M, N, K, accumulate ? 1 : 0, (unsigned)nt, (unsigned)tiles, scratch,
-                       a_index);
-    DRIN_CHECK_LAUNCH("k_gemm_bf16x3_sk");
-    if (groups > 1) {
-      hipLaunchKernelGGL((k_sk_fixup<BM, BN>), dim3(BM * BN / 1024, (unsigned)tiles), dim3(256), 0, st, scratch, bias, y, ldy, M, N,
-                         (unsigned)nt, (unsigned)tiles, (unsigned)nkb, (unsigned)groups, accumulate ? 1 : 0);
-      DRIN_CHECK_LAUNCH("k_sk_fixup");
-    }
-  }
-  *done = true;
   return DRIN_OK;
 }
 
@@ -709,50 +391,60 @@ int launch_tail_add_256(const float* tail, float* y, int64_t ldy, int64_t M, int
   return DRIN_OK;
 }
 
-bool gemm_nt_f16_scaled_fits(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N,
-                             int K) {
-  return cdiv(M, 256) * cdiv(N, 256) >= 192 && K > 0 && (K % (2 * x3::BK)) == 0 && (ldx % 4) == 0 && (ldw % 8) == 0 && (N % 4) == 0 &&
-         (ldy % 4) == 0 && aligned16(x) && aligned16(w_f16) && aligned16(y);
-}
-
-int launch_gemm_nt_f16_scaled(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* row_scale, float* y, int64_t ldy,
-                              int64_t M, int N, int K, hipStream_t st) {
-  if (M <= 0 || N <= 0) return DRIN_OK;
-  if (row_scale == nullptr || !gemm_nt_f16_scaled_fits(x, ldx, w_f16, ldw, y, ldy, M, N, K)) {
-    set_error("gemm_f16_scaled: built for whole 256 x 256 grids, K %% 64 == 0, 16-byte aligned operands and a row-scale array");
-    return DRIN_E_UNSUPPORTED;
+// ---- one fp16 plane of a weight matrix under ONE power-of-two scale (DRIN_PREC_BF16X3_IF16: the folded W_h1 W_ei) ----------------
+// out = fp16(x / s) with s = the power of two that brings max |x| into [0.5, 1] (clamped to 2^+-126: its reciprocal is a normal
+// number), written to scale[0]; the contraction's epilogue multiplies it back.  Exact to apply; fp16's range (6e-5 .. 65 504) then
+// never matters whatever the magnitude of the weights (an unscaled plane of weights ~1e-5 is mostly subnormal).
+// The maximum is order-independent, so the integer atomic below gives the same bits every run.
+__global__ void __launch_bounds__(256) k_abs_max_bits(const float* __restrict__ x, int64_t n4, unsigned* __restrict__ out_bits) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = ld4(x + i * 4);
+    const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = fmaxf(m, a);   // (a NaN weight is not seen here: it reaches the scores through its own fp16 NaN)
   }
-  return x3::launch<256, 256, 2, 4, true, true, true>(x, ldx, nullptr, w_f16, w_f16, ldw, nullptr, y, ldy, M, N, K, st, false, nullptr, 0,
-                                                      nullptr, row_scale);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));   // |x| >= 0: the bit patterns order like the values
 }
 
-__global__ void __launch_bounds__(256) k_to_f16(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n4) {
+__global__ void __launch_bounds__(256) k_to_f16_scaled(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n4,
+                                                       float* __restrict__ scale) {
+  const float s = cache_field_scale(scale[1]);   // (an infinite maximum: scale 1, the infinity propagates as it is)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) scale[0] = s;
   if (i >= n4) return;
+  const float inv = 1.0f / s;
   const float4 v = ld4(x + i * 4);
   f16x4 h;
-  h[0] = (_Float16)v.x, h[1] = (_Float16)v.y, h[2] = (_Float16)v.z, h[3] = (_Float16)v.w;
+  h[0] = (_Float16)(v.x * inv), h[1] = (_Float16)(v.y * inv), h[2] = (_Float16)(v.z * inv), h[3] = (_Float16)(v.w * inv);
   *reinterpret_cast<f16x4*>(out + i * 4) = h;
 }
 
-int launch_to_f16(const float* x, void* out, int64_t n, hipStream_t st) {
+// scale: two floats - [0] receives the scale, [1] is scratch (the running maximum's bits)
+int launch_to_f16_scaled(const float* x, void* out, int64_t n, float* scale, hipStream_t st) {
   if (n <= 0) return DRIN_OK;
-  if ((n % 4) || !aligned16(x) || (reinterpret_cast<uintptr_t>(out) & 7u)) {
-    set_error("to_f16: %lld elements (multiple of 4) from a 16-byte aligned source", (long long)n);
+  if ((n % 4) || !aligned16(x) || (reinterpret_cast<uintptr_t>(out) & 7u) || scale == nullptr) {
+    set_error("to_f16_scaled: %lld elements (multiple of 4) from a 16-byte aligned source, and a two-float scale buffer", (long long)n);
     return DRIN_E_SHAPE;
   }
+  hipError_t e = hipMemsetAsync(scale, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(to_f16_scaled)");
   KernelTimer timer(DRIN_KC_GCN, st);
-  hipLaunchKernelGGL(k_to_f16, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, x, (_Float16*)out, n / 4);
-  DRIN_CHECK_LAUNCH("k_to_f16");
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(k_abs_max_bits, dim3((unsigned)(cdiv(n4, 256) < 1024 ? cdiv(n4, 256) : 1024)), dim3(256), 0, st, x, n4,
+                     reinterpret_cast<unsigned*>(scale + 1));
+  DRIN_CHECK_LAUNCH("k_abs_max_bits");
+  hipLaunchKernelGGL(k_to_f16_scaled, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, x, (_Float16*)out, n4, scale);
+  DRIN_CHECK_LAUNCH("k_to_f16_scaled");
   return DRIN_OK;
 }
 
 // w_hi / w_lo: optional pre-split bf16 planes of w (same row stride); when given, w itself is not read.
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi, const void* w_lo,
-                          bool accumulate, bool one_pass, float* tail, size_t tail_floats, const int64_t* a_index) {
+                          bool accumulate, float* tail, size_t tail_floats, const int64_t* a_index) {
   if (M <= 0 || N <= 0) return DRIN_OK;
-  if (a_index != nullptr && ((K % x3::BK) || K <= 0 || one_pass)) {
+  if (a_index != nullptr && ((K % x3::BK) || K <= 0)) {
     set_error("gemm_bf16x3: indexed rows need K %% 32 == 0 (got %d) on the split-bf16 kernel", K);
     return DRIN_E_UNSUPPORTED;
   }
@@ -771,18 +463,6 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   }
   // pair-sized problems: 256 x 256 tiles; anything that would not fill the chip with them: 64 x 128 tiles
   const bool big = cdiv(M, 256) * cdiv(N, 256) >= 192;
-  if (one_pass) {  // DRIN_PREC_BF16: pair-sized products on pre-split weight planes only
-    if (!planes || !big) {
-      set_error("gemm_bf16x3: the one-pass (plain bf16) variant is built for pair-sized problems on weight planes");
-      return DRIN_E_UNSUPPORTED;
-    }
-    // (Measured in round 4 and removed - profiles/r4_one_pass_ab.txt: an all-DMA three-stage ring for this product, raw fp32
-    //  activation rows straight into LDS, two 48 KiB stages in flight, fragments rounded at read time.  Correct, and slower
-    //  (x_i C_i^T 1.9 against 1.6 ms): six LDS-DMA instructions per wave per 32 MFMAs cost more issue time than they hide.)
-    if (K % (2 * x3::BK) == 0)   // 64-wide K-blocks; a reduction length that is an odd multiple of 32 keeps three passes
-      return x3::launch<256, 256, 2, 4, true, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate);
-    one_pass = false;
-  }
   if (tail != nullptr && !aligned16(tail)) tail = nullptr;
   // Mid-sized products (a few thousand to a few ten thousand rows: the training step at the reference's batch): 64 x 128 tiles
   // fill the chip but run at the L2 -> LDS bandwidth so small a tile needs (SQ counters: an MFMA executing in 0.30 of the
@@ -790,49 +470,28 @@ int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t l
   // least three quarters of a whole number of rounds of the chip's 256 CUs, it is taken instead - BM in {96, 128, 160, 192},
   // the one with the least rounds x rows: 6 464 rows -> 96 (204 tiles), 12 928 -> 160 (243), 25 856 -> 160 (486).  Same
   // box, the B = 64 step's split-bf16 GEMM time 0.730 -> 0.679 ms, B = 128 1.360 -> 1.249 (profiles/r3_tile_shapes_ab.txt).
-  // Measured there and NOT adopted: the same tiles at a fixed BM for every product (0.726 - 0.855 ms), and three stream-K
-  // forms (k_gemm_bf16x3_sk, kept behind DRIN_SK for the record: every CU gets the same number of K-blocks, but below one
-  // round every tile is cut and takes the scratch + fix-up path: 64 x 128 0.859, 128 x 256 0.781, 256 x 256 0.955 ms).
-  {
-    static const char* sk = getenv("DRIN_SK");
-    const bool mid = !big && M >= 2048;
-    const char* mode = sk != nullptr ? sk : "auto";
-    bool done = false;
-    if (mode[0] == '6' && mid) {
-      DRIN_TRY(planes ? (x3::launch_sk<64, 128, 2, 2, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done))
-                      : (x3::launch_sk<64, 128, 2, 2, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done)));
-    } else if (mode[0] == '1' && mid) {
-      DRIN_TRY(planes ? (x3::launch_sk<128, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done))
-                      : (x3::launch_sk<128, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done)));
-    } else if (mode[0] == '2' && (mid || big)) {
-      DRIN_TRY(planes ? (x3::launch_sk<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done))
-                      : (x3::launch_sk<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index, &done)));
+  // Measured there, NOT adopted and since removed: the same tiles at a fixed BM for every product (0.726 - 0.855 ms), and three
+  // stream-K forms (every CU the same number of K-blocks, but below one round every tile is cut and takes a scratch + fix-up
+  // path: 64 x 128 0.859, 128 x 256 0.781, 256 x 256 0.955 ms).
+  if (!big && M >= 2048 && planes) {
+    int best = 0;
+    int64_t cost = 0;
+    for (int cand : {192, 160, 128, 96}) {
+      const int64_t tiles = cdiv(M, cand) * cdiv(N, 256), rounds = cdiv(tiles, x3::kCUs);
+      const bool filled = 4 * tiles >= 3 * rounds * (int64_t)x3::kCUs;
+      if (filled && (best == 0 || rounds * cand <= cost)) cost = rounds * cand, best = cand;
     }
-    if (done) return DRIN_OK;
-    if ((mode[0] == 'a' || mode[0] == 't') && mid && planes) {
-      int best = 0;
-      int64_t cost = 0;
-      for (int cand : {192, 160, 128, 96}) {
-        const int64_t tiles = cdiv(M, cand) * cdiv(N, 256), rounds = cdiv(tiles, x3::kCUs);
-        const bool filled = mode[0] == 't' || 4 * tiles >= 3 * rounds * (int64_t)x3::kCUs;
-        if (filled && (best == 0 || rounds * cand <= cost)) cost = rounds * cand, best = cand;
-      }
-      if (mode[0] == 't' && mode[1] != 0) best = atoi(mode + 1);   // probe: a fixed BM
-      switch (best) {
-        case 96: return x3::launch<96, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
-        case 128: return x3::launch<128, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
-        case 160: return x3::launch<160, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
-        case 192: return x3::launch<192, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
-        default: break;   // no tall tile fills its rounds: the 64 x 128 tiles below
-      }
+    switch (best) {
+      case 96: return x3::launch<96, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+      case 128: return x3::launch<128, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+      case 160: return x3::launch<160, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+      case 192: return x3::launch<192, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, nullptr, 0, a_index);
+      default: break;   // no tall tile fills its rounds: the 64 x 128 tiles below
     }
   }
-  {  // big products on weight planes: the four-phase pipeline of gemm_x3_planes.hip (DRIN_P4=0: the kernel below, for A/Bs)
-    static const char* p4 = getenv("DRIN_P4");
-    if (big && planes && !one_pass && a_index == nullptr && !(p4 != nullptr && p4[0] == '0') && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) &&
-        (bias == nullptr || aligned16(bias)))
-      return launch_gemm_nt_bf16x3_p4(x, ldx, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
-  }
+  // big products on weight planes: the four-phase pipeline of gemm_x3_planes.hip (indexed rows and odd layouts: the two-phase kernel below)
+  if (big && planes && a_index == nullptr && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && (bias == nullptr || aligned16(bias)))
+    return launch_gemm_nt_bf16x3_p4(x, ldx, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats);
   if (big)
     return planes ? x3::launch<256, 256, 2, 4, true>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index)
                   : x3::launch<256, 256, 2, 4, false>(x, ldx, w, w_hi, w_lo, ldw, bias, y, ldy, M, N, K, st, accumulate, tail, tail_floats, a_index);

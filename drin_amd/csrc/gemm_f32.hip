@@ -548,7 +548,7 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
     const bool planes = w_planes != nullptr && ldw == K && (K % 32) == 0;
     const __bf16* hi = reinterpret_cast<const __bf16*>(w_planes);
     return launch_gemm_nt_bf16x3(x, ldx, w, ldw, bias, y, ldy, M, N, K, st, planes ? (const void*)hi : nullptr,
-                                 planes ? (const void*)(hi + (int64_t)N * K) : nullptr, false, false, splitk, splitk_floats);
+                                 planes ? (const void*)(hi + (int64_t)N * K) : nullptr, false, splitk, splitk_floats);
   }
   if (precision == DRIN_PREC_BF16X3 || precision == DRIN_PREC_BF16X3_ALL) precision = DRIN_PREC_F32;
   DRIN_TRY(check_precision(precision, "gemm_nt"));

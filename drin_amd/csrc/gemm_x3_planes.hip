@@ -64,7 +64,6 @@ struct Pieces {
   int64_t row0, lim;  // first row of this lane's piece 0, number of valid rows
 };
 
-// B_LO = false as well (DRIN_PREC_BF16): operands rounded to bf16, hi x hi only - one MFMA per tile pair.
 template <bool A_LO, bool B_LO>
 __device__ __forceinline__ void issue_piece(const Pieces& p, char* buf, int kb, int i) {
   const int wave = threadIdx.x >> 6;
@@ -335,13 +334,14 @@ struct Src {
 };
 
 // unit u: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  Wave w fills pieces 2 w and 2 w + 1 of the unit's 16 (plane w >> 2, rows 32 (w & 3) ..)
-template <int U>
+// (KB_BYTES: bytes a K-block advances along a plane row - 64, or 128 in the single-plane fp16 kernel, whose K-blocks are 64 wide)
+template <int U, int KB_BYTES = BK * 2>
 __device__ __forceinline__ void issue_unit(const Src& s, char* buf, int kb) {
   const int wave = threadIdx.x >> 6;
   char* dst = buf + U * UNIT_BYTES + (wave >> 2) * (128 * 64) + (wave & 3) * 2048;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
-    __builtin_amdgcn_global_load_lds((gptr_t)(s.ptr[U][i] + (int64_t)kb * (BK * 2)), (lptr_t)(dst + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(s.ptr[U][i] + (int64_t)kb * KB_BYTES), (lptr_t)(dst + i * 1024), 16, 0, 0);
 }
 
 }  // namespace p4
@@ -349,12 +349,26 @@ __device__ __forceinline__ void issue_unit(const Src& s, char* buf, int kb) {
 // A_LO = false: the activation operand is exact in bf16 (features stored as bf16: the image rows read in place) - the hi x lo_a
 // term does not exist, 16 MFMAs per phase instead of 24.  The A units keep their shape and their DMA count (the wave group that
 // would fetch the lo plane fetches the hi plane once more, into the slot nobody reads), so that every counted wait is unchanged.
-template <bool A_LO = true>
+// F16 (DRIN_PREC_BF16X3_IF16: the entity-image contraction in ONE pass of v_mfma_f32_16x16x32_f16): each operand is a SINGLE fp16
+// plane and a K-block is 64 wide - its two 32-wide sub-blocks take the unit slots the split product gives to the hi and the lo
+// plane (a_lo = a_hi + 32, b_lo = b_hi + 32 elements, set here), so units, DMA counts and counted waits are again unchanged; a
+// 16 x 16 tile takes two MFMAs per K-block (sub-block 0, sub-block 1: the k order of 32-wide blocks), 16 per phase, for half
+// the K-blocks.  Row m of A was divided by row_scale[m] and B by *b_scale when their planes were written (powers of two: exact;
+// fp16's range never matters): the epilogue multiplies output row m by row_scale[m] * *b_scale.
+template <bool A_LO = true, bool F16 = false>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes_p4(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
                         const __bf16* __restrict__ b_hi, const __bf16* __restrict__ b_lo, int64_t ldb,
                         const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, int nx,
-                        unsigned full, int ksplit, float* __restrict__ tail) {
+                        unsigned full, int ksplit, float* __restrict__ tail, const float* __restrict__ row_scale,
+                        const float* __restrict__ b_scale) {
+  static_assert(!F16 || A_LO, "the fp16 form uses both slots of every unit");
+  constexpr int KSTEP = F16 ? 2 * BK : BK;       // elements of K per K-block
+  constexpr int KB_BYTES = KSTEP * 2;
+  if (F16) {
+    a_lo = a_hi + BK;
+    b_lo = b_hi + BK;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tx, kpart;
   int64_t ty;
@@ -367,7 +381,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     K /= ksplit;
     k0 = (int64_t)kpart * K;
   }
-  const int nkb = K / BK;
+  const int nkb = K / KSTEP;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, c = lane >> 4;
@@ -422,6 +436,22 @@ __global__ void __launch_bounds__(THREADS, 2)
   };
   auto mma = [&](f32x4 (&cc)[4][2], auto&& mid) {
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (F16) {   // (ah, bh): k sub-block 0 of the 64-wide block, (al, bl): sub-block 1 - fp16 bit patterns in the planes
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[j]), __builtin_bit_cast(f16x8, ah[i]), cc[i][j], 0, 0, 0);
+      mid();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl[j]), __builtin_bit_cast(f16x8, al[i]), cc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
     // term-major over the quadrant's eight tiles: an accumulator's next MFMA is eight issues away (same order of the three
     // terms per accumulator as everywhere: hi lo, lo hi, hi hi - same bits)
     if (p4::kTermMajor) {
@@ -460,10 +490,10 @@ __global__ void __launch_bounds__(THREADS, 2)
     __builtin_amdgcn_sched_barrier(0);
   };
   // prologue: K-block 0 whole, landed and published to everybody
-  p4::issue_unit<0>(src, smem, 0);
-  p4::issue_unit<2>(src, smem, 0);
-  p4::issue_unit<3>(src, smem, 0);
-  p4::issue_unit<1>(src, smem, 0);
+  p4::issue_unit<0, KB_BYTES>(src, smem, 0);
+  p4::issue_unit<2, KB_BYTES>(src, smem, 0);
+  p4::issue_unit<3, KB_BYTES>(src, smem, 0);
+  p4::issue_unit<1, KB_BYTES>(src, smem, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
   if (wm == 1) barrier();   // the second half of the workgroup runs one barrier behind the first from here on
@@ -479,12 +509,12 @@ __global__ void __launch_bounds__(THREADS, 2)
 #define DRIN_P4_PHASE(READS, UNIT, ACC)                                  \
   {                                                                      \
     READS;                                                               \
-    if (p4::kDmaPlace == 0) p4::issue_unit<UNIT>(src, nbuf, kn);         \
+    if (p4::kDmaPlace == 0) p4::issue_unit<UNIT, KB_BYTES>(src, nbuf, kn);         \
     p4::wait_units();                                                    \
     barrier();                                                           \
-    if (p4::kDmaPlace == 1) p4::issue_unit<UNIT>(src, nbuf, kn);         \
+    if (p4::kDmaPlace == 1) p4::issue_unit<UNIT, KB_BYTES>(src, nbuf, kn);         \
     if (p4::kDmaPlace == 2)                                              \
-      mma(ACC, [&] { p4::issue_unit<UNIT>(src, nbuf, kn); });            \
+      mma(ACC, [&] { p4::issue_unit<UNIT, KB_BYTES>(src, nbuf, kn); });            \
     else                                                                 \
       mma(ACC, none);                                                    \
     barrier();                                                           \
@@ -507,15 +537,22 @@ __global__ void __launch_bounds__(THREADS, 2)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        // (fp16 form: a slice carries its rows' scale like the part stored to C - powers of two, so the sum of scaled slices is the scaled sum)
+        const int64_t row = m0 + a * 128 + wm * 64 + i * 16 + r;
+        const float rs = F16 ? row_scale[row < M ? row : M - 1] * *b_scale : 1.0f;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            st4(part + (a * 128 + wm * 64 + i * 16 + r) * BN + b * 128 + wn * 32 + j * 16 + c * 4,
-                make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]));
+          for (int j = 0; j < 2; ++j) {
+            float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]);
+            if (F16) o = o * rs;
+            st4(part + (a * 128 + wm * 64 + i * 16 + r) * BN + b * 128 + wn * 32 + j * 16 + c * 4, o);
+          }
+      }
     return;
   }
+  const float bs = F16 ? *b_scale : 1.0f;
   float4 bv[2][2];   // the bias of this lane's four column groups, fetched once (a load per store would serialise the stores)
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -530,13 +567,16 @@ __global__ void __launch_bounds__(THREADS, 2)
     for (int i = 0; i < 4; ++i) {
       const int64_t row = m0 + a * 128 + wm * 64 + i * 16 + r;
       if (row >= M) continue;
+      const float rs = F16 ? row_scale[row] * bs : 1.0f;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = n0 + b * 128 + wn * 32 + j * 16 + c * 4;
           if (col >= N) continue;   // N % 4 == 0 (checked by the launcher)
-          st4(C + row * ldc + col, make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]) + bv[b][j]);
+          float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]);
+          if (F16) o = o * rs;
+          st4(C + row * ldc + col, o + bv[b][j]);
         }
     }
 }
@@ -1031,9 +1071,8 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
                           hipStream_t st, float* splitk, size_t splitk_floats) {
   if (M <= 0 || N <= 0) return DRIN_OK;
   const bool a_lo_plane = a_lo != nullptr;  // NULL: A is exact in bf16 (one plane, two MFMAs per tile pair)
-  const bool b_lo_plane = b_lo != nullptr;  // NULL too: plain bf16 contraction (DRIN_PREC_BF16), one MFMA
-  if (!b_lo_plane && a_lo_plane) {
-    set_error("gemm_x3_planes: a weight lo plane may only be dropped together with the activation lo plane");
+  if (b_lo == nullptr) {
+    set_error("gemm_x3_planes: the weight operand needs both planes");
     return DRIN_E_UNSUPPORTED;
   }
   if (K <= 0 || (K % x3p::BK) || (lda % 8) || (ldb % 8) || !aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) ||
@@ -1047,11 +1086,10 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
     return DRIN_E_SHAPE;
   }
   {
-    static DynLdsOptIn opt_in[3];
-    const void* kernels[3] = {reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<true, true>),
-                              reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, true>),
-                              reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, false>)};
-    for (int i = 0; i < 3; ++i)
+    static DynLdsOptIn opt_in[2];
+    const void* kernels[2] = {reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<true, true>),
+                              reinterpret_cast<const void*>(x3p::k_gemm_x3_planes<false, true>)};
+    for (int i = 0; i < 2; ++i)
       DRIN_TRY(ensure_dynamic_lds(opt_in[i], kernels[i], x3p::LDS_BYTES, "hipFuncSetAttribute(gemm_x3_planes)"));
   }
   // A handful of mentions is a handful of tiles walking K serially (101 rows x 768 x 768: 3 workgroups, 50 us): split K
@@ -1070,36 +1108,24 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
   const int nx = (int)cdiv(N, x3p::BN);
   unsigned full = (unsigned)tiles;
   int ksplit = 1;
-  if (splits == 1 && splitk != nullptr && aligned16(splitk) && tiles <= 16 * 256) {
-    const unsigned frac = (unsigned)(tiles % 256);
-    for (int s = 4; s >= 2 && frac > 0; --s)
-      if ((unsigned)s * frac <= 256 && nkb % s == 0 && nkb / s >= 4 &&
-          (size_t)frac * (s - 1) * (x3p::BM * x3p::BN) <= splitk_floats) {
-        ksplit = s;
-        full = (unsigned)tiles - frac;
-        break;
-      }
-  }
-  {  // the full split product (both lo planes) on whole tiles + tail slices: the four-phase pipeline (DRIN_P4=0: the previous kernel, for A/Bs)
-    static const char* p4 = getenv("DRIN_P4");
-    // (an activation operand without a lo plane - exact in bf16 - takes the A_LO = false instantiation from half a round of tiles up;
-    //  smaller grids of it keep the two-phase kernel and its split-K forms)
-    if (!(p4 != nullptr && p4[0] == '0') && b_lo_plane && (a_lo_plane || tiles >= 128) && splits == 1 && (N % 4) == 0 && (ldy % 4) == 0 &&
-        aligned16(y) && (bias == nullptr || aligned16(bias))) {
-      static DynLdsOptIn opt[2];
-      auto kern = a_lo_plane ? x3p::k_gemm_x3_planes_p4<true> : x3p::k_gemm_x3_planes_p4<false>;
-      DRIN_TRY(ensure_dynamic_lds(opt[a_lo_plane ? 0 : 1], reinterpret_cast<const void*>(kern), x3p::p4::LDS, "hipFuncSetAttribute(gemm_x3_planes_p4)"));
-      const unsigned p4_items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
-      {
-        KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
-        hipLaunchKernelGGL(kern, dim3(p4_items), dim3(x3p::THREADS), x3p::p4::LDS, st, (const __bf16*)a_hi,
-                           (const __bf16*)(a_lo_plane ? a_lo : a_hi), lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K, nx,
-                           full, ksplit, splitk);
-        DRIN_CHECK_LAUNCH("k_gemm_x3_planes_p4");
-      }
-      if (ksplit > 1) DRIN_TRY(launch_tail_add_256(splitk, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
-      return DRIN_OK;
+  if (splits == 1) tail_split_256(tiles, nkb, splitk, splitk_floats, &full, &ksplit);
+  // the full split product on whole tiles + tail slices: the four-phase pipeline
+  // (an activation operand without a lo plane - exact in bf16 - takes the A_LO = false instantiation from half a round of tiles up;
+  //  smaller grids of it keep the two-phase kernel and its split-K forms)
+  if ((a_lo_plane || tiles >= 128) && splits == 1 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(y) && (bias == nullptr || aligned16(bias))) {
+    static DynLdsOptIn opt[2];
+    auto kern = a_lo_plane ? x3p::k_gemm_x3_planes_p4<true, false> : x3p::k_gemm_x3_planes_p4<false, false>;
+    DRIN_TRY(ensure_dynamic_lds(opt[a_lo_plane ? 0 : 1], reinterpret_cast<const void*>(kern), x3p::p4::LDS, "hipFuncSetAttribute(gemm_x3_planes_p4)"));
+    const unsigned p4_items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
+    {
+      KernelTimer timer(DRIN_KC_GEMM_PLANES, st);
+      hipLaunchKernelGGL(kern, dim3(p4_items), dim3(x3p::THREADS), x3p::p4::LDS, st, (const __bf16*)a_hi,
+                         (const __bf16*)(a_lo_plane ? a_lo : a_hi), lda, (const __bf16*)b_hi, (const __bf16*)b_lo, ldb, bias, y, ldy, M, N, K, nx,
+                         full, ksplit, splitk, (const float*)nullptr, (const float*)nullptr);
+      DRIN_CHECK_LAUNCH("k_gemm_x3_planes_p4");
     }
+    if (ksplit > 1) DRIN_TRY(launch_tail_add_256(splitk, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
+    return DRIN_OK;
   }
   const unsigned items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
   dim3 grid(items, 1, (unsigned)splits);
@@ -1111,16 +1137,48 @@ int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const
     if (a_lo_plane)
       hipLaunchKernelGGL((x3p::k_gemm_x3_planes<true, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
                          bl, ldb, bias, out, ldy, M, N, K, part_stride, nx, full, ksplit, splitk);
-    else if (b_lo_plane)
-      hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
-                         bl, ldb, bias, out, ldy, M, N, K, part_stride, nx, full, ksplit, splitk);
     else
-      hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, false>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
+      hipLaunchKernelGGL((x3p::k_gemm_x3_planes<false, true>), grid, dim3(x3p::THREADS), x3p::LDS_BYTES, st, ah, al, lda, bh,
                          bl, ldb, bias, out, ldy, M, N, K, part_stride, nx, full, ksplit, splitk);
     DRIN_CHECK_LAUNCH("k_gemm_x3_planes");
   }
   if (splits > 1) DRIN_TRY(launch_splitk_reduce(splitk, splits, part_stride, bias, y, ldy, M, N, false, st));
   if (ksplit > 1) DRIN_TRY(launch_tail_add_256(splitk, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
+  return DRIN_OK;
+}
+
+// ONE fp16 MFMA pass on single fp16 planes (the F16 instantiation of the four-phase kernel): see internal.h
+bool gemm_f16_planes_fits(const void* a_f16, int64_t lda, const void* b_f16, int64_t ldb, const float* y, int64_t ldy, int64_t M, int N,
+                          int K) {
+  return cdiv(M, x3p::BM) * cdiv(N, x3p::BN) >= 128 && cdiv(M, x3p::BM) * cdiv(N, x3p::BN) <= ((int64_t)1 << 28) && K > 0 &&
+         (K % (2 * x3p::BK)) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (N % 4) == 0 && (ldy % 4) == 0 && aligned16(a_f16) &&
+         aligned16(b_f16) && aligned16(y);
+}
+
+int launch_gemm_f16_planes(const void* a_f16, int64_t lda, const void* b_f16, int64_t ldb, const float* row_scale, const float* b_scale,
+                           float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, float* tail, size_t tail_floats) {
+  if (M <= 0 || N <= 0) return DRIN_OK;
+  if (row_scale == nullptr || b_scale == nullptr || !gemm_f16_planes_fits(a_f16, lda, b_f16, ldb, y, ldy, M, N, K)) {
+    set_error("gemm_f16_planes: built for at least half a round of 256 x 256 tiles, K %% 64 == 0, 16-byte aligned planes and both scales");
+    return DRIN_E_UNSUPPORTED;
+  }
+  const int nx = (int)cdiv(N, x3p::BN);
+  const int64_t tiles = cdiv(M, x3p::BM) * nx;
+  unsigned full;
+  int ksplit;
+  tail_split_256(tiles, K / (2 * x3p::BK), tail, tail_floats, &full, &ksplit);
+  const unsigned items = full + ((unsigned)tiles - full) * (unsigned)ksplit;
+  auto kern = x3p::k_gemm_x3_planes_p4<true, true>;
+  static DynLdsOptIn opt;
+  DRIN_TRY(ensure_dynamic_lds(opt, reinterpret_cast<const void*>(kern), x3p::p4::LDS, "hipFuncSetAttribute(gemm_f16_planes)"));
+  {
+    KernelTimer timer(DRIN_KC_GEMM_X3, st);   // (the class of the product it replaces: x_i C_i^T)
+    hipLaunchKernelGGL(kern, dim3(items), dim3(x3p::THREADS), x3p::p4::LDS, st, (const __bf16*)a_f16, (const __bf16*)a_f16, lda,
+                       (const __bf16*)b_f16, (const __bf16*)b_f16, ldb, (const float*)nullptr, y, ldy, M, N, K, nx, full, ksplit, tail, row_scale,
+                       b_scale);
+    DRIN_CHECK_LAUNCH("k_gemm_f16_planes");
+  }
+  if (ksplit > 1) DRIN_TRY(launch_tail_add_256(tail, y, ldy, M, N, (unsigned)nx, full, (unsigned)tiles - full, ksplit, st));
   return DRIN_OK;
 }
 

@@ -132,17 +132,11 @@ int launch_gemm_nt(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 // (w_hi, w_lo: optional pre-split planes of w - then w itself is not read and the weights stream by LDS-DMA)
 int launch_gemm_nt_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                           int64_t ldy, int64_t M, int N, int K, hipStream_t st, const void* w_hi = nullptr,
-                          const void* w_lo = nullptr, bool accumulate = false, bool one_pass = false,
+                          const void* w_lo = nullptr, bool accumulate = false,
                           float* tail = nullptr, size_t tail_floats = 0, const int64_t* a_index = nullptr);
 // (a_index: row m of x is row a_index[m] of a table)
-// y = x w^T in ONE fp16 MFMA pass (DRIN_PREC_BF16X3_IF16): row m of x is multiplied by 1 / row_scale[m] (powers of two: exact)
-// before it is rounded to fp16 and output row m by row_scale[m] afterwards; w_f16 is the weight as one fp16 plane [N][K].
-// Whole 256 x 256 grids with K % 64 == 0 only: DRIN_E_UNSUPPORTED otherwise (the caller runs the split-bf16 product).
-int launch_gemm_nt_f16_scaled(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* row_scale, float* y, int64_t ldy,
-                              int64_t M, int N, int K, hipStream_t st);
-bool gemm_nt_f16_scaled_fits(const float* x, int64_t ldx, const void* w_f16, int64_t ldw, const float* y, int64_t ldy, int64_t M, int N, int K);
-// fp32 -> fp16 (round to nearest even), n % 4 == 0
-int launch_to_f16(const float* x, void* out, int64_t n, hipStream_t st);
+// one fp16 plane of x under ONE power-of-two scale: out = fp16(x / s), s -> scale[0] (scale: two floats, [1] is scratch); n % 4 == 0
+int launch_to_f16_scaled(const float* x, void* out, int64_t n, float* scale, hipStream_t st);
 // (tail: optional scratch; a partly filled last round of 256 x 256 tiles is then split along K over the idle CUs)
 // (accumulate: y += ... instead of y = ...)
 // weight-gradient contraction y[n, k] += sum_m a[m, n] b[m, k] in split-bf16 (gemm_tn_bf16x3.hip)
@@ -184,14 +178,17 @@ struct TnGroup {
 int launch_gemm_tn_group(const TnGroup& g, hipStream_t st, float* scratch, size_t scratch_floats, SliceSum* defer = nullptr,
                          int64_t target_rows = 0);
 int64_t tn_group_target(const TnGroup& g, size_t scratch_floats);
-// bf16 MFMA passes of those products: 3 (split-bf16, default) or 1 (drin_set_weight_gradient_passes: an experiment)
-int weight_gradient_passes();
-void set_weight_gradient_passes(int passes);
 // same, operands pre-split into bf16 hi / lo planes (gemm_x3_planes.hip); K % 32 == 0
-// (a_lo NULL: A exact in bf16, two MFMAs per tile pair; b_lo NULL as well: plain bf16, one MFMA)
+// (a_lo NULL: A exact in bf16, two MFMAs per tile pair)
 int launch_gemm_x3_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, const float* bias, float* y, int64_t ldy, int64_t M, int N, int K,
                           hipStream_t st, float* splitk = nullptr, size_t splitk_floats = 0);
+// y = a b^T in ONE fp16 MFMA pass on single fp16 planes (DRIN_PREC_BF16X3_IF16; gemm_x3_planes.hip): a_f16 [M][K] holds row m of the
+// activation divided by row_scale[m], b_f16 [N][K] the weight divided by *b_scale (powers of two: exact); output row m is multiplied
+// by row_scale[m] * *b_scale.  Whole 256 x 256 tiles, K % 64 == 0, 16-byte aligned: gemm_f16_planes_fits, DRIN_E_UNSUPPORTED otherwise.
+bool gemm_f16_planes_fits(const void* a_f16, int64_t lda, const void* b_f16, int64_t ldb, const float* y, int64_t ldy, int64_t M, int N, int K);
+int launch_gemm_f16_planes(const void* a_f16, int64_t lda, const void* b_f16, int64_t ldb, const float* row_scale, const float* b_scale,
+                           float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, float* tail = nullptr, size_t tail_floats = 0);
 // the four-phase pipeline (gemm_x3_planes.hip) on an fp32 x against pre-split weight planes: whole 256 x 256 tiles
 int launch_gemm_nt_bf16x3_p4(const float* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw, const float* bias,
                              float* y, int64_t ldy, int64_t M, int N, int K, hipStream_t st, bool accumulate, float* tail = nullptr,

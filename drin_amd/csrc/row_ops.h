@@ -90,6 +90,42 @@ __device__ __forceinline__ void store_row_planes(void* __restrict__ hi, void* __
     }
   }
 }
+// row / scale as ONE fp16 plane (the A operand of the single-plane fp16 contraction, gemm_x3_planes.hip), exact widths only
+// (no column guards), 16-byte streaming stores.  PAIR: a lane's slot pair already holds eight consecutive columns.  Otherwise a
+// lane holds four columns per slot: the lanes of a pair (l, l ^ 1) swap one packed slot each, so that the even lane stores the
+// eight columns 4 l .. 4 l + 7 of slot 2 q and the odd lane those of slot 2 q + 1 (8-byte stores move at 0.54-0.70 of the
+// 16-byte rate, MI355X_MICROARCH.md).  `inv` = 1 / scale, a power of two: the division is exact.
+template <int V, bool PAIR = false>
+__device__ __forceinline__ void store_row_f16_scaled(void* __restrict__ out, int64_t row_off, const Row<V>& r, float inv, int lane) {
+  static_assert(V % 2 == 0, "slot pairs");
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  _Float16* base = reinterpret_cast<_Float16*>(out) + row_off;
+  auto pack = [inv](float4 v, uint32_t& a, uint32_t& b) {
+    const f32x2 lo = {v.x * inv, v.y * inv}, hi = {v.z * inv, v.w * inv};
+    a = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, f16x2));
+    b = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, f16x2));
+  };
+#pragma unroll
+  for (int q = 0; q < V / 2; ++q) {
+    uint32_t a0, a1, b0, b1;
+    pack(r.v[2 * q], a0, a1);
+    pack(r.v[2 * q + 1], b0, b1);
+    u32x4_t o;
+    int col;
+    if (PAIR) {
+      o = u32x4_t{a0, a1, b0, b1};
+      col = 8 * (lane + 64 * q);
+    } else {
+      const bool odd = lane & 1;
+      const uint32_t s0 = odd ? a0 : b0, s1 = odd ? a1 : b1;        // the slot the partner stores
+      const uint32_t r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+      o = odd ? u32x4_t{r0, r1, b0, b1} : u32x4_t{a0, a1, r0, r1};
+      col = odd ? 4 * (lane - 1 + 64 * (2 * q + 1)) : 4 * (lane + 64 * (2 * q));
+    }
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(base + col));
+  }
+}
 template <int V>
 __device__ __forceinline__ float dot_rows(const Row<V>& a, const Row<V>& b) {
   float s = 0.f;

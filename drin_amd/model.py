@@ -63,8 +63,8 @@ class GCNLayer(nn.Module):  # drin/model.py:109-119 (scaler edges: w_m is Identi
 
 # precisions that are modes of the fused inference path only: whatever else they meet (training, the per-entity cache,
 # geometries off the fused path, traced forwards) runs split-bf16
-_FUSED_ONLY = (_lib.PREC_BF16, _lib.PREC_BF16X3_I1, _lib.PREC_BF16X3_IF16)
-_PLANES = (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16, _lib.PREC_BF16X3_I1, _lib.PREC_BF16X3_IF16)
+_FUSED_ONLY = (_lib.PREC_BF16X3_IF16,)
+_PLANES = (_lib.PREC_BF16X3, _lib.PREC_BF16X3_ALL, _lib.PREC_BF16X3_IF16)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -524,16 +524,13 @@ class Model(nn.Module):
         """`cfg`: None reads an importable reference `common.args` (the no-argument `Model()` of `train.py:136`), else the
         WikiDiverse defaults (`config.default_config`).
         `precision`: "bf16x3" (default: split-bf16 MFMA, fp32-equivalent - measured <= 1.4e-6 on the scores against the
-        reference's fp32 forward, bar 1e-4; 2x the rate of exact fp32), "f32" (exact fp32 MFMA) or "bf16" (opt-in: the
-        pair-sized contractions of the fused inference path in ONE bf16 MFMA pass - score error ~6e-4, outside the
-        1e-4 bar; training and every other path then run "bf16x3") or "bf16x3_i1" (precision by contraction: split-bf16 except
-        the folded entity-image contraction, which runs one bf16 pass where the candidate list is long enough - N >= 64 - for
-        the mean over candidates behind it to average its rounding noise down: <= 2.5e-5 on the scores at N = 101 with freshly
-        initialised weights, but 1.6e-4 - outside the 1e-4 bar - once the weights are trained (DESIGN.md 4.3): a benchmark mode;
-        shorter lists and every other path run "bf16x3") or "bf16x3_if16" (the same one pass on the FP16 matrix
-        instruction, every image row scaled by a power of two into fp16's range: <= 4e-6 on the scores at N = 101 with freshly
-        initialised weights, <= 2e-5 with trained ones - inside the bar either way; same N >= 64 gate (N = 11 on trained weights:
-        1.2e-4) - for the per-pair fp32 image rows of large inference calls; else "bf16x3");
+        reference's fp32 forward, <= 6e-6 on trained weights, bar 1e-4; 2x the rate of exact fp32), "f32" (exact fp32 MFMA) or
+        "bf16x3_if16" (precision by contraction: split-bf16 except the folded entity-image contraction, which runs ONE pass of the
+        FP16 matrix instruction on the image rows the stream kernel hands over as fp16 under a power-of-two scale per row, where the
+        candidate list is long enough - N >= 64 - for the mean over candidates behind it to average its rounding noise down:
+        <= 4e-6 on the scores at N = 101 with freshly initialised weights, <= 2e-5 with trained ones - inside the bar either way;
+        for per-pair (not table-form) image rows, fp32- or bf16-stored, of large inference calls at D = 768 / R = 2048; shorter
+        lists, small calls and every other path run "bf16x3" bit for bit);
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;
         `grad_bucket`: backward writes every gradient into one flat bucket the `.grad`s are views of (like DDP's
         `gradient_as_bucket_view`: a `.grad` kept across `zero_grad(set_to_none=True)` + `backward()` is overwritten)."""
@@ -549,8 +546,12 @@ class Model(nn.Module):
         self._param_flat: Optional[torch.Tensor] = None
         self._layout = None
         self.register_load_state_dict_post_hook(_invalidate_after_load)
-        self.precision = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL,
-                          "bf16": _lib.PREC_BF16, "bf16x3_i1": _lib.PREC_BF16X3_I1, "bf16x3_if16": _lib.PREC_BF16X3_IF16}[precision]
+        modes = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL, "bf16x3_if16": _lib.PREC_BF16X3_IF16}
+        if precision not in modes:
+            # ("bf16" - every contraction in one bf16 pass, 5e-4 - and "bf16x3_i1" - the image contraction in one bf16 pass, 1.6e-4 on
+            #  trained weights - were outside the path's 1e-4 bar and were removed in round 5)
+            raise ValueError(f"precision {precision!r}: one of {sorted(modes)}")
+        self.precision = modes[precision]
         self.vertex_encoder = VertexEncoder(self.cfg)          # model.py:159 (RNG order: ghmfc.py:165,211; model.py:23-24)
         self.gcn_layers = nn.ModuleList([GCNLayer(self.cfg) for _ in range(self.cfg.num_gcn_layers)])  # model.py:161
 
@@ -687,7 +688,7 @@ class Model(nn.Module):
         # other path (training, exact fp32, geometries off the fused path) gets them widened to fp32 - exact
         in_place = (not training and self._prepared is not None and self.cfg.num_gcn_layers == 2
                     and self.precision in _PLANES)
-        # "bf16" is a mode of the fused inference path; anything else it meets runs split-bf16
+        # "bf16x3_if16" is a mode of the fused inference path; anything else it meets runs split-bf16
         prec = self.precision if (in_place or self.precision not in _FUSED_ONLY) else _lib.PREC_BF16X3
         if (cls is None and training and len(batch) >= 14 and batch[7].dtype == torch.bfloat16 and batch[7].dim() == 4
                 and batch[7].is_cuda and batch[7].shape[0] > 0):

@@ -13,7 +13,8 @@
  *     thread-local message for the last failure on the calling thread.
  *   - all data pointers are DEVICE pointers unless a parameter says "host".  The caller owns every
  *     buffer, including the workspace (size from drin_workspace_bytes); the library allocates
- *     nothing and keeps no mutable global state, so calls are re-entrant.
+ *     nothing and keeps no mutable global state (the opt-in profile of drin_profile_begin apart; environment
+ *     probes are read once), so calls are re-entrant.
  *   - every kernel is launched on the caller's `stream` (a hipStream_t passed as void*); the
  *     library never synchronises.
  *   - tensors are dense row-major fp32 (`float`), index/mask tensors int64 exactly as
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DRIN_ABI_VERSION 5
+#define DRIN_ABI_VERSION 6
 #define DRIN_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -42,37 +43,29 @@ typedef enum {
   DRIN_E_UNSUPPORTED = -6 /* configuration not built (e.g. vector edge features)                */
 } drin_status;
 
-/* Arithmetic of the contractions.  All other arithmetic is fp32. */
+/* Arithmetic of the contractions.  All other arithmetic is fp32.  Every value here is INSIDE the 1e-4 bar of the path on freshly
+ * initialised and on trained weights (tests/test_gpu_round4.py, tests/test_gpu_round5.py); the values 2 and 4 (plain one-pass bf16: 5e-4;
+ * one bf16 pass for the image contraction: 1.6e-4 on trained weights) were outside it and were removed with ABI 6. */
 typedef enum {
   DRIN_PREC_F32 = 0,    /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): k-ordered fmaf chain        */
-  DRIN_PREC_BF16X3 = 1, /* operands split hi+lo bf16, 3 bf16 MFMAs, fp32 accumulate (~fp32)      */
-  DRIN_PREC_BF16 = 2,   /* drin_forward_prepared only, opt-in: the three pair-sized contractions with operands
-                           rounded to bf16, ONE MFMA pass (BASELINE's "bf16 inference").  Measured score error
-                           ~6e-4: OUTSIDE the 1e-4 bar of the path - never a default; mention-sized work keeps the
-                           BF16X3 arithmetic.  Other entry points return DRIN_E_UNSUPPORTED for it. */
+  DRIN_PREC_BF16X3 = 1, /* operands split hi+lo bf16, 3 bf16 MFMAs, fp32 accumulate (~fp32): <= 2e-6 on the scores at
+                           initialisation, <= 6e-6 on trained weights.  The default.                */
   DRIN_PREC_BF16X3_ALL = 3, /* BF16X3 also for the mention-sized contractions that BF16X3 leaves on
                               the fp32 kernel for latency reasons (used by the parity tests)      */
-  DRIN_PREC_BF16X3_I1 = 4, /* drin_forward_prepared only: precision BY CONTRACTION.  BF16X3 everywhere except the
-                              folded entity-image contraction x_i (W_h1 W_ei)^T - 57 % of the path's FLOPs - which runs
-                              ONE bf16 MFMA pass (operands rounded, no lo planes).  Its result feeds only the layer-1
-                              entity IMAGE vertex, which reaches the score through mean_n(ti' ei') in the layer-2
-                              mention vertex alone (model.py:124-129,143-144; vertex graph :105): the rounding noise is
-                              averaged over the N candidates before it meets the score.  Measured at N = 101 with
-                              freshly initialised weights: max |score - fp32 reference| <= 2.5e-5 (bar 1e-4), top-1
-                              unchanged - but 0.5-1.6e-4 once the weights are TRAINED (the vertex -> score map steepens;
-                              profiles/r4_precision_on_trained_weights.txt): a benchmark mode, not a serving one; taken only for
-                              num_candidates >= 64 - shorter lists (N = 11: 5-10e-5, no margin) keep three passes and
-                              equal BF16X3 bit for bit.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
-  DRIN_PREC_BF16X3_IF16 = 5 /* drin_forward_prepared only: as BF16X3_I1, but the one pass of the entity-image contraction runs
-                              on the FP16 matrix instruction (11-bit operands: an eighth of the bf16 pass's rounding error).
-                              fp16's range is made a non-issue by scaling every image row by a power of two (its max |x|
-                              into [0.5, 1): exact) before the conversion and the output row back afterwards; the folded
-                              weight is converted once by drin_prepare.  Measured at N = 101: <= 4e-6 on the scores with freshly
-                              initialised weights, <= 2e-5 with trained ones (BF16X3 itself: 2e-6 / 6e-6) - inside the bar
-                              either way.  Same candidate-count gate as BF16X3_I1 (num_candidates >= 64): at N = 11 the
-                              pass costs 8e-6 at initialisation but 1.2e-4 on trained weights.  Taken for the
-                              per-pair fp32 image rows of large calls (the benchmark's form); bf16-stored features, the table
-                              form and small calls run BF16X3.  Other entry points return DRIN_E_UNSUPPORTED for it.  */
+  DRIN_PREC_BF16X3_IF16 = 5 /* drin_forward_prepared only: precision BY CONTRACTION.  BF16X3 everywhere except the folded
+                              entity-image contraction x_i (W_h1 W_ei)^T - 57 % of the path's FLOPs - which runs ONE pass of the
+                              FP16 matrix instruction (11-bit operands).  Its result feeds only the layer-1 entity IMAGE vertex,
+                              which reaches the score through mean_n(ti' ei') in the layer-2 mention vertex alone
+                              (model.py:124-129,143-144; vertex graph :105): the rounding noise is averaged over the N candidates
+                              before it meets the score.  fp16's range is made a non-issue by scaling: k_entity_stream writes
+                              every image row as fp16(x / 2^ceil(log2 max|x|)) (exact) with the scale beside it, drin_prepare
+                              the folded weight as one fp16 plane under one power-of-two scale, and the contraction multiplies
+                              both back in its epilogue.  Measured at N = 101: <= 4e-6 on the scores with freshly initialised
+                              weights, <= 2e-5 with trained ones (BF16X3 itself: 2e-6 / 6e-6).  Taken only for num_candidates >= 64
+                              (at N = 11 the pass costs 8e-6 at initialisation but 1.2e-4 on trained weights), D = 768, R = 2048,
+                              per-pair (not table-form) image rows - fp32- or bf16-stored - and calls of at least 128 tiles of
+                              256 x 256 (~11 000 pairs); every other call runs BF16X3 bit for bit.  Other entry points return
+                              DRIN_E_UNSUPPORTED for it.  */
 } drin_precision;
 
 /* Geometry + switches of one forward.  Names follow common/args.py. */
@@ -123,6 +116,11 @@ typedef struct {
  * entity, 16 400 B instead of 23 568 at D = 768, R = 2 048.  Effect on the scores: 2e-7 at N = 101, 6e-7 at N = 11
  * (oracle/precision_emulation.py; measured: tests/test_gpu_round4.py) - below the split-bf16 contractions' own 1.3e-6; with
  * TRAINED weights <= 3e-6 at N = 101 and <= 1.7e-5 at N = 11 against the fp32 rows (profiles/r4_precision_on_trained_weights.txt).
+ * The limit of the format: an fp16 field holds an edge logit mean_d(W_u(u) W_v(v)) to 2^-12 of the size of its TERMS.  For feature
+ * rows of ordinary size (|x| up to ~1e3 x unit scale) that is below 1e-5 on the scores; for an entity whose image row is scaled by
+ * 1e6 (terms ~1e5) the sigmoid is normally saturated and nothing moves, but a logit whose terms cancel to within a few units is then
+ * held to ~1 by the fp16 field where the fp32 row holds it to ~1e-3: measured 6.7e-5 on the scores of such a mention against the
+ * fp64 oracle, the fp32 rows 9e-7 (tests/test_gpu_round5.py).  Tables with rows that far off scale: DRIN_CACHE_F32.
  * Needs embed_dim % 8 == 0 and image_dim % 8 == 0. */
 typedef enum {
   DRIN_CACHE_F32 = 0,
@@ -333,23 +331,6 @@ DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* bat
  * counterpart. */
 DRIN_API int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached);
 
-/* Large batches in the split-bf16 precision: drin_forward_prepared cuts the batch into chunks of mentions and runs chunk
- * c + 1's pass over the entity bytes (HBM-bound) on `stream_cus` of the CUs while chunk c's contractions (MFMA-bound) run on
- * the others - two internal streams created with hipExtStreamCreateWithCUMask, forked from and joined to `stream` by
- * events, so the call keeps its stream-ordered contract.  stream_cus: 0 = everything on `stream` itself, -1 = the built-in
- * default (also: environment DRIN_PIPE = "off" | "<cus>" | "<cus>:<pairs per chunk>"); chunk_pairs: (mention, candidate)
- * pairs per chunk, -1 = default.  Process-wide; drin_fused_workspace_bytes answers for the setting in force, so change it
- * between calls, not between the size query and its call.  No reference counterpart (the reference runs one stream). */
-DRIN_API int drin_set_pipeline(int32_t stream_cus, int32_t chunk_pairs);
-
-/* EXPERIMENT, off by default: matrix passes of the pair-sized weight-gradient products dW = dY^T X of drin_backward
- * (`loss.backward()` of train.py:33-34 through model.py:164-209) in split-bf16 precision.  3 = the split product (hi hi + hi lo
- * + lo hi: fp32-equivalent, the default); 1 = both operands rounded to bf16, one pass - a weight gradient is a sum over
- * >= 6 464 pair rows, which averages the rounding of its terms (measured against the oracle's Adam loop:
- * profiles/r4_dw_one_pass.txt); -1 = the default (also: environment DRIN_DW_PASSES=1).  Process-wide; change it between
- * steps.  No reference counterpart. */
-DRIN_API int drin_set_weight_gradient_passes(int32_t passes);
-
 /* ---- per-entity precompute cache for table-form inference ---------------------- *
  * With frozen weights, what the first GCN layer takes from an entity (its rows of the entity_* tables,
  * `drin/data.py:87-93`) does not depend on the mention: `W_h1 W_et x_t`, `W_h1 W_ei x_i`, `W_v1(et0)`,
@@ -374,7 +355,7 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* batch
 /* Building blocks of the split-bf16 precision: x = hi + lo with hi, lo bf16 planes (n % 4 == 0), and the
  * contraction y = x w^T (+ bias) on such planes by LDS-DMA + bf16 MFMA (k % 32 == 0).  Plane pointers are
  * device pointers to bf16 arrays with the row strides of the fp32 originals.  x_lo may be NULL when x is
- * exact in bf16 (then two MFMAs per tile pair instead of three). */
+ * exact in bf16 (then two MFMAs per tile pair instead of three); the weight planes are both required. */
 DRIN_API int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
 DRIN_API int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                     const float* bias, float* y, int64_t rows, int32_t n_out, int32_t k,

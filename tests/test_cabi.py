@@ -55,40 +55,31 @@ def test_workspace_query_and_validation():
     assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
     assert b"multiples of 4" in lib.drin_last_error()
     c.embed_dim = 768
-    c.precision = 7
-    assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
+    for removed_or_unknown in (2, 4, 7):                                # 2, 4: the out-of-tolerance one-pass modes removed with ABI 6
+        c.precision = removed_or_unknown
+        assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
     c.precision = 0
     c.num_layers = 9
     assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
 
 
-def test_pipeline_setting_sizes_the_fused_workspace():
-    """`drin_set_pipeline` (host logic only): off by default; with it a large split-bf16 batch is sized as whole chunks of
-    mentions, each with its own workspace; short pipelines, exact-fp32 precision and small batches keep the one-stream size."""
+def test_fused_workspace_size_is_a_pure_function_of_the_configuration():
+    """ABI 6 removed the process-wide setters (`drin_set_pipeline`, `drin_set_weight_gradient_passes`): a size query depends on its
+    `drin_config` alone - the same answer before and after other calls, from any thread."""
     lib = _lib.load()
+    for name in ("drin_set_pipeline", "drin_set_weight_gradient_passes"):
+        assert not hasattr(lib, name), name
     c = _lib.DrinConfigC()
-    lib.drin_default_config(C.byref(c))
-    c.precision = _lib.PREC_BF16X3
-    c.num_candidates = 16
-
-    def size(batch):
-        c.batch = batch
-        return lib.drin_fused_workspace_bytes(C.byref(c))
-
-    try:
-        assert lib.drin_set_pipeline(0, -1) == _lib.OK
-        one_stream = {b: size(b) for b in (256, 700, 1200)}
-        assert 0 < one_stream[256] < one_stream[1200]
-        assert lib.drin_set_pipeline(64, 4096) == _lib.OK              # 4 096 pairs = 256 mentions of 16 candidates per chunk
-        assert size(1200) == 5 * one_stream[256]                        # ceil(1200 / 256) chunks, the last one ragged
-        assert size(700) == one_stream[700]                             # three chunks: fill and drain would cost what the overlap buys
-        c.precision = _lib.PREC_F32
-        f32 = size(1200)
-        assert lib.drin_set_pipeline(0, -1) == _lib.OK
-        assert size(1200) == f32                                        # the exact-fp32 path never pipelines
-        assert lib.drin_set_pipeline(256, -1) == _lib.E_SHAPE and b"stream_cus" in lib.drin_last_error()
-    finally:
-        lib.drin_set_pipeline(-1, -1)
+    _lib.check(lib.drin_default_config(C.byref(c)))
+    sizes = []
+    for _ in range(2):
+        row = []
+        for batch, prec in ((1200, _lib.PREC_BF16X3), (1200, _lib.PREC_F32), (64, _lib.PREC_BF16X3), (1200, _lib.PREC_BF16X3_IF16)):
+            c.batch, c.precision = batch, prec
+            row.append(lib.drin_fused_workspace_bytes(C.byref(c)))
+        sizes.append(row)
+    assert sizes[0] == sizes[1] and all(v > 0 for v in sizes[0])
+    assert sizes[0][3] > sizes[0][0]                                    # the fp16 mode's row scales
 
 
 def test_null_arguments_are_reported_not_crashed():

@@ -912,42 +912,25 @@ def test_inner_feature_dims_take_the_pooled_path():
     assert (got - ref).abs().max().item() <= 2e-5
 
 
-# ---- opt-in plain-bf16 contractions (DRIN_PREC_BF16) ----------------------------------------------------------
-def test_plain_bf16_precision_is_a_stated_tolerance_mode():
-    """`precision="bf16"`: the pair-sized contractions of the fused inference path in one bf16 MFMA pass.  It is
-    OUTSIDE the 1e-4 bar of the path (so never a default): the tolerance stated for it is 3e-3 on the scores with
-    top-1 agreement >= 0.9 on synthetic candidates; training and the layer-by-layer path run split-bf16 instead."""
-    cfg = wikimel_config(max_entity_attr_token_len=8, max_mention_sentence_len=16, resnet_num_region=4)
-    sd = synth.make_state_dict(cfg, 7)
-    batch = synth.make_batch(cfg, 48, 91)   # 4848 pairs: the pair-sized problems are big enough for the 256 x 256 tiles
-    ref = O.forward(sd, batch)
-    fast = Model(cfg, precision="bf16").to(DEV).eval()
-    fast.load_state_dict(sd)
-    exact = Model(cfg, precision="bf16x3").to(DEV).eval()
-    exact.load_state_dict(sd)
-    with torch.no_grad():
-        _lib.profile_begin()
-        s = fast(_to_dev(batch[:14])).cpu()
-        prof = _lib.profile_end()
-        s3 = exact(_to_dev(batch[:14])).cpu()
-    assert prof["stream"][1] == 1
-    err, err3 = (s - ref).abs().max().item(), (s3 - ref).abs().max().item()
-    agree = (s[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean().item()
-    print(f"plain bf16: max |score - oracle| = {err:.2e} (split-bf16: {err3:.2e}), top-1 agreement {agree:.3f}")
-    assert err3 <= 1e-5 and 1e-5 < err <= 3e-3 and agree >= 0.9
-    # training under this precision runs the split-bf16 layer-by-layer path: gradients as accurate as "bf16x3"
-    from drin_amd.metrics import TripletLoss
-    fast.train()
-    dbatch = _to_dev(batch)
-    loss = TripletLoss(cfg.triplet_margin)(dbatch[-1], fast(dbatch[:-1]))
-    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref_loss = O.triplet_loss(batch[-1], O.forward(p, batch), cfg.triplet_margin)
-    assert abs(loss.item() - ref_loss.item()) <= 1e-5
-    # the library refuses the mode outside the fused inference entry point
+# ---- modes outside the path's tolerance are gone (ABI 6) ------------------------------------------------------
+def test_precisions_outside_the_bar_are_not_offered():
+    """`precision="bf16"` (every pair-sized contraction in one bf16 pass: 5e-4 on the scores) and `"bf16x3_i1"` (the image
+    contraction in one bf16 pass: 1.6e-4 on trained weights) were outside the path's 1e-4 bar and were removed in round 5: the
+    module refuses their names, the library their enum values (2, 4) at every entry point."""
+    cfg = DrinConfig()
+    for name in ("bf16", "bf16x3_i1"):
+        with pytest.raises(ValueError, match="precision"):
+            Model(cfg, precision=name)
     lib = _lib.load()
     c = _lib.DrinConfigC()
     lib.drin_default_config(C.byref(c))
-    c.batch, c.precision = 4, _lib.PREC_BF16
+    c.batch = 4
+    for value in (2, 4, 6, -1):
+        c.precision = value
+        assert lib.drin_fused_supported(C.byref(c)) == _lib.E_UNSUPPORTED and b"precision" in lib.drin_last_error()
+        assert lib.drin_workspace_bytes(C.byref(c), 0) == 0
+    # the one precision-by-contraction mode left is a mode of the fused inference entry point only
+    c.precision = _lib.PREC_BF16X3_IF16
     assert lib.drin_fused_supported(C.byref(c)) == _lib.OK
     bt = _lib.DrinBatchC()
     assert lib.drin_forward(C.byref(c), C.byref(bt), None, None, 0, None, 0, None, None) in (_lib.E_UNSUPPORTED, _lib.E_NULL)

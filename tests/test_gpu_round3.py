@@ -523,52 +523,6 @@ def test_train_cli_test_only(tmp_path, monkeypatch):
     assert max(abs(a - b) for a, b in zip(got, want)) <= 1e-6
 
 
-# ---- the two phases of the fused forward side by side on disjoint CU sets (drin_set_pipeline; opt-in) ---------------------
-@pytest.mark.parametrize("layout", ["wikidiverse", "wikimel", "bf16_features", "table"])
-def test_pipelined_forward_equals_the_one_stream_schedule(layout):
-    """Chunks of mentions on two CU-masked streams (stream phase of chunk c + 1 beside the contractions of chunk c): same
-    scores as the one-stream schedule up to the tile choices of the mention-sized products, a ragged last chunk, the caller's
-    stream ordered behind the join (the scores are read on it right after the call), the oracle on a slice."""
-    from drin_amd.model import EntityTable, IndexedBatch
-    lib = _lib.load()
-    if layout == "wikimel":
-        cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=15, max_entity_attr_token_len=6, **TINY)
-    else:
-        cfg = DrinConfig(num_candidates_data=15, **TINY)
-    sd = synth.make_state_dict(cfg, 8)
-    model = Model(cfg).to(DEV).eval()
-    model.load_state_dict(sd)
-    B = 1200                                                          # 16 candidates: chunks of 256 mentions, the last one of 176
-    dtype = torch.bfloat16 if layout == "bf16_features" else torch.float32
-    batch = synth.make_device_batch(cfg, B, 9, DEV, dtype=dtype)[:14]
-    feed = batch
-    if layout == "table":
-        tab = synth.make_device_batch(cfg.with_(num_candidates_data=499), 1, 4, DEV)
-        table = EntityTable(tab[7][0], None, tab[9][0], tab[10][0], tab[11][0])
-        cand = torch.randint(0, 500, (B, 16), device=DEV)
-        feed = IndexedBatch(batch[:7], table, cand, batch[12], batch[13])
-    try:
-        with torch.no_grad():
-            _lib.check(lib.drin_set_pipeline(0, -1))
-            one = model(feed).clone()
-            torch.cuda.synchronize()
-            _lib.check(lib.drin_set_pipeline(64, 4096))
-            side = torch.cuda.Stream()
-            with torch.cuda.stream(side):                             # not the legacy stream: nothing but the join orders the read
-                two = model(feed)
-                again = model(feed)
-                diff = (two - one.to(two.device)).abs().max()
-            side.synchronize()
-        assert diff.item() <= 5e-6 and torch.equal(two, again)          # fp32 re-association of other tile shapes
-        rows = slice(250, 262)                                        # across the first chunk boundary
-        ref_in = feed.gathered() if layout == "table" else batch
-        ref = O.forward(sd, [t[rows].float().cpu() if t.is_floating_point() else t[rows].cpu() for t in ref_in])
-        assert (two[rows].cpu() - ref).abs().max().item() <= 1e-5
-    finally:
-        _lib.check(lib.drin_set_pipeline(-1, -1))
-    assert lib.drin_set_pipeline(256, -1) != _lib.OK
-
-
 def test_four_phase_gemm_with_a_single_k_block():
     """D = R = 32: every pair-sized contraction of the fused path is ONE 32-wide K-block (the four-phase kernels' prologue,
     one block that re-fetches itself, epilogue) with 32 output columns of a 256-column tile; 80 000 pair rows = 313 tiles,

@@ -2,7 +2,7 @@
 workgroups of the fused path at D = 768 / R = 2048 / N = 101; the 128-candidate workgroups of the per-entity-cache path live in
 test_gpu_round2.py next to its million-entity fixture); a training TRAJECTORY at the reference's width in the default
 arithmetic against the oracle's fp32 Adam loop; the exact-fp32 backward in the batch-size windows ADVICE r3 found without
-slice scratch; precision by contraction (`bf16x3_i1`)."""
+slice scratch; precision by contraction (`bf16x3_if16`: the entity-image contraction in one fp16 pass) and by storage (mixed-f16 cache rows)."""
 import ctypes as C
 import os
 
@@ -143,50 +143,11 @@ def _models(cfg, sd, *precisions):
     return out
 
 
-def test_mixed_precision_every_score_of_a_headline_step():
-    """`precision="bf16x3_i1"`: only the folded entity-image contraction x_i (W_h1 W_ei)^T runs one bf16 pass.  A whole
-    headline-sized step - 4 096 mentions x 101 candidates = 413 696 scores at D = 768 / R = 2048 (T = 4: the token count does
-    not touch this contraction) - against the exact-fp32 MFMA path on the same batch as the yardstick for EVERY score
-    (itself within 3e-7 of the oracle), and against the CPU oracle on slices: <= 2.5e-5 on a 1e-4 bar, top-1 of every
-    mention unchanged.  The plain one-pass mode (`"bf16"`: all three contractions) is shown next to it on the same batch."""
-    cfg = wikimel_config(max_entity_attr_token_len=4)
-    sd = synth.make_state_dict(cfg, 7)
-    B = 4096
-    batch = synth.make_device_batch(cfg, B, 100, DEV)[:14]
-    exact, mixed, x3, plain = _models(cfg, sd, "f32", "bf16x3_i1", "bf16x3", "bf16")
-    assert mixed.precision == _lib.PREC_BF16X3_I1
-    _threads()
-    with torch.no_grad():
-        ref = exact(batch)
-        mixed(batch)
-        _lib.profile_begin()
-        got = mixed(batch)
-        prof_mixed = _lib.profile_end()
-        _lib.profile_begin()
-        base = x3(batch)
-        prof_x3 = _lib.profile_end()
-        err = (got - ref).abs().max().item()
-        err_x3 = (base - ref).abs().max().item()
-        err_plain = (plain(batch) - ref).abs().max().item()
-        top1 = (got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean().item()
-        worst_oracle = 0.0
-        for rows in (slice(0, 8), slice(2044, 2052), slice(B - 8, B)):
-            o = O.forward(sd, [t[rows].cpu() for t in batch])
-            worst_oracle = max(worst_oracle, (got[rows].cpu() - o).abs().max().item())
-            assert (ref[rows].cpu() - o).abs().max().item() <= 2e-6        # the yardstick itself
-    print(f"bf16x3_i1 over {got.numel()} scores: max |score - exact fp32| {err:.2e} (bf16x3 {err_x3:.2e}, plain bf16 {err_plain:.2e}), "
-          f"oracle slices {worst_oracle:.2e}, top-1 agreement {top1}; x_i C_i^T class 'gemm_x3' {prof_x3['gemm_x3'][0]:.3f} -> {prof_mixed['gemm_x3'][0]:.3f} ms")
-    assert err <= 2.5e-5 and worst_oracle <= 2.5e-5 and top1 == 1.0
-    assert err_x3 <= 5e-6 and err_plain > 1e-4                          # why the plain one-pass mode stays an opt-in
-    with torch.no_grad():
-        assert torch.equal(got, mixed(batch))
-
-
-@pytest.mark.parametrize("mode,bound", [("bf16x3_i1", 2.5e-5), ("bf16x3_if16", 1e-5)])
+@pytest.mark.parametrize("mode,bound", [("bf16x3_if16", 1e-5)])
 def test_mixed_precision_keeps_planted_near_ties_in_order(mode, bound):
     """The ranking evidence: for every mention the top candidate's entity rows are copied into a second slot and one CLIP
     similarity (mention image / entity text) of the copy is nudged until the exact-fp32 scores of the two are 1e-4 apart (5e-5 ... 2e-4 after two
-    calibration rounds) - a gold / runner-up pair as close as the path's tolerance.  Both one-pass modes must order every such pair
+    calibration rounds) - a gold / runner-up pair as close as the path's tolerance.  The one-pass mode must order every such pair
     as the exact path does: its rounding noise enters the score through the layer-2 MENTION vertex (model.py:143-144), which
     all candidates of a mention share, so it moves near-tied candidates together."""
     cfg = wikimel_config(max_entity_attr_token_len=4)
@@ -231,37 +192,11 @@ def test_mixed_precision_keeps_planted_near_ties_in_order(mode, bound):
     assert (s_mixed[:, :-1].argmax(1) == s_exact[:, :-1].argmax(1))[near].all()
 
 
-def test_mixed_precision_short_candidate_lists_and_other_paths_stay_split_bf16():
-    """N < 64 (WikiDiverse: 11 candidates; the averaging behind the image contraction is sqrt(11), the emulation gives 5-10e-5:
-    no margin): `bf16x3_i1` keeps three passes there and equals `bf16x3` bit for bit; training runs split-bf16 as well."""
-    cfg = DrinConfig()
-    sd = synth.make_state_dict(cfg, 7)
-    batch = synth.make_device_batch(cfg, 2048, 5, DEV)
-    mixed, x3 = _models(cfg, sd, "bf16x3_i1", "bf16x3")
-    with torch.no_grad():
-        assert torch.equal(mixed(batch[:14]), x3(batch[:14]))
-    grads = []
-    for m in (mixed, x3):
-        m.train()
-        m.zero_grad(set_to_none=True)
-        TripletLoss(cfg.triplet_margin)(batch[14][:64], m([t[:64] for t in batch[:14]])).backward()
-        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-    assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
-    # bf16-stored features and the table form take the mode too (one plane per operand on the LDS-DMA kernel)
-    wm = wikimel_config(max_entity_attr_token_len=4)
-    wsd = synth.make_state_dict(wm, 7)
-    b32 = synth.make_device_batch(wm, 512, 9, DEV)[:14]
-    b16 = [t.to(torch.bfloat16) if i in (0, 4, 5, 7, 9, 10) else t for i, t in enumerate(b32)]
-    m_mixed, m_exact = _models(wm, wsd, "bf16x3_i1", "f32")
-    with torch.no_grad():
-        ref16 = m_exact([t.float() if t.dtype == torch.bfloat16 else t for t in b16])
-        assert (m_mixed(b16) - ref16).abs().max().item() <= 2.5e-5
-
-
-# ---- the same one pass on the FP16 matrix instruction, rows scaled into range (`bf16x3_if16`) --------------------------------
+# ---- the entity-image contraction in one pass of the FP16 matrix instruction, rows scaled into range (`bf16x3_if16`) ----------
 def test_f16_image_contraction_every_score_of_a_headline_step():
-    """`precision="bf16x3_if16"`: x_i (W_h1 W_ei)^T in ONE pass of v_mfma_f32_16x16x32_f16 (11-bit operands), every image row
-    scaled by a power of two into fp16's range by the stream kernel's hand-over (`xi_scale`), the output row scaled back.  All
+    """`precision="bf16x3_if16"`: x_i (W_h1 W_ei)^T in ONE pass of v_mfma_f32_16x16x32_f16 (11-bit operands) on single fp16 planes:
+    every image row written by the stream kernel as fp16(x / 2^k) with the scale beside it (`xi_f16`, `xi_scale`), the folded weight
+    as one fp16 plane under one scale, the output row scaled back by both in the all-DMA four-phase kernel's epilogue.  All
     413 696 scores of a headline-sized step against the exact-fp32 MFMA path: <= 1e-5 - the guard every split-bf16 test of this
     suite uses (bar 1e-4) - top-1 unchanged; CPU-oracle slices; the class time of the contraction next to split-bf16's."""
     cfg = wikimel_config(max_entity_attr_token_len=4)
@@ -290,7 +225,7 @@ def test_f16_image_contraction_every_score_of_a_headline_step():
     print(f"bf16x3_if16 over {got.numel()} scores: max |score - exact fp32| {err:.2e} (bf16x3 {err_x3:.2e}), oracle slices {worst_oracle:.2e}, "
           f"top-1 agreement {top1}; class 'gemm_x3' {prof_x3['gemm_x3'][0]:.3f} -> {prof_f16['gemm_x3'][0]:.3f} ms")
     assert err <= 1e-5 and worst_oracle <= 1e-5 and top1 == 1.0
-    assert prof_f16["gemm_x3"][0] < 0.8 * prof_x3["gemm_x3"][0], "the one-pass fp16 kernel did not run"
+    assert prof_f16["gemm_x3"][0] < 0.6 * prof_x3["gemm_x3"][0], "the one-pass fp16 kernel did not run"
 
 
 def test_f16_image_contraction_is_blind_to_the_scale_of_the_rows():
@@ -321,8 +256,10 @@ def test_f16_image_contraction_is_blind_to_the_scale_of_the_rows():
 def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
     """Where the fp16 pass does NOT run, the mode is split-bf16 bit for bit: candidate lists shorter than 64 (WikiDiverse-shaped,
     16 384 mentions - at N = 11 the pass costs 8e-6 at initialisation but 1.2e-4 on trained weights,
-    `profiles/r4_precision_on_trained_weights.txt`: same gate as `bf16x3_i1`), calls too small for whole 256 x 256 grids,
-    bf16-stored features, training."""
+    `profiles/r4_precision_on_trained_weights.txt`), calls of fewer than 128 tiles of 256 x 256, the table form, training.
+    bf16-STORED image rows take the pass too (round 5: a bf16 value is exact in fp16 under its row scale): against the oracle on
+    the widened values."""
+    from drin_amd.model import EntityTable, IndexedBatch
     cfg = DrinConfig()
     sd = synth.make_state_dict(cfg, 7)
     batch = synth.make_device_batch(cfg, 16384, 5, DEV)
@@ -334,12 +271,26 @@ def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
     sd = synth.make_state_dict(cfg, 7)
     batch = synth.make_device_batch(cfg, 512, 5, DEV)
     f16, x3 = _models(cfg, sd, "bf16x3_if16", "bf16x3")
+    _threads()
     with torch.no_grad():
-        assert not torch.equal(f16(batch[:14]), x3(batch[:14]))        # N = 101, 512 mentions: the pass runs
-        small = [t[:64] for t in batch[:14]]
+        assert not torch.equal(f16(batch[:14]), x3(batch[:14]))        # N = 101, 512 mentions = 609 tiles: the pass runs
+        small = [t[:64] for t in batch[:14]]                           # 6 464 pairs = 78 tiles: three passes
         assert torch.equal(f16(small), x3(small))
         b16 = [t.to(torch.bfloat16) if i in (0, 4, 5, 7, 9, 10) else t for i, t in enumerate(batch[:14])]
-        assert torch.equal(f16(b16), x3(b16))
+        _lib.profile_begin()
+        got16 = f16(b16)
+        prof = _lib.profile_end()
+        assert prof["gemm_x3"][1] >= 1 and not torch.equal(got16, x3(b16))          # bf16-stored rows: the fp16 plane, one pass
+        ref = O.forward(sd, [(t[:16].float() if t.dtype == torch.bfloat16 else t[:16]).cpu() for t in b16])
+        err = (got16[:16].cpu() - ref).abs().max().item()
+        print(f"bf16-stored features through the fp16 image contraction: max |score - oracle(widened)| {err:.2e}")
+        assert err <= 1e-5 and torch.equal(got16, f16(b16))
+        # table form: the gathered planes, three passes
+        tab = synth.make_device_batch(cfg.with_(num_candidates_data=1999), 1, 4, DEV)
+        table = EntityTable(tab[7][0], tab[8][0], tab[9][0], tab[10][0], tab[11][0])
+        cand = torch.randint(0, 2000, (512, cfg.num_candidates_model), device=DEV)
+        ib = IndexedBatch(batch[:7], table, cand, batch[12], batch[13])
+        assert torch.equal(f16(ib), x3(ib))
     f16.train()
     x3.train()
     g = []
@@ -348,6 +299,25 @@ def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
         TripletLoss(cfg.triplet_margin)(batch[14][:64], m([t[:64] for t in batch[:14]])).backward()
         g.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     assert all(torch.equal(g[0][k], g[1][k]) for k in g[0])
+
+
+def test_f16_image_contraction_is_blind_to_the_scale_of_the_weights():
+    """the folded weight W_h1 W_ei used to go to fp16 UNSCALED - entries below 6e-5 fall into fp16's subnormals, above
+    65 504 to infinity.  It is now one fp16 plane under one power-of-two scale (`drin_prepare`).  `entity_image_linear.weight`
+    scaled by 1e-4 and by 1e4 (the folded entries ~7e-7 and ~70: the first all subnormal as plain fp16): every score within 1e-5 of
+    the exact-fp32 path on the same weights, as at the default scale."""
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    B = 1024
+    batch = synth.make_device_batch(cfg, B, 56, DEV)[:14]
+    for factor in (1e-4, 1.0, 1e4):
+        sd = synth.make_state_dict(cfg, 7)
+        sd["vertex_encoder.entity_image_linear.weight"] = sd["vertex_encoder.entity_image_linear.weight"] * factor
+        exact, f16, x3 = _models(cfg, sd, "f32", "bf16x3_if16", "bf16x3")
+        with torch.no_grad():
+            ref, got, base = exact(batch), f16(batch), x3(batch)
+        err, err3 = (got - ref).abs().max().item(), (base - ref).abs().max().item()
+        print(f"W_ei x {factor:g}: bf16x3_if16 {err:.2e}, bf16x3 {err3:.2e} from the exact-fp32 path")
+        assert torch.isfinite(got).all() and err <= 1e-5 and not torch.equal(got, base)
 
 
 # ---- precision by storage: the per-entity cache's DRIN_CACHE_MIXED_F16 rows ---------------------------------------------
@@ -457,46 +427,15 @@ def test_mixed_f16_cache_rows_hold_rows_of_any_magnitude():
     assert (huge <= 1e-5).float().mean().item() >= 0.99
 
 
-def test_weight_gradient_one_pass_experiment_is_off_by_default_and_within_its_stated_error():
-    """`drin_set_weight_gradient_passes(1)` (measured, not adopted - profiles/r4_dw_one_pass.txt): the switch
-    changes the pair-sized weight gradients by ~2.5e-3 relative and nothing else (biases, LayerNorm and the mention-sized
-    products keep their bits); setting it back restores the default's bits."""
-    cfg = wikimel_config(max_entity_attr_token_len=4, batch_size=64)
-    sd = synth.make_state_dict(cfg, 7)
-    batch = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 64, 50, "cpu"), 0.15)]
-    lib = _lib.load()
-
-    def grads():
-        m = Model(cfg).to(DEV)
-        m.load_state_dict(sd)
-        TripletLoss(cfg.triplet_margin)(batch[14], m(batch[:14])).backward()
-        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-
-    base = grads()
-    assert lib.drin_set_weight_gradient_passes(2) == _lib.E_SHAPE
-    try:
-        _lib.check(lib.drin_set_weight_gradient_passes(1))
-        one = grads()
-    finally:
-        _lib.check(lib.drin_set_weight_gradient_passes(-1))
-    again = grads()
-    assert all(torch.equal(base[k], again[k]) for k in base)
-    moved = {k: ((one[k] - base[k]).norm() / base[k].norm()).item() for k in base}
-    pair_sized = [k for k in base if k.endswith("weight") and "layer_norm" not in k and "mention" not in k]
-    print({k: f"{v:.1e}" for k, v in moved.items()})
-    assert max(moved[k] for k in pair_sized) <= 6e-3 and max(moved[k] for k in pair_sized) >= 1e-4
-    assert all(v <= 6e-3 for v in moved.values())
-
-
 def test_precision_modes_on_trained_weights():
     """Every other precision test scores with freshly initialised weights.  Here the weights are TRAINED first - 40 Adam steps of
     the reference's loop (`train.py:30-56`) on the learnable synthetic stream at the reference's width and batch (D = 768, R = 2048,
     N = 101, B = 64), loss 0.25 -> ~0.03 - and 512 held-out mentions (a call large enough for the one-pass image contraction to
-    run) are scored in the exact-fp32 arithmetic, the default split-bf16 one and both precision-by-contraction modes with the same
+    run) are scored in the exact-fp32 arithmetic, the default split-bf16 one and the precision-by-contraction mode with the same
     weights.  Training steepens the map from the vertices to the score (top-minus-median score 0.06 -> 0.7) and every mode's
     absolute error grows with it (`profiles/r4_precision_on_trained_weights.txt`, 0 .. 400 steps): the default stays under the
-    1e-5 guard (4e-6), the fp16 pass inside the 1e-4 bar with a margin of five (2e-5), and the bf16 pass `bf16x3_i1` - 2e-5 at
-    initialisation - LEAVES the bar (1.6e-4): that mode is inside the bar near initialisation only, and this test pins the fact.
+    1e-5 guard (4e-6), the fp16 pass inside the 1e-4 bar with a margin of five (2e-5).  (The bf16 one-pass mode of round 4,
+    `bf16x3_i1` - 2e-5 at initialisation - LEFT the bar here, 1.6e-4, and was removed in round 5.)
     Rankings do not move: the same top-1 / top-5 counts and arg-max as the exact path for every mode."""
     from drin_amd.train import make_adam
     cfg = wikimel_config(max_entity_attr_token_len=8, batch_size=64)
@@ -517,14 +456,14 @@ def test_precision_modes_on_trained_weights():
     held = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, 512, 999, "cpu"), 0.15)]
     y = held[14].cpu()
     scores = {}
-    for prec in ("f32", "bf16x3", "bf16x3_if16", "bf16x3_i1"):
+    for prec in ("f32", "bf16x3", "bf16x3_if16"):
         m = Model(cfg, precision=prec).to(DEV).eval()
         m.load_state_dict(sd)
         with torch.no_grad():
             _lib.profile_begin()
             scores[prec] = m(held[:14]).cpu()
             prof = _lib.profile_end()
-        if prec in ("bf16x3_if16", "bf16x3_i1"):
+        if prec == "bf16x3_if16":
             assert prof["gemm_x3"][1] >= 1                       # (the one-pass product is of this class; 512 x 101 pairs fill the grid)
     ref = scores["f32"]
     counts = {p: {k: O.topk_counts(s, y, k)[0] for k in (1, 5)} for p, s in scores.items()}
@@ -534,8 +473,7 @@ def test_precision_modes_on_trained_weights():
     assert counts["f32"][1] >= 150                                # of 512: learnt
     assert errs["bf16x3"] <= 1e-5, errs                           # the default: under the suite's guard on trained weights too
     assert errs["bf16x3_if16"] <= 5e-5, errs                      # the fp16 pass: inside the bar (measured 2.0e-5)
-    assert 5e-5 <= errs["bf16x3_i1"] <= 5e-4, errs                # the bf16 pass: measured 1.6e-4 - outside the 1e-4 bar (documented)
-    for p in ("bf16x3", "bf16x3_if16", "bf16x3_i1"):
+    for p in ("bf16x3", "bf16x3_if16"):
         assert all(abs(counts[p][k] - counts["f32"][k]) <= 1 for k in (1, 5)), (p, counts)
         assert agree[p] >= 0.996, (p, agree)
     # the per-entity cache's two row formats on the same trained weights (the held-out pairs' entity rows as a table)

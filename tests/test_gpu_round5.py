@@ -166,20 +166,26 @@ def test_trained_weights_exact_and_default_arithmetic_against_the_oracle():
 
 # ---- (d) mixed-f16 cache rows on entity rows of extreme magnitude: both formats against the fp64 oracle ---------------------
 def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
-    """`test_mixed_f16_cache_rows_hold_rows_of_any_magnitude` (round 4) found the two row formats > 1e-5 apart on ~1 % of the scores
-    of mentions whose candidates include entities with image rows scaled by 1e6 .. 3e37, and argued - without a yardstick - that
-    "the fp32 rows' own logit is then good to 1e-2".  Here BOTH formats meet the fp64 oracle on the gathered 14-sequence
-    (`model.py:121-153` in double precision).  Such an entity's edge-update operand W_v1(ei0) is ~1e5 .. 1e37 in size; the edge logit
-    mean_d(W_u(u) W_v(v)) (`model.py:148-153`) then either saturates the sigmoid (both formats exact) or - when its terms happen to
-    cancel to a few units - is noise in ANY finite format: fp32 keeps 24 bits of 1e5-sized terms, the scaled fp16 field 11.
-    Asserted: (1) mentions WITHOUT such candidates (rows x 1e-6, x 1e-30, zero rows, zero object scores next to ordinary ones): both
-    formats within 1e-5 of the fp64 oracle; (2) for every score where the formats differ by > 1e-5, the fp32-row score is itself
-    > 1e-5 from the fp64 oracle or the differing mention holds a candidate whose fp64 edge logit is unsaturated while its terms are
-    >= 1e4 times larger (an ill-conditioned input by construction) - and the count of such scores is reported."""
+    """`test_mixed_f16_cache_rows_hold_rows_of_any_magnitude` (round 4) compares the two row formats with EACH OTHER on tables whose
+    image rows are scaled by 1e-30 .. 3e37 and argued - without a yardstick - about the mentions where they differed.  Here BOTH
+    formats meet the oracle on the gathered 14-sequence (`model.py:121-153`), in fp32 (what the reference computes) and in fp64 (the
+    arbiter of rounding), in three groups of mentions:
+      A  candidates with image rows x 1e-6, x 1e-30, an all-zero image row, an all-zero object score next to ordinary ones:
+         both formats within 1e-5 of the fp64 oracle;
+      B  additionally three candidates with rows x 1e6 (W_v1(ei0) ~ 3e5: inf as plain fp16, held by the field's power-of-two scale).
+         Such a candidate's edge logit mean_d(W_u(u) W_v(v)) (`model.py:148-153`) is a sum of 768 terms of size ~1e5 - typically
+         +-4e3, a saturated sigmoid, which any format reproduces.  Where the terms happen to CANCEL to a few units the fp32 rows still
+         hold the logit to ~1e-3 (24 bits of 1e5), the fp16 field to ~1 (11 bits): THAT is where the formats part - measured here:
+         the fp32 rows stay within 1e-6 of the fp64 oracle, the mixed rows reach 6.7e-5 on such a mention (inside the 1e-4 bar, outside
+         the 1e-5 guard).  The test pins the cause: every mention whose mixed-row scores are > 1e-5 off holds a x 1e6 candidate with an
+         UNSATURATED layer-1 edge in the fp64 oracle; all other mentions are within 1e-5 in both formats.  The format's contract
+         (include/drin_hip.h, drin_cache_format) states it: fp16 fields hold an edge logit to 2^-12 of the size of its TERMS;
+      C  additionally a row scaled to 3e37: its layer-1 pre-activations are ~1e37 and their LayerNorm variance overflows fp32 in the
+         reference itself (`model.py:128`) - fp64 is no yardstick there; the formats must agree with each other and stay finite."""
     from drin_amd.model import EntityTable, IndexedBatch
     cfg = wikimel_config(max_entity_attr_token_len=4)
     sd = synth.make_state_dict(cfg, 7)
-    E, B, N = 600, 64, cfg.num_candidates_model
+    E, B, N = 600, 96, cfg.num_candidates_model
     g = torch.Generator(device=DEV).manual_seed(3)
     img = torch.randn(E, cfg.resnet_embed_dim, device=DEV, generator=g)
     img[0:50] *= 1e6
@@ -192,10 +198,12 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
     table = EntityTable(torch.randn(E, 4, cfg.bert_embed_dim, device=DEV, generator=g), torch.ones(E, 4, dtype=torch.int64, device=DEV),
                         img, torch.randn(E, 1, cfg.resnet_embed_dim, device=DEV, generator=g), score)
     men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 12, DEV)
-    cand = torch.randint(50, E, (B, N), device=DEV, generator=g)
+    cand = torch.randint(50, E, (B, N), device=DEV, generator=g)                       # rows 0-49 (x 1e6) only where planted
     cand[cand == 150] = 153
-    cand[:, :5] = torch.tensor([60, 120, 151, 152, 300], device=DEV)
-    cand[B // 2:, 5:9] = torch.tensor([0, 17, 49, 150], device=DEV)                    # second half: the huge rows as well
+    cand[:, :5] = torch.tensor([60, 120, 151, 152, 300], device=DEV)                   # every mention: small, tiny, zero rows
+    third = B // 3
+    cand[third:, 5:8] = torch.tensor([0, 17, 49], device=DEV)                          # groups B, C: rows x 1e6
+    cand[2 * third:, 8] = 150                                                          # group C: the 3e37 row
     sims = 20.0 + 5.0 * torch.randn(2, B, N, device=DEV, generator=g)
     ib = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
     model = Model(cfg).to(DEV).eval()
@@ -209,25 +217,29 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
     assert torch.isfinite(mixed).all() and torch.isfinite(full).all()
     _threads()
     host = [t.cpu() for t in ib.gathered()]
+    ab = slice(0, 2 * third)
+    trace = {}
     with torch.no_grad():
-        ref64 = O.forward({k: v.double() for k, v in sd.items()}, host, dtype=torch.float64)
-    e32, e16, d = (full.double() - ref64).abs(), (mixed.double() - ref64).abs(), (mixed - full).abs()
-    h = B // 2
-    print(f"ordinary / tiny / zero rows: fp32 rows {e32[:h].max().item():.2e}, mixed-f16 rows {e16[:h].max().item():.2e} from the fp64 oracle")
-    assert e32[:h].max().item() <= 1e-5 and e16[:h].max().item() <= 1e-5
-    differ = d[h:] > 1e-5
-    n_diff = int(differ.sum())
-    if n_diff:
-        sel32, sel16 = e32[h:][differ], e16[h:][differ]
-        rows = differ.any(1).nonzero().flatten().tolist()
-        print(f"huge rows among the candidates: {n_diff} of {differ.numel()} scores differ by > 1e-5 between the formats, in mentions {rows}; on those "
-              f"scores the fp32 rows are {sel32.min().item():.2e} .. {sel32.max().item():.2e} and the mixed-f16 rows {sel16.min().item():.2e} .. "
-              f"{sel16.max().item():.2e} from the fp64 oracle")
-    else:
-        print("huge rows among the candidates: no score differs by > 1e-5 between the formats")
-    print(f"second half overall: fp32 rows max {e32[h:].max().item():.2e} (median {e32[h:].median().item():.2e}), mixed-f16 rows max {e16[h:].max().item():.2e} "
-          f"(median {e16[h:].median().item():.2e}) from the fp64 oracle")
-    # the scores the formats agree on are good in both
-    agree = ~differ
-    assert e16[h:][agree].max().item() <= 2e-5 + e32[h:][agree].max().item()
-    assert differ.float().mean().item() <= 0.01
+        ref32 = O.forward(sd, [t[ab] for t in host])
+        ref64 = O.forward({k: v.double() for k, v in sd.items()}, [t[ab] for t in host], dtype=torch.float64, trace=trace)
+    own = (ref32.double() - ref64).abs()
+    e32, e16 = (full[ab].double() - ref64).abs(), (mixed[ab].double() - ref64).abs()
+    d = (mixed - full).abs()
+    a_rows, b_rows = slice(0, third), slice(third, 2 * third)
+    print(f"group A: fp32 oracle vs fp64 {own[a_rows].max().item():.2e}; fp32 rows {e32[a_rows].max().item():.2e}, mixed-f16 rows "
+          f"{e16[a_rows].max().item():.2e} from the fp64 oracle; formats apart {d[a_rows].max().item():.2e}")
+    assert own[a_rows].max().item() <= 1e-5 and e32[a_rows].max().item() <= 1e-5 and e16[a_rows].max().item() <= 1e-5
+    # group B: the layer-1 edges (ti, ii: the two that read the image vertex; model.py:107) of the three x 1e6 candidates, fp64
+    edges1 = torch.stack([trace["edge1"][1], trace["edge1"][3]])[:, b_rows, 5:8]                # [2, third, 3]
+    unsat = ((edges1 > 1e-4) & (edges1 < 1 - 1e-4)).any(0).any(-1)                                # per mention
+    off = e16[b_rows].max(1).values > 1e-5
+    print(f"group B: fp32 oracle vs fp64 {own[b_rows].max().item():.2e}; fp32 rows {e32[b_rows].max().item():.2e} from the fp64 oracle; mixed-f16 rows: "
+          f"{int(off.sum())} of {third} mentions > 1e-5 (max {e16[b_rows].max().item():.2e}), {int(unsat.sum())} mentions hold a x 1e6 candidate with an "
+          f"unsaturated layer-1 edge; on the other mentions mixed-f16 rows {e16[b_rows][~unsat].max().item():.2e}")
+    assert own[b_rows].max().item() <= 1e-5 and e32[b_rows].max().item() <= 1e-5          # the fp32 rows are NOT noise there
+    assert bool((~off | unsat).all()), "a mention is off without an unsaturated edge of a huge-row candidate: another cause"
+    assert e16[b_rows][~unsat].max().item() <= 1e-5
+    assert e16[b_rows].max().item() <= 1e-3 and int(off.sum()) <= 3
+    c = slice(2 * third, B)
+    print(f"group C (a 3e37 row among the candidates): finite; formats apart max {d[c].max().item():.2e}, {(d[c] <= 1e-5).float().mean().item():.4f} within 1e-5")
+    assert (d[c] <= 1e-5).float().mean().item() >= 0.95

@@ -149,7 +149,7 @@ def test_precision_by_contraction_emulation():
     """VERDICT r3 item 2, the emulation reproduced (oracle/precision_emulation.py: the oracle in fp64, the operands of ONE
     folded contraction rounded to bf16, everything else exact; WikiMEL-shaped, N = 101): the entity-image contraction in one
     pass moves the scores by ~2e-5 - its result meets the score through a mean over the candidates - while either D x D
-    contraction moves them by ~3e-4, outside the 1e-4 bar.  That asymmetry is what `precision="bf16x3_i1"` is built on."""
+    contraction moves them by ~3e-4, outside the 1e-4 bar.  That asymmetry is what `precision="bf16x3_if16"` is built on."""
     import torch
     from drin_amd import synth
     from drin_amd.config import wikimel_config

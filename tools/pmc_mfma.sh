@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_mfma
-TAG=${1:-r3}
+TAG=${1:-r5}
 rm -rf $O && mkdir -p $O
 CNT="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE"
 run() {  # section, bench arguments
@@ -14,7 +14,7 @@ run() {  # section, bench arguments
   echo "[pmc_mfma] $sec done"
 }
 run wikimel_b4096 --steps 3 --warmup 1 --no-cpu-baseline --legs none
-run wikimel_b4096_mixed --precision bf16x3_i1 --steps 3 --warmup 1 --no-cpu-baseline --legs none
+run wikimel_b4096_if16 --precision bf16x3_if16 --steps 3 --warmup 1 --no-cpu-baseline --legs none
 run wikidiverse_b16384 --workload wikidiverse --steps 3 --warmup 1 --no-cpu-baseline --legs none
 run train_b64 --mode train --batch 64 --steps 5 --warmup 5
 run train_b512 --mode train --batch 512 --steps 3 --warmup 3

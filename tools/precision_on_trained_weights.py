@@ -27,7 +27,7 @@ opt = make_adam(model, cfg.learning_rate)
 loss_fn = TripletLoss(cfg.triplet_margin)
 held = [t.to(DEV) for t in synth.plant_gold_signal(cfg, synth.make_device_batch(cfg, HELD, 999, "cpu"), strength)]
 y = held[14].cpu()
-modes = ("bf16x3", "bf16x3_if16", "bf16x3_i1", "bf16")
+modes = ("bf16x3", "bf16x3_if16")
 print(f"gold signal strength {strength}; columns: max |score - exact fp32| over the held-out scores (top-1 agreement with the exact path)")
 step, loss = 0, float("nan")
 CHECKPOINTS = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 20, 40, 100, 200, 400)

@@ -30,7 +30,7 @@ def variant(name):
 for name in ("gaussian", "relu_images", "bert_outliers", "both", "scaled_x30"):
     b = variant(name)
     out = {}
-    for prec in ("f32", "bf16x3", "bf16x3_if16", "bf16x3_i1"):
+    for prec in ("f32", "bf16x3", "bf16x3_if16"):
         m = Model(cfg, precision=prec).to(DEV).eval()
         m.load_state_dict(sd)
         with torch.no_grad():
@@ -38,4 +38,4 @@ for name in ("gaussian", "relu_images", "bert_outliers", "both", "scaled_x30"):
     ref = out["f32"]
     spread = float((ref[:, :-1].max(1).values - ref[:, :-1].median(1).values).mean())
     print(f"{name:14s} scores in [{float(ref.min()):+.3f}, {float(ref.max()):+.3f}] top-minus-median {spread:.3f}: " +
-          "  ".join(f"{p} {float((out[p] - ref).abs().max()):.2e} (top-1 {float((out[p][:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean()):.4f})" for p in ("bf16x3", "bf16x3_if16", "bf16x3_i1")), flush=True)
+          "  ".join(f"{p} {float((out[p] - ref).abs().max()):.2e} (top-1 {float((out[p][:, :-1].argmax(1) == ref[:, :-1].argmax(1)).float().mean()):.4f})" for p in ("bf16x3", "bf16x3_if16")), flush=True)

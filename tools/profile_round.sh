@@ -5,47 +5,47 @@
 #   tools/pmc_mfma.sh (separate call: it writes gpurun_out/pmc_mfma/).
 # rocprofv3: program directly after `--`, counters in their own passes.
 set -e
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round
 rm -rf $O && mkdir -p $O
 HEAD="--no-cpu-baseline --legs none"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/wm -- python3 bench.py --steps 10 --warmup 3 $HEAD > $O/wm_bench_under_rocprof.json 2> $O/wm.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/wm -- python3 bench.py --steps 10 --warmup 3 $HEAD --legs-file $O/wm_bench_under_rocprof.json > /dev/null 2> $O/wm.err
 echo "[profile_round] default kernel stats done"
-python3 bench.py > $O/wm_bench.json 2> $O/wm_bench.err
+python3 bench.py --legs-file $O/wm_bench.json > $O/wm_bench_line.json 2> $O/wm_bench.err
 echo "[profile_round] full default line done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 $HEAD > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 $HEAD > $O/pmc_write.log 2>&1
 python3 tools/collect_pmc.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic.json kernels > $O/hbm_traffic.txt
 echo "[profile_round] default PMC done"
-# the mixed-precision leg (bf16x3_i1: x_i C_i^T in one bf16 pass) and the bf16-stored-features leg: kernel stats of their own commands
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/mixed -- python3 bench.py --precision bf16x3_i1 --steps 10 --warmup 3 $HEAD > $O/mixed_bench_under_rocprof.json 2> $O/mixed.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16f -- python3 bench.py --features bf16 --steps 10 --warmup 3 $HEAD > $O/bf16f_bench_under_rocprof.json 2> $O/bf16f.err
+# the bf16-stored-features leg (three-pass and with the fp16 image contraction): kernel stats of their own commands
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16f_if16 -- python3 bench.py --features bf16 --precision bf16x3_if16 --steps 10 --warmup 3 $HEAD --legs-file $O/bf16f_if16_bench_under_rocprof.json > /dev/null 2> $O/bf16f_if16.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16f -- python3 bench.py --features bf16 --steps 10 --warmup 3 $HEAD --legs-file $O/bf16f_bench_under_rocprof.json > /dev/null 2> $O/bf16f.err
 echo "[profile_round] mixed precision / bf16 features done"
 TAB="--workload table --batch 4096 --entity-cache"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/tab -- python3 bench.py $TAB --steps 5 --warmup 2 $HEAD > $O/table_cache_bench_under_rocprof.json 2> $O/tab.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tab -- python3 bench.py $TAB --steps 5 --warmup 2 $HEAD --legs-file $O/table_cache_bench_under_rocprof.json > /dev/null 2> $O/tab.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tab -- python3 bench.py $TAB --steps 2 --warmup 1 $HEAD > $O/pmc_fetch_tab.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_tab -- python3 bench.py $TAB --steps 2 --warmup 1 $HEAD > $O/pmc_write_tab.log 2>&1
 python3 tools/collect_pmc.py $O/pmc_fetch_tab $O/pmc_write_tab $O/hbm_traffic.json kernels_table_cache "python3 bench.py $TAB --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
 # the same chunk from DRIN_CACHE_MIXED_F16 rows: kernel stats + its own PMC passes (section kernels_table_cache_mixed_f16)
 TABM="$TAB --cache-format mixed_f16"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/tabm -- python3 bench.py $TABM --steps 5 --warmup 2 $HEAD > $O/table_cache_mixed_f16_bench_under_rocprof.json 2> $O/tabm.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tabm -- python3 bench.py $TABM --steps 5 --warmup 2 $HEAD --legs-file $O/table_cache_mixed_f16_bench_under_rocprof.json > /dev/null 2> $O/tabm.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tabm -- python3 bench.py $TABM --steps 2 --warmup 1 $HEAD > $O/pmc_fetch_tabm.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_tabm -- python3 bench.py $TABM --steps 2 --warmup 1 $HEAD > $O/pmc_write_tabm.log 2>&1
 python3 tools/collect_pmc.py $O/pmc_fetch_tabm $O/pmc_write_tabm $O/hbm_traffic.json kernels_table_cache_mixed_f16 "python3 bench.py $TABM --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
 echo "[profile_round] table cache done"
 # WikiDiverse-shaped (BASELINE config 2): kernel stats of the default arithmetic (the one-pass image contraction is gated on N >= 64)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/wd -- python3 bench.py --workload wikidiverse --steps 10 --warmup 3 $HEAD > $O/wd_bench_under_rocprof.json 2> $O/wd.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/wd -- python3 bench.py --workload wikidiverse --steps 10 --warmup 3 $HEAD --legs-file $O/wd_bench_under_rocprof.json > /dev/null 2> $O/wd.err
 # the fp16 image contraction at the headline's shape (the mode's own kernel stats)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/if16 -- python3 bench.py --precision bf16x3_if16 --steps 10 --warmup 3 $HEAD > $O/if16_bench_under_rocprof.json 2> $O/if16.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/if16 -- python3 bench.py --precision bf16x3_if16 --steps 10 --warmup 3 $HEAD --legs-file $O/if16_bench_under_rocprof.json > /dev/null 2> $O/if16.err
 echo "[profile_round] wikidiverse done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 > $O/train64_bench_under_rocprof.json 2> $O/train.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train512 -- python3 bench.py --mode train --batch 512 --steps 20 --warmup 30 > $O/train512_bench_under_rocprof.json 2> $O/train512.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_rccl -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 --force-collective > $O/train64_rccl_world1_bench_under_rocprof.json 2> $O/train_rccl.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 --legs-file $O/train64_bench_under_rocprof.json > /dev/null 2> $O/train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train512 -- python3 bench.py --mode train --batch 512 --steps 20 --warmup 30 --legs-file $O/train512_bench_under_rocprof.json > /dev/null 2> $O/train512.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_rccl -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 --force-collective --legs-file $O/train64_rccl_world1_bench_under_rocprof.json > /dev/null 2> $O/train_rccl.err
 echo "[profile_round] training done"
-python3 bench.py --workload table --entity-cache --mentions 1000000 --chunk 4096 > $O/config5_1M_stream.json 2> $O/config5.err
+python3 bench.py --workload table --entity-cache --mentions 1000000 --chunk 4096 --legs-file $O/config5_1M_stream.json > /dev/null 2> $O/config5.err
 echo "[profile_round] config 5 full stream done"
-for i in 1 2; do python3 bench.py > $O/wm_bench_$i.json 2>> $O/wm_bench.err; done
+for i in 1 2; do python3 bench.py --legs-file $O/wm_bench_$i.json > $O/wm_bench_line_$i.json 2>> $O/wm_bench.err; done
 echo "[profile_round] two more default lines done"
 bash tools/pmc_mfma.sh $TAG > $O/pmc_mfma.log 2>&1 && cp gpurun_out/pmc_mfma/${TAG}_mfma_pmc.json gpurun_out/pmc_mfma/summary.txt $O/
 echo "[profile_round] SQ / MFMA counter passes done"

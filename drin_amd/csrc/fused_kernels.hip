@@ -630,6 +630,10 @@ int launch_mention_input2(const float* part, const float* mt1, float* out, int B
 // Layer-2 entity-text vertex and the score (model.py:128 for et'', :207-209), grid (chunks, B), 256 threads:
 //   et2 = gelu(LN(H2raw[p] + e1_tt hm2_t[b] + e1_it hm2_i[b] + b_h2)),  score[p] = cos(mt2[b], et2)
 // The five per-mention / constant vectors live in LDS; each wave walks candidates of its chunk.
+// (Measured in round 5 and dropped - profiles/r5_pair_final_two_rows_ab.txt: two candidates per wave and trip, so that one row's four
+//  dependent wave reductions fill the other's waits.  133 VGPRs instead of 100 = three waves per SIMD instead of five: config 5's
+//  3.39 ms became 3.75, the headline's row kernels 1.13 -> 1.17 ms.  Round 4's tries on the same kernel: single-round LayerNorm
+//  statistics, the next row prefetched - profiles/r4_ln_stats_ab.txt, r4_pair_final_prefetch_ab.txt.)
 template <int DV, bool EXACT, bool GENERIC_ACT = false>
 __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
   __shared__ __attribute__((aligned(16))) float l_const[6 * DV * 256];  // hm2_t, hm2_i, b_h2, gamma, beta, mt2

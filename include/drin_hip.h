@@ -116,11 +116,12 @@ typedef struct {
  * entity, 16 400 B instead of 23 568 at D = 768, R = 2 048.  Effect on the scores: 2e-7 at N = 101, 6e-7 at N = 11
  * (oracle/precision_emulation.py; measured: tests/test_gpu_round4.py) - below the split-bf16 contractions' own 1.3e-6; with
  * TRAINED weights <= 3e-6 at N = 101 and <= 1.7e-5 at N = 11 against the fp32 rows (profiles/r4_precision_on_trained_weights.txt).
- * The limit of the format: an fp16 field holds an edge logit mean_d(W_u(u) W_v(v)) to 2^-12 of the size of its TERMS.  For feature
- * rows of ordinary size (|x| up to ~1e3 x unit scale) that is below 1e-5 on the scores; for an entity whose image row is scaled by
- * 1e6 (terms ~1e5) the sigmoid is normally saturated and nothing moves, but a logit whose terms cancel to within a few units is then
- * held to ~1 by the fp16 field where the fp32 row holds it to ~1e-3: measured 6.7e-5 on the scores of such a mention against the
- * fp64 oracle, the fp32 rows 9e-7 (tests/test_gpu_round5.py).  Tables with rows that far off scale: DRIN_CACHE_F32.
+ * The limit of the format: an fp16 field holds its per-pair scalar (an edge logit, the static image-image edge) to ~1e-5, which the
+ * mention aggregates mean_n(edge x vertex) (model.py:143-144) average over the N candidates.  A candidate whose image row is 1e6 times
+ * the others' DOMINATES that mean, and the aggregate then inherits the error of its ONE edge: measured 1e-5 .. 7e-5 on the scores of
+ * such mentions against the fp64 oracle (fp32 rows: 9e-7), reproduced to 1e-5 by the fp64 oracle with the three fields passed through
+ * the format's rounding (tests/test_gpu_round5.py).  Inside the 1e-4 bar, outside the 1e-5 guard: tables with rows that far off
+ * scale belong in DRIN_CACHE_F32.
  * Needs embed_dim % 8 == 0 and image_dim % 8 == 0. */
 typedef enum {
   DRIN_CACHE_F32 = 0,

@@ -416,13 +416,18 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DRIN_BENCH_SHARE_GPU="1", DRIN_BENCH_BACKEND="gloo")
+    import tempfile
+    full_path = os.path.join(tempfile.mkdtemp(prefix="drin_bench_"), "full.json")
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--mode", "train", "--batch", "16", "--steps", "3",
-                        "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+                        "--warmup", "2", "--legs-file", full_path], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096                  # ONE headline line the driver can parse (round 4's was 32 KB)
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["config"]["global_batch"] == 32
     assert line["allreduce_ms"] > 0 and line["allreduce_bytes"] == 26775552 and 0 < line["final_loss"] < 1
-    assert "library Adam" in line["optimizer"]
+    assert line["collective"]["world"] == 2 and len(line["rank_roofline_avg_launch_ms"]) == 2 and "expected_weak_scaling_efficiency" in line["scaling_model"]
+    assert "library Adam" in json.load(open(full_path))["optimizer"]  # the full record: in the legs file
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "2", "--warmup", "1",
                         "--legs", "none", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -389,11 +389,14 @@ def test_rccl_process_group_of_one_rank_drives_the_real_collectives():
 def test_bench_force_collective_reports_a_nonzero_rccl_allreduce():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    full_path = os.path.join(tempfile.mkdtemp(prefix="drin_bench_"), "full.json")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--mode", "train", "--gpus", "1", "--force-collective", "--batch", "64",
-                        "--steps", "5", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=900)
+                        "--steps", "5", "--warmup", "5", "--legs-file", full_path], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    head = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[:500]   # RCCL's banner went to stderr
+    assert head["collective"]["backend"] == "nccl" and head["collective"]["world"] == 1 and head["allreduce_ms"] > 0
+    line = json.load(open(full_path))                                                       # the full record: in the legs file
     c = line["collective"]
     assert c["backend"] == "nccl" and c["world"] == 1 and c["forced_world_of_one"] and c["overlap"] == "forward" and c["in_place"]
     assert c["steps_overlapped_under_next_forward"] >= 10 and line["allreduce_ms"] > 0 and line["allreduce_exposed_ms"] >= 0

@@ -172,14 +172,15 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
     arbiter of rounding), in three groups of mentions:
       A  candidates with image rows x 1e-6, x 1e-30, an all-zero image row, an all-zero object score next to ordinary ones:
          both formats within 1e-5 of the fp64 oracle;
-      B  additionally three candidates with rows x 1e6 (W_v1(ei0) ~ 3e5: inf as plain fp16, held by the field's power-of-two scale).
-         Such a candidate's edge logit mean_d(W_u(u) W_v(v)) (`model.py:148-153`) is a sum of 768 terms of size ~1e5 - typically
-         +-4e3, a saturated sigmoid, which any format reproduces.  Where the terms happen to CANCEL to a few units the fp32 rows still
-         hold the logit to ~1e-3 (24 bits of 1e5), the fp16 field to ~1 (11 bits): THAT is where the formats part - measured here:
-         the fp32 rows stay within 1e-6 of the fp64 oracle, the mixed rows reach 6.7e-5 on such a mention (inside the 1e-4 bar, outside
-         the 1e-5 guard).  The test pins the cause: every mention whose mixed-row scores are > 1e-5 off holds a x 1e6 candidate with an
-         UNSATURATED layer-1 edge in the fp64 oracle; all other mentions are within 1e-5 in both formats.  The format's contract
-         (include/drin_hip.h, drin_cache_format) states it: fp16 fields hold an edge logit to 2^-12 of the size of its TERMS;
+      B  additionally three candidates with rows x 1e6 (W_v1(ei0) ~ 3e5: inf as plain fp16, held by the field's power-of-two scale;
+         their dynamic edges saturate the sigmoid in either format).  What parts the formats there is the STATIC image-image edge
+         (`model.py:84-92`): the fp16 object row holds it to ~1e-5, and that edge multiplies the candidate's layer-1 image vertex in the
+         mention aggregate mean_n(ii ei) (`model.py:143-144`) - a vertex 1e6 times the others' DOMINATES the mean, so the aggregate
+         inherits the relative error of ONE edge instead of averaging 101 of them.  Measured: the fp32 rows stay within 1e-6 of the
+         fp64 oracle, the mixed rows are 1e-5 .. 7e-5 off on half of such mentions (inside the 1e-4 bar, outside the 1e-5 guard).
+         The test pins the cause by EMULATION: the fp64 oracle with exactly the three fp16 fields passed through the format's
+         rounding (`oracle/precision_emulation.py`) reproduces the HIP scores of the mixed rows to 1e-5 - the deviation is the
+         storage format's and nothing else's (`include/drin_hip.h`, drin_cache_format, states the limit);
       C  additionally a row scaled to 3e37: its layer-1 pre-activations are ~1e37 and their LayerNorm variance overflows fp32 in the
          reference itself (`model.py:128`) - fp64 is no yardstick there; the formats must agree with each other and stay finite."""
     from drin_amd.model import EntityTable, IndexedBatch
@@ -229,17 +230,20 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
     print(f"group A: fp32 oracle vs fp64 {own[a_rows].max().item():.2e}; fp32 rows {e32[a_rows].max().item():.2e}, mixed-f16 rows "
           f"{e16[a_rows].max().item():.2e} from the fp64 oracle; formats apart {d[a_rows].max().item():.2e}")
     assert own[a_rows].max().item() <= 1e-5 and e32[a_rows].max().item() <= 1e-5 and e16[a_rows].max().item() <= 1e-5
-    # group B: the layer-1 edges (ti, ii: the two that read the image vertex; model.py:107) of the three x 1e6 candidates, fp64
-    edges1 = torch.stack([trace["edge1"][1], trace["edge1"][3]])[:, b_rows, 5:8]                # [2, third, 3]
-    unsat = ((edges1 > 1e-4) & (edges1 < 1 - 1e-4)).any(0).any(-1)                                # per mention
+    # group B: what the format's rounding of its three fp16 fields does to the fp64 forward - and nothing else - is what the HIP path shows
+    from oracle.precision_emulation import MIXED_F16_FIELDS, scores_with_rounded_cache_fields
+    with torch.no_grad():
+        emul = scores_with_rounded_cache_fields({k: v.double() for k, v in sd.items()}, [t[b_rows] for t in host], MIXED_F16_FIELDS)
+        only_ohat = scores_with_rounded_cache_fields({k: v.double() for k, v in sd.items()}, [t[b_rows] for t in host], ("ohat",))
+    fmt = (emul - ref64[b_rows]).abs()                                   # the format's own effect, emulated
     off = e16[b_rows].max(1).values > 1e-5
     print(f"group B: fp32 oracle vs fp64 {own[b_rows].max().item():.2e}; fp32 rows {e32[b_rows].max().item():.2e} from the fp64 oracle; mixed-f16 rows: "
-          f"{int(off.sum())} of {third} mentions > 1e-5 (max {e16[b_rows].max().item():.2e}), {int(unsat.sum())} mentions hold a x 1e6 candidate with an "
-          f"unsaturated layer-1 edge; on the other mentions mixed-f16 rows {e16[b_rows][~unsat].max().item():.2e}")
+          f"{int(off.sum())} of {third} mentions > 1e-5 (max {e16[b_rows].max().item():.2e}); emulated format effect max {fmt.max().item():.2e} "
+          f"(the object row alone: {(only_ohat - ref64[b_rows]).abs().max().item():.2e}); HIP mixed rows vs the emulation {(mixed[b_rows].double() - emul).abs().max().item():.2e}")
     assert own[b_rows].max().item() <= 1e-5 and e32[b_rows].max().item() <= 1e-5          # the fp32 rows are NOT noise there
-    assert bool((~off | unsat).all()), "a mention is off without an unsaturated edge of a huge-row candidate: another cause"
-    assert e16[b_rows][~unsat].max().item() <= 1e-5
-    assert e16[b_rows].max().item() <= 1e-3 and int(off.sum()) <= 3
+    assert (mixed[b_rows].double() - emul).abs().max().item() <= 1e-5                      # the deviation IS the storage format's rounding
+    assert (only_ohat - emul).abs().max().item() <= 1e-5                                   # ... of the object row (the static ii edge)
+    assert e16[b_rows].max().item() <= 2e-4
     c = slice(2 * third, B)
     print(f"group C (a 3e37 row among the candidates): finite; formats apart max {d[c].max().item():.2e}, {(d[c] <= 1e-5).float().mean().item():.4f} within 1e-5")
     assert (d[c] <= 1e-5).float().mean().item() >= 0.95

@@ -243,12 +243,13 @@ def test_f16_image_contraction_is_blind_to_the_scale_of_the_rows():
     img[3, 5] = 0.0
     img[4] *= 1e-30
     img[5, 7] *= 3e37 / img[5, 7].abs().max()
+    img[6, 9] *= 3.0e38 / img[6, 9].abs().max()                     # the top binade: the row scale is clamped to 2^126 (its reciprocal stays normal)
     exact, f16 = _models(cfg, sd, "f32", "bf16x3_if16")
     with torch.no_grad():
         ref, got = exact(batch), f16(batch)
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item()
-    print(f"rows scaled by 1e6 / 1e-6 / 3e4 / 0 / 1e-30 / up to 3e37: max |score - exact fp32| {err:.2e}")
+    print(f"rows scaled by 1e6 / 1e-6 / 3e4 / 0 / 1e-30 / up to 3e37 and 3e38: max |score - exact fp32| {err:.2e}")
     assert err <= 1e-5
     assert (got[:, :-1].argmax(1) == ref[:, :-1].argmax(1)).all()
 

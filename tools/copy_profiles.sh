@@ -18,12 +18,12 @@ cp $O/train512_bench_under_rocprof.json $P/${R}_train_b512_bench_under_rocprof.j
 cp $O/train64_rccl_world1_bench_under_rocprof.json $P/${R}_train_b64_rccl_world1_bench_under_rocprof.json
 cp $O/config5_1M_stream.json $P/${R}_config5_1M_mentions_streamed.json
 cp $O/hbm_traffic.json $P/${R}_hbm_traffic.json
-cp $O/${R}_mfma_pmc.json $P/${R}_mfma_pmc.json
+cp gpurun_out/pmc_mfma/${R}_mfma_pmc.json $P/${R}_mfma_pmc.json
 cp "$(stats bf16f_if16)" $P/${R}_wikimel_b4096_bf16_features_if16_kernel_stats.csv
 cp "$(stats bf16f)" $P/${R}_wikimel_b4096_bf16_features_kernel_stats.csv
 cp $O/bf16f_if16_bench_under_rocprof.json $P/${R}_wikimel_b4096_bf16_features_if16_bench_under_rocprof.json
 cp $O/bf16f_bench_under_rocprof.json $P/${R}_wikimel_b4096_bf16_features_bench_under_rocprof.json
-cp $O/summary.txt $P/${R}_mfma_pmc_summary.txt
+cp gpurun_out/pmc_mfma/summary.txt $P/${R}_mfma_pmc_summary.txt
 cp "$(stats tabm)" $P/${R}_table_cache_mixed_f16_b4096_kernel_stats.csv
 cp $O/table_cache_mixed_f16_bench_under_rocprof.json $P/${R}_table_cache_mixed_f16_b4096_bench_under_rocprof.json
 cp "$(stats wd)" $P/${R}_wikidiverse_b16384_kernel_stats.csv
@@ -34,3 +34,5 @@ cp $O/if16_bench_under_rocprof.json $P/${R}_wikimel_b4096_mixed_bf16x3_if16_benc
 cat $O/wm_bench.json $O/wm_bench_1.json $O/wm_bench_2.json > $P/${R}_wikimel_b4096_bench_all_legs.json
 cat $O/wm_bench_line.json $O/wm_bench_line_1.json $O/wm_bench_line_2.json > $P/${R}_wikimel_b4096_bench_stdout_lines.json
 ls -la $P | grep ${R}_ | wc -l
+# every figure DESIGN.md quotes from these files must agree with them to 3 % (tags: tools/check_design_numbers.py)
+python3 tools/check_design_numbers.py DESIGN.md

@@ -9,6 +9,7 @@ TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round
 rm -rf $O && mkdir -p $O
+export PYTHONUNBUFFERED=1
 HEAD="--no-cpu-baseline --legs none"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wm -- python3 bench.py --steps 10 --warmup 3 $HEAD --legs-file $O/wm_bench_under_rocprof.json > /dev/null 2> $O/wm.err
 echo "[profile_round] default kernel stats done"
@@ -47,6 +48,6 @@ python3 bench.py --workload table --entity-cache --mentions 1000000 --chunk 4096
 echo "[profile_round] config 5 full stream done"
 for i in 1 2; do python3 bench.py --legs-file $O/wm_bench_$i.json > $O/wm_bench_line_$i.json 2>> $O/wm_bench.err; done
 echo "[profile_round] two more default lines done"
-bash tools/pmc_mfma.sh $TAG > $O/pmc_mfma.log 2>&1 && cp gpurun_out/pmc_mfma/${TAG}_mfma_pmc.json gpurun_out/pmc_mfma/summary.txt $O/
-echo "[profile_round] SQ / MFMA counter passes done"
+# (the SQ / MFMA counter passes are their own gpurun call: bash tools/pmc_mfma.sh $TAG, which leaves gpurun_out/pmc_mfma/${TAG}_mfma_pmc.json
+#  and summary.txt; tools/copy_profiles.sh picks them up from there)
 ls $O

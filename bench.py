@@ -331,7 +331,7 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
         # precision each algorithmic multiply-add is three bf16 MFMAs: `executed_*` is the matrix-core rate
         if dom == "gemm_planes":
             step_flops = pairs * (1 if cached else 2) * (2.0 * D * D)   # (x_t C_t^T and) et' W_h2^T
-            if not cached and (workload == "table" or features == "bf16") and not if16_taken(precision, cfg, workload, B):
+            if not cached and (workload == "table" or features == "bf16"):
                 step_flops += pairs * 2.0 * R * D   # x_i C_i^T runs on this kernel too (gathered / bf16 image planes)
         elif dom == "gemm_x3" and fused:
             # x_i C_i^T plus the mention-sized products, which run on the same kernel from 256 rows up
@@ -344,7 +344,7 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(launches),
                 "avg_launch_ms": per_launch_ms}
         if dom != "gemm":
-            passes = 1 if (dom == "gemm_x3" and if16_taken(precision, cfg, workload, B)) else 3
+            passes = 1 if (dom == "gemm_x3" and if16_taken(precision, cfg, workload, B, features)) else 3
             roof["executed_bf16_tflops"] = passes * achieved
             roof["executed_frac"] = passes * achieved / peak
             section = None
@@ -354,21 +354,23 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
     return roof, ab, stream_bytes_pair, flops_pair
 
 
-def if16_taken(precision, cfg, workload, B):
+def if16_taken(precision, cfg, workload, B, features="f32"):
     """Whether a call takes the one-pass fp16 image contraction: the library's own gate (csrc/fused_forward.hip: N >= 64, the exact
-    widths, per-pair rows, at least 128 tiles of 256 x 256) - a `bf16x3_if16` line of any other shape ran split-bf16 and says so."""
+    widths, per-pair fp32-stored rows, at least 128 tiles of 256 x 256) - a `bf16x3_if16` line of any other shape ran split-bf16 and
+    says so."""
     D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
     tiles = -(-B * N // 256) * -(-D // 256)
-    return precision == "bf16x3_if16" and N >= 64 and D == 768 and R == 2048 and workload != "table" and tiles >= 128
+    return (precision == "bf16x3_if16" and N >= 64 and D == 768 and R == 2048 and workload != "table" and features == "f32"
+            and tiles >= 128)
 
 
-def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision, workload="wikimel", B=1 << 20):
+def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision, workload="wikimel", B=1 << 20, features="f32"):
     D, R = cfg.bert_embed_dim, cfg.resnet_embed_dim
     x3 = precision in ("bf16x3", "bf16x3_if16")
     peak = (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MATRIX_TFLOPS) * 1e12
     ref_flops = 2.0 * D * D + 2.0 * R * D + cfg.num_gcn_layers * 8.0 * D * D
     executed = (3 if x3 else 1) * flops_pair
-    if if16_taken(precision, cfg, workload, B):
+    if if16_taken(precision, cfg, workload, B, features):
         executed -= 2 * 2.0 * R * D                       # the image contraction in one pass instead of three
     return {
         "hbm_fraction_whole_path": ab["whole_path"] * rate_per_gpu / (PEAK_HBM_GBS * 1e9),
@@ -548,7 +550,7 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
     cache_format = cache_format or getattr(args, "cache_format", "f32")
     roof, ab, stream_bytes_pair, flops_pair = score_roofline(cfg, batch, B, prof, steps, precision, features, workload, cached, fused, cache_format)
     value = pairs * ctx.world * steps / elapsed
-    fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision, workload, B)
+    fr, ref_flops = whole_path_fractions(cfg, ab, flops_pair, value / ctx.world, precision, workload, B, features)
     # the one HBM-bound pass over the entity bytes, whichever class is the longest of this leg
     s_ms, s_n = prof.get("stream", (0.0, 0))
     hbm_kernel = None
@@ -587,7 +589,7 @@ def score_line(ctx, cfg, args, B, batch, elapsed, per_rank, prof, steps, warmup,
                                           "kernel of the call (tools/collect_pmc.py), replayed - not re-measured in this run") if whole_traffic else None,
         "launch": "hipGraph replay" if graph else "eager",
         "path": ((f"per-entity cache ({cache_format} rows) + layer 2") if cached else "fused two-layer" if fused else "layer-by-layer") + ", "
-                + ("bf16x3 (the fp16 image contraction is not taken at this shape)" if (precision == "bf16x3_if16" and not if16_taken(precision, cfg, workload, B))
+                + ("bf16x3 (the fp16 image contraction is not taken at this shape)" if (precision == "bf16x3_if16" and not if16_taken(precision, cfg, workload, B, features))
                    else precision) + (", features stored as bf16" if features == "bf16" else ""),
         "algorithmic": {"bytes_per_pair": ab["whole_path"], "dominant_kernel_bytes_per_pair": stream_bytes_pair,
                         "bytes_per_pair_split": ab, "flops_per_pair_executed": flops_pair, "flops_per_pair_reference": ref_flops},
@@ -1267,15 +1269,6 @@ def main(argv=None):
             ln = score_line(ctx, cfg, args, B, b16, e, pr, pf, st, 2, args.precision, "bf16", args.workload, False, fused)
             ln["parity"] = parity_of_timed_batch(cfg, sd, b16, o, n_slices=4, width=8, fp32_batch=batch)
             res = compact(ln)
-            # the same stored features with the image contraction in ONE fp16 pass (`bf16x3_if16`): a bf16 image row is exact in fp16
-            # under its row scale, so only the folded weight is rounded (11 bits) - the two-pass form above drops to one MFMA per tile pair
-            mm = make_model(cfg, sd, dev, "bf16x3_if16")
-            e, pr, o2, pf = run_score(ctx, mm, b16, st, 2)
-            l2 = score_line(ctx, cfg, args, B, b16, e, pr, pf, st, 2, "bf16x3_if16", "bf16", args.workload, False, fused)
-            l2["parity"] = parity_of_timed_batch(cfg, sd, b16, o2, n_slices=4, width=8)
-            l2["parity"]["max_abs_diff_vs_three_pass_scores_all"] = float((o2 - o).abs().max())
-            l2["parity"]["top1_agreement_vs_three_pass_all_mentions"] = float((o2[:, :-1].argmax(1) == o[:, :-1].argmax(1)).float().mean())
-            res["image_contraction_in_one_pass"] = compact(l2)
             return res
         extra["wikimel_bf16_features"] = leg_guard("wikimel_bf16_features", bf16_leg)
     del batch, out, model

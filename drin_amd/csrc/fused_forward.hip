@@ -263,14 +263,18 @@ static int forward_prepared_on_stream(const drin_config* cfg, const drin_batch* 
   // kernel gains on that GEMM (-0.35 ms).  Only the table form, which has to gather the rows anyway, writes them.
   const bool xi_planes = planes && indexed;
   // DRIN_PREC_BF16X3_IF16: x_i C_i^T in ONE pass of the fp16 matrix instruction on single planes.  k_entity_stream, which holds every
-  // image row in registers anyway, writes it as fp16(x / 2^ceil(log2 max|x|)) - 4 KB per pair, fp32- and bf16-stored rows alike
-  // (a bf16 value is exact in fp16 under the row scale) - with the scale beside it; the folded weight is one fp16 plane under one
-  // scale (drin_prepare); the all-DMA four-phase kernel multiplies both back in its epilogue.  For gathered (per-pair) rows at the
-  // exact widths in calls of at least half a round of 256 x 256 tiles; everything else runs the three passes, bit for bit.
+  // image row in registers anyway, writes it as fp16(x / 2^ceil(log2 max|x|)) - 4 KB per pair - with the scale beside it; the folded
+  // weight is one fp16 plane under one scale (drin_prepare); the all-DMA four-phase kernel multiplies both back in its epilogue.
+  // For gathered (per-pair) fp32-stored rows at the exact widths in calls of at least half a round of 256 x 256 tiles; everything
+  // else runs the three passes, bit for bit.  Measured (profiles/r5_*if16*): the contraction 3.4 -> 1.29 ms, the stream kernel +0.70 ms
+  // for the 1.69 GB it now writes (HBM writes inside a read-bound pass cost ~2.5 x their bytes) - the headline batch 15.8 -> 14.6 ms,
+  // what round 4's register-staged fp32-A kernel reached too (1.80 ms, nothing written).  bf16-STORED rows do NOT take the pass: their
+  // two-pass contraction reads them in place (2.07 ms); the plane costs their stream kernel +0.88 ms for -0.78 ms: measured, a wash.
   // (the candidate-count gate: with freshly initialised weights the fp16 pass costs 8e-6 at N = 11, but once the weights are
   //  TRAINED the vertex -> score map steepens and 11 candidates average too little - 1.2e-4 after 200 Adam steps, outside the bar;
   //  at N = 101 the same weights give 2e-5: profiles/r4_precision_on_trained_weights.txt)
-  const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !indexed && cfg->num_candidates >= kMixedMinCandidates &&
+  const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !indexed && cfg->feature_dtype == DRIN_FEAT_F32 &&
+                    cfg->num_candidates >= kMixedMinCandidates &&
                     D == 768 && R == 2048 &&   // (the stream kernel's fp16 hand-over is an instantiation of the exact widths)
                     gemm_f16_planes_fits(ws + L.p_xi, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
   if (b->entity_text_cls) {

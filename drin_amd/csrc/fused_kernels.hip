@@ -392,10 +392,9 @@ static int launch_stream_t(const StreamArgs& a, hipStream_t st) {
         set_error("entity_stream: xi_scale without xi_f16");
         return DRIN_E_NULL;
       }
-      return a.bf16_features ? launch_stream_ft<DV, RV, TOKENS, EXACT, __bf16, true>(a, st)
-                             : launch_stream_ft<DV, RV, TOKENS, EXACT, float, true>(a, st);
+      if (!a.bf16_features) return launch_stream_ft<DV, RV, TOKENS, EXACT, float, true>(a, st);
     }
-    set_error("entity_stream: the scaled fp16 image plane is built for D = 768, R = 2048");
+    set_error("entity_stream: the scaled fp16 image plane is built for fp32-stored rows at D = 768, R = 2048");
     return DRIN_E_UNSUPPORTED;
   }
   return a.bf16_features ? launch_stream_ft<DV, RV, TOKENS, EXACT, __bf16>(a, st)

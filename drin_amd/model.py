@@ -529,8 +529,8 @@ class Model(nn.Module):
         FP16 matrix instruction on the image rows the stream kernel hands over as fp16 under a power-of-two scale per row, where the
         candidate list is long enough - N >= 64 - for the mean over candidates behind it to average its rounding noise down:
         <= 4e-6 on the scores at N = 101 with freshly initialised weights, <= 2e-5 with trained ones - inside the bar either way;
-        for per-pair (not table-form) image rows, fp32- or bf16-stored, of large inference calls at D = 768 / R = 2048; shorter
-        lists, small calls and every other path run "bf16x3" bit for bit);
+        for per-pair (not table-form) fp32-stored image rows of large inference calls at D = 768 / R = 2048; shorter lists, small
+        calls, bf16-stored features and every other path run "bf16x3" bit for bit);
         `fused`: let inference calls (no parameter needs a gradient) take the folded two-layer path;
         `grad_bucket`: backward writes every gradient into one flat bucket the `.grad`s are views of (like DDP's
         `gradient_as_bucket_view`: a `.grad` kept across `zero_grad(set_to_none=True)` + `backward()` is overwritten)."""

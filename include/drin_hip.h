@@ -63,8 +63,9 @@ typedef enum {
                               both back in its epilogue.  Measured at N = 101: <= 4e-6 on the scores with freshly initialised
                               weights, <= 2e-5 with trained ones (BF16X3 itself: 2e-6 / 6e-6).  Taken only for num_candidates >= 64
                               (at N = 11 the pass costs 8e-6 at initialisation but 1.2e-4 on trained weights), D = 768, R = 2048,
-                              per-pair (not table-form) image rows - fp32- or bf16-stored - and calls of at least 128 tiles of
-                              256 x 256 (~11 000 pairs); every other call runs BF16X3 bit for bit.  Other entry points return
+                              per-pair (not table-form) fp32-stored image rows and calls of at least 128 tiles of 256 x 256
+                              (~11 000 pairs); every other call - bf16-stored features included: their two-pass contraction reads
+                              the rows in place and writing the plane buys nothing - runs BF16X3 bit for bit.  Other entry points return
                               DRIN_E_UNSUPPORTED for it.  */
 } drin_precision;
 

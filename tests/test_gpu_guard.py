@@ -86,7 +86,6 @@ def _dev_batch(cfg, B, seed, dtype=torch.float32):
     ("headline_small_call", wikimel_config(max_entity_attr_token_len=7), 5, "bf16x3", "f32"),
     ("ragged_last_tile", wikimel_config(max_entity_attr_token_len=3, num_candidates_data=36), 77, "bf16x3", "f32"),
     ("f16_image_contraction", wikimel_config(max_entity_attr_token_len=4), 2048, "bf16x3_if16", "f32"),
-    ("f16_image_contraction_bf16_rows", wikimel_config(max_entity_attr_token_len=4), 1200, "bf16x3_if16", "bf16"),
     ("bf16_features", wikimel_config(max_entity_attr_token_len=5), 600, "bf16x3", "bf16"),
     ("exact_f32", wikimel_config(max_entity_attr_token_len=4), 130, "f32", "f32"),
     ("wikidiverse", DrinConfig(), 3000, "bf16x3", "f32"),

@@ -257,9 +257,9 @@ def test_f16_image_contraction_is_blind_to_the_scale_of_the_rows():
 def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
     """Where the fp16 pass does NOT run, the mode is split-bf16 bit for bit: candidate lists shorter than 64 (WikiDiverse-shaped,
     16 384 mentions - at N = 11 the pass costs 8e-6 at initialisation but 1.2e-4 on trained weights,
-    `profiles/r4_precision_on_trained_weights.txt`), calls of fewer than 128 tiles of 256 x 256, the table form, training.
-    bf16-STORED image rows take the pass too (round 5: a bf16 value is exact in fp16 under its row scale): against the oracle on
-    the widened values."""
+    `profiles/r4_precision_on_trained_weights.txt`), calls of fewer than 128 tiles of 256 x 256, bf16-stored features (their
+    two-pass contraction reads the rows in place; handing them over as an fp16 plane was built in round 5 and measured a wash:
+    stream kernel +0.88 ms for -0.78 ms of contraction), the table form, training."""
     from drin_amd.model import EntityTable, IndexedBatch
     cfg = DrinConfig()
     sd = synth.make_state_dict(cfg, 7)
@@ -278,14 +278,7 @@ def test_f16_image_contraction_short_lists_small_calls_and_other_forms():
         small = [t[:64] for t in batch[:14]]                           # 6 464 pairs = 78 tiles: three passes
         assert torch.equal(f16(small), x3(small))
         b16 = [t.to(torch.bfloat16) if i in (0, 4, 5, 7, 9, 10) else t for i, t in enumerate(batch[:14])]
-        _lib.profile_begin()
-        got16 = f16(b16)
-        prof = _lib.profile_end()
-        assert prof["gemm_x3"][1] >= 1 and not torch.equal(got16, x3(b16))          # bf16-stored rows: the fp16 plane, one pass
-        ref = O.forward(sd, [(t[:16].float() if t.dtype == torch.bfloat16 else t[:16]).cpu() for t in b16])
-        err = (got16[:16].cpu() - ref).abs().max().item()
-        print(f"bf16-stored features through the fp16 image contraction: max |score - oracle(widened)| {err:.2e}")
-        assert err <= 1e-5 and torch.equal(got16, f16(b16))
+        assert torch.equal(f16(b16), x3(b16))                          # bf16-stored rows: read in place by their two-pass contraction
         # table form: the gathered planes, three passes
         tab = synth.make_device_batch(cfg.with_(num_candidates_data=1999), 1, 4, DEV)
         table = EntityTable(tab[7][0], tab[8][0], tab[9][0], tab[10][0], tab[11][0])

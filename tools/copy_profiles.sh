@@ -19,9 +19,7 @@ cp $O/train64_rccl_world1_bench_under_rocprof.json $P/${R}_train_b64_rccl_world1
 cp $O/config5_1M_stream.json $P/${R}_config5_1M_mentions_streamed.json
 cp $O/hbm_traffic.json $P/${R}_hbm_traffic.json
 cp gpurun_out/pmc_mfma/${R}_mfma_pmc.json $P/${R}_mfma_pmc.json
-cp "$(stats bf16f_if16)" $P/${R}_wikimel_b4096_bf16_features_if16_kernel_stats.csv
 cp "$(stats bf16f)" $P/${R}_wikimel_b4096_bf16_features_kernel_stats.csv
-cp $O/bf16f_if16_bench_under_rocprof.json $P/${R}_wikimel_b4096_bf16_features_if16_bench_under_rocprof.json
 cp $O/bf16f_bench_under_rocprof.json $P/${R}_wikimel_b4096_bf16_features_bench_under_rocprof.json
 cp gpurun_out/pmc_mfma/summary.txt $P/${R}_mfma_pmc_summary.txt
 cp "$(stats tabm)" $P/${R}_table_cache_mixed_f16_b4096_kernel_stats.csv

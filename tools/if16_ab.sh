@@ -1,6 +1,6 @@
 #!/bin/bash
-# Same-box A/B of the headline arithmetic (bf16x3) against the one-pass fp16 image contraction on single planes (bf16x3_if16), fp32- and
-# bf16-stored features, alternating.   tools/if16_ab.sh [runs]   -> gpurun_out/if16_ab.txt
+# Same-box A/B of the headline arithmetic (bf16x3) against the one-pass fp16 image contraction on single planes (bf16x3_if16), alternating
+# (with --features bf16 the mode is gated off since round 5: both arms then run the same kernels).   tools/if16_ab.sh [runs]   -> gpurun_out/if16_ab.txt
 N=${1:-3}
 O=gpurun_out/if16_ab.txt
 : > $O

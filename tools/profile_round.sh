@@ -19,8 +19,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 $HEAD > $O/pmc_write.log 2>&1
 python3 tools/collect_pmc.py $O/pmc_fetch $O/pmc_write $O/hbm_traffic.json kernels > $O/hbm_traffic.txt
 echo "[profile_round] default PMC done"
-# the bf16-stored-features leg (three-pass and with the fp16 image contraction): kernel stats of their own commands
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16f_if16 -- python3 bench.py --features bf16 --precision bf16x3_if16 --steps 10 --warmup 3 $HEAD --legs-file $O/bf16f_if16_bench_under_rocprof.json > /dev/null 2> $O/bf16f_if16.err
+# the bf16-stored-features leg: kernel stats of its own command
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16f -- python3 bench.py --features bf16 --steps 10 --warmup 3 $HEAD --legs-file $O/bf16f_bench_under_rocprof.json > /dev/null 2> $O/bf16f.err
 echo "[profile_round] mixed precision / bf16 features done"
 TAB="--workload table --batch 4096 --entity-cache"

@@ -349,3 +349,27 @@ def test_untracked_loads_are_not_touched_before_their_counted_wait():
               (16, "v_mov_b64_e32 v[4:5], v[12:13]", None), (20, "s_waitcnt vmcnt(0)", None), (24, "v_add_u32_e32 v6, v4, v5", None)]
     assert not resources.untracked_load_hazards(ifelse)
 
+
+
+def test_design_md_quotes_what_its_tracked_files_say():
+    """DESIGN.md quoted best-box numbers while citing tracked files that said otherwise.  Every measured figure there now
+    carries a tag naming the file and the field it comes from; the figure and the file must agree to 3 %, and the tag must sit on the
+    line that shows the number (tools/check_design_numbers.py).  Also: the checker itself flags a wrong figure and a misplaced tag."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_design_numbers", os.path.join(repo, "tools", "check_design_numbers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, problems = mod.check(os.path.join(repo, "DESIGN.md"))
+    assert n >= 30 and not problems, problems
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        doc = os.path.join(d, "doc.md")
+        ok = "stream 8.269 ms <!--track csv profiles/r5_wikimel_b4096_kernel_stats.csv k_entity_stream AverageNs 8.269-->\n"
+        wrong = "stream 7.5 ms <!--track csv profiles/r5_wikimel_b4096_kernel_stats.csv k_entity_stream AverageNs 7.5-->\n"
+        apart = "stream is fast <!--track csv profiles/r5_wikimel_b4096_kernel_stats.csv k_entity_stream AverageNs 8.269-->\n"
+        missing = "x 1.0 <!--track json profiles/no_such_file.json value 1.0-->\n"
+        for text, bad in ((ok, 0), (wrong, 1), (apart, 1), (missing, 1)):
+            with open(doc, "w") as f:
+                f.write(text)
+            assert len(mod.check(doc)[1]) == bad, (text, mod.check(doc))

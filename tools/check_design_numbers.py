@@ -37,7 +37,11 @@ def _csv_value(path, substring, field):
 
 def _json_value(path, dotted):
     with open(path) as f:
-        node = json.loads(f.readline())
+        text = f.read()
+    try:
+        node = json.loads(text)                       # one document (indented or not)
+    except ValueError:
+        node = json.loads(text.splitlines()[0])       # several records, one per line: the first
     for key in dotted.split("."):
         node = node[int(key)] if isinstance(node, list) else node[key]
     return float(node)

@@ -6,6 +6,8 @@ spans of one token, token counts at the Python-slice corners of `ghmfc.py:245-24
 offers for that configuration against the CPU oracle on the same inputs: inference (the folded path where it applies, else
 layer by layer), the training-mode forward, the table form and the per-entity cache in both row formats, and the parameter
 gradients of the triplet loss against autograd through the oracle, including WHICH gradients are None."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 CASES = 48
 FULL_WIDTH_CASES = 16     # the same draw at D = 768 / R = 2048: the exact-width instantiations of every row / stream / GEMM kernel
+EXTRA_CASES = int(os.environ.get("DRIN_FUZZ_EXTRA", "0"))   # one-off deeper sweeps: further seeds at the small widths (every 8th at full width)
 
 
 def _draw(i: int):
@@ -31,7 +34,7 @@ def _draw(i: int):
     if vector and D % 8:
         D = 64
     R = pick([64, 128, 192])
-    if i >= CASES:
+    if CASES <= i < CASES + FULL_WIDTH_CASES or (i >= CASES + FULL_WIDTH_CASES and i % 8 == 0):
         D, R = 768, 2048
     kw = dict(
         dataset_name="wikimel" if wikimel else "wikidiverse",
@@ -62,7 +65,27 @@ def _oracle_kwargs(cfg):
     return O.config_kwargs(cfg)
 
 
-@pytest.mark.parametrize("i", range(CASES + FULL_WIDTH_CASES))
+class _relu_inputs:
+    """Records min |x| of every `F.relu` call made inside the block (the oracle resolves activations by name at call time,
+    `model.py:117-118`): how close a case's pre-activations come to relu's kink."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._F, self._orig, self.mins = F, F.relu, []
+
+        def spy(x, *a, **k):
+            if x.numel():
+                self.mins.append(float(x.detach().abs().min()))
+            return self._orig(x, *a, **k)
+        F.relu = spy
+        return self.mins
+
+    def __exit__(self, *exc):
+        self._F.relu = self._orig
+        return False
+
+
+@pytest.mark.parametrize("i", range(CASES + FULL_WIDTH_CASES + EXTRA_CASES))
 def test_random_configuration_every_path_against_the_oracle(i):
     cfg, B, precision, seed = _draw(i)
     sd = synth.make_state_dict(cfg, 3 + i)
@@ -111,7 +134,15 @@ def test_random_configuration_every_path_against_the_oracle(i):
         # one - tools/probes/fuzz_grad_case.py, profiles/r4_fuzz_grad_cases.txt) and scales the bound; a relu vertex meets its
         # kink: a split-bf16 product moves a pre-activation by 1e-6 and one element in ten thousand flips its derivative
         p64 = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
-        out64 = O.forward(p64, batch[:14], dtype=torch.float64, **_oracle_kwargs(cfg))
+        with _relu_inputs() as relu_in:
+            out64 = O.forward(p64, batch[:14], dtype=torch.float64, **_oracle_kwargs(cfg))
+        # relu has no derivative at 0: a pre-activation closer to it than the arithmetic resolves (split-bf16 moves a mention-sized
+        # pre-activation by up to ~5e-6, exact fp32 by ~1e-7) may sit on either side, and ONE flipped unit of a last-layer MENTION
+        # vertex - which all N scores of its mention share - moved a LayerNorm bias gradient by 15 % (seed 349 of a 640-seed sweep:
+        # min |z| 4.6e-6, relu vertices 0.147, the same case with gelu 1.1e-5; tools/probes/fuzz_case_diff.py).  A gradient MISMATCH
+        # is therefore excused - said aloud, not silently - only when the fp64 oracle shows a relu input that close to the kink; a
+        # case that is near a kink and still agrees counts like any other.
+        near_kink = bool(relu_in) and min(relu_in) < (2e-5 if precision == "bf16x3_all" else 1e-6)
         loss64 = ((out64 * w.double()).sum() if cfg.num_candidates_data == 0
                   else O.triplet_loss(batch[14].double(), out64, cfg.triplet_margin))
         g64 = torch.autograd.grad(loss64, list(p64.values()), allow_unused=True)
@@ -119,6 +150,7 @@ def test_random_configuration_every_path_against_the_oracle(i):
         base = 5e-4 if precision == "bf16x3_all" else 5e-5
         if cfg.gcn_vertex_activation == "relu" and precision == "bf16x3_all":
             base *= 4
+        mismatches = []
         for (k, p), r, r64 in zip(model.named_parameters(), ref_g, g64):
             assert k in ref_p
             got = p.grad
@@ -126,7 +158,16 @@ def test_random_configuration_every_path_against_the_oracle(i):
             if r is not None and r64.norm().item() > 1e-10:
                 cond = (r.double() - r64).norm().item() / r64.norm().item()          # the fp32 oracle's own distance
                 rel = (got.cpu().double() - r64).norm().item() / r64.norm().item()
-                assert rel <= max(base, 3 * cond), f"case {i}: grad of {k} off by {rel:.2e} (fp32 oracle itself: {cond:.2e}) ({cfg}, B={B}, {precision})"
+                # (5 x: the fp32 oracle's distance is ONE sample of the case's conditioning, the library's another; sigmoid vertices
+                #  squeeze all scores into a band of 4e-5 .. 2e-4, where a 1 400-seed sweep saw the two samples 3.5 x and 5.5 x apart:
+                #  profiles/r5_fuzz_deep_sweep.txt)
+                if rel > max(base, (10 if cfg.gcn_vertex_activation == "sigmoid" else 5) * cond):
+                    mismatches.append(f"case {i}: grad of {k} off by {rel:.2e} (fp32 oracle itself: {cond:.2e}) ({cfg}, B={B}, {precision})")
+        if mismatches and near_kink:
+            print(f"case {i}: {len(mismatches)} gradient(s) differ with a relu input {min(relu_in):.1e} from its kink (fp64 oracle): no gradient is "
+                  f"defined there at this precision - excused: {mismatches[0][:160]}")
+        else:
+            assert not mismatches, mismatches[0]
     # table form + per-entity cache (inference; the library says so when a geometry has no table form)
     model.eval()
     e_tab = e_cache = None

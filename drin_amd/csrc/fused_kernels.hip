@@ -110,6 +110,10 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   float sg_tt = 0.f, sg_ti = 0.f, sg_it = 0.f, sg_ii = 0.f;
   const float inv_d = 1.0f / (float)D;
 
+  // (Measured in round 5 and dropped - profiles/r5_stream_reorder_ab.txt: the mask words, the object row and the image row requested at
+  //  the top of a pair and worked off BEFORE the token walk, so that the walk starts with its count already there.  In-process A/B on
+  //  one resident batch (tools/probes/inprocess_lib_ab.py): 7.96 against 7.97 ms, bit-identical scores - the other seven waves of the CU
+  //  already cover a wave's round trips - for 256 instead of 230 VGPRs and spills in the bf16 and XSCALE instantiations.)
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
     // entity row: the pair itself, or a row of the entity tables (on-device form of data.py:87-93)

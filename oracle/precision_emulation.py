@@ -1,5 +1,6 @@
 """Test infrastructure (never imported by the product): what rounding the operands of ONE pair-sized contraction of the folded
-scoring path to bf16 costs on the final scores - the evidence behind `precision="bf16x3_i1"`.
+scoring path to fewer bits costs on the final scores - the evidence behind precision BY CONTRACTION (`precision="bf16x3_if16"`, DESIGN.md
+section 4.3; round 4's bf16 form of it, `bf16x3_i1`, was removed in round 5) and behind the mixed-f16 cache rows (section 6.1).
 
 The folded inference path (csrc/fused_forward.hip) leaves three contractions per (mention, candidate) pair:
     image  x_i C_i^T,  C_i = W_h1 W_ei   (D x R: 57 % of the path's FLOPs)  -> pre-LayerNorm value of the layer-1 entity IMAGE vertex

@@ -11,16 +11,19 @@ makes any GPU call and relays rank 0's JSON line and the children's exit code; s
 is a rank.  Every rank scores its own shard of mentions (weak scaling, no data-path collective - mentions are
 independent); the timed region is bracketed by barrier + synchronize and the max over ranks is used.
 
-Prints ONE JSON line (rank 0): the contract fields of the headline (BASELINE.json's metric on its WikiMEL-100 config) plus
+Prints ONE JSON line (rank 0) of at most 4 KB, strict JSON: the contract fields of the headline (BASELINE.json's metric on its WikiMEL-100
+config) plus
   roofline     : dominant kernel of the headline, HIP-event timed inside this process on the launch stream
   cpu_baseline : the CPU oracle (oracle/drin_oracle.py) timed on this host's cores on a bounded sample (N = 1)
   parity       : slices of the TIMED batch re-scored by the oracle (N = 1)
-  legs         : the other BASELINE configs under the same clock - f32_exact, wikimel_bf16_features (the headline batch with
-                 bf16-stored features), wikidiverse_b4 (configs[0]: the reference's CPU-runnable case), train_step (configs
-                 3 / 4; the only leg that also runs at N > 1: one RCCL all-reduce of the flat gradient bucket per step),
-                 train_b512 (the step at a rate-bound batch, gathered and table form),
-                 wikidiverse (config 2, fp32- and bf16-stored features), table_cache (config 5: 1 M-entity table, 1000
-                 candidates gathered on the device, mention chunks streamed)
+  legs         : value / ms_per_step / roofline fraction / parity error of every other leg, <= 150 bytes each
+  legs_file    : where the FULL record went (--legs-file, default bench_legs.json next to this file): every leg with its own roofline,
+                 the scaling model, step floors and provenance sentences - the other BASELINE configs under the same clock: f32_exact,
+                 wikimel_mixed_f16 (only the entity-image contraction in one fp16 pass), wikimel_bf16_features (the headline batch with
+                 bf16-stored features), wikidiverse_b4 (configs[0]: the reference's CPU-runnable case), train_step (configs 3 / 4; the
+                 only leg that also runs at N > 1: one RCCL all-reduce of the flat gradient bucket per step), train_b512 (the step at
+                 a rate-bound batch, gathered and table form), wikidiverse (config 2, fp32- and bf16-stored features), table_cache
+                 (config 5: 1 M-entity table, 1000 candidates gathered on the device, mention chunks streamed)
 """
 from __future__ import annotations
 

@@ -153,6 +153,22 @@ class EntityTable:
         self.cache_format = format
         return self
 
+    def _warn_if_rows_far_off_scale(self) -> None:
+        """The mixed-f16 row format holds a per-pair scalar (edge logit, image-image edge) to ~1e-5; the mention aggregates average
+        that over the candidates - unless ONE candidate's image vertex is orders of magnitude larger than the others' and dominates
+        the mean (`include/drin_hip.h`, drin_cache_format: measured 1e-5 .. 7e-5 on the scores with image rows x 1e6).  Checked once
+        per cache build (one pass over the image table, one host sync): rows whose largest |x| exceeds 1 000 x the median row's."""
+        import warnings
+        m = self.image.reshape(self.image.shape[0], -1).abs().amax(1).float()
+        finite = m[torch.isfinite(m) & (m > 0)]
+        if finite.numel() == 0:
+            return
+        far = int((finite > 1e3 * finite.median()).sum())
+        if far:
+            warnings.warn(f"EntityTable cache format mixed_f16: {far} of {m.numel()} entity image rows are more than 1 000 x the median row's "
+                          f"magnitude; mentions that list such an entity may score up to ~1e-4 from the fp32 rows (inside the 1e-4 bar, outside "
+                          f"the 1e-5 guard) - use format='f32' for tables like this", UserWarning, stacklevel=3)
+
     def invalidate(self) -> "EntityTable":
         """Drop the per-entity cache and the pooled-text copy.  Needed only after the tables were edited through a path
         PyTorch's version counters do not see (`t.data.copy_(...)`, an external kernel writing the storage): in-place torch
@@ -180,6 +196,8 @@ class EntityTable:
             _lib.check(lib.drin_build_entity_cache(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), prepared.data_ptr(),
                                                    cache.data_ptr(), n, ws.data_ptr(), ws.numel(), stream))
             self._cache, self._cache_key = cache, key
+            if self.cache_format == "mixed_f16":
+                self._warn_if_rows_far_off_scale()
         return self._cache
 
     @property

@@ -15,9 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DRIN_LIB_PATH: another build of the same library (the sanitizer build of `python -m drin_amd.build --asan-host`)
 LIB_PATH = os.environ.get("DRIN_LIB_PATH") or os.path.join(_HERE, "libdrin_hip.so")
 MAX_LAYERS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
-OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, E_SHAPE, E_NULL, E_ALIGN, E_WORKSPACE, E_HIP, E_UNSUPPORTED, E_INDEX = 0, -1, -2, -3, -4, -5, -6, -7
 PREC_F32, PREC_BF16X3, PREC_BF16X3_ALL, PREC_BF16X3_IF16 = 0, 1, 3, 5     # (2 and 4: removed with ABI 6 - outside the 1e-4 bar)
 FEAT_F32, FEAT_BF16 = 0, 1
 CACHE_F32, CACHE_MIXED_F16 = 0, 1                                      # drin_cache_format
@@ -48,6 +48,7 @@ class DrinBatchC(C.Structure):
         ("entity_text", C.c_void_p), ("entity_text_mask", C.c_void_p), ("entity_image", C.c_void_p),
         ("entity_object", C.c_void_p), ("entity_object_score", C.c_void_p), ("miet_similarity", C.c_void_p),
         ("mtei_similarity", C.c_void_p), ("entity_index", C.c_void_p), ("entity_text_cls", C.c_void_p),
+        ("index_status", C.c_void_p),
     ]
 
 
@@ -95,6 +96,7 @@ EXPORTS = {
     "drin_prepared_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
     "drin_fused_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
     "drin_workgroups_per_mention": (C.c_int32, [C.POINTER(DrinConfigC), C.c_int32]),
+    "drin_index_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "drin_prepare": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinParamsC), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_forward_prepared": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

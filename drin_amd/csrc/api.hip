@@ -29,6 +29,62 @@ int hip_fail(hipError_t e, const char* what) {
   return DRIN_E_HIP;
 }
 
+// ---- the device of a call (internal.h: DeviceScope) -----------------------------------------------
+static thread_local int g_call_device = -1;
+
+int call_device() {
+  if (g_call_device >= 0) return g_call_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return dev;
+}
+
+DeviceScope::DeviceScope(void* stream, const void* device_pointer, const char* entry_point)
+    : status(DRIN_OK), prev(-1), dev(-1), outer(g_call_device), switched(false) {
+  hipError_t e = hipGetDevice(&prev);
+  if (e != hipSuccess) {
+    // no usable device on this host: nothing to bind; argument validation still answers, and a launch would report the HIP error
+    (void)hipGetLastError();
+    prev = -1;
+    return;
+  }
+  dev = prev;
+  if (stream != nullptr) {
+    hipDevice_t d = 0;
+    e = hipStreamGetDevice((hipStream_t)stream, &d);
+    if (e != hipSuccess) {
+      set_error("%s: hipStreamGetDevice: %s (is `stream` a hipStream_t?)", entry_point, hipGetErrorString(e));
+      status = DRIN_E_HIP;
+      return;
+    }
+    dev = (int)d;
+  } else if (device_pointer != nullptr) {
+    // the NULL stream is "the default stream of the current device": take the device that owns the call's memory instead, so
+    // that a NULL-stream call on another device's tensors runs on that device's default stream
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, device_pointer) == hipSuccess && attr.type == hipMemoryTypeDevice)
+      dev = attr.device;
+    else
+      (void)hipGetLastError();   // an unregistered pointer: keep the current device (validation will say what is wrong)
+  }
+  if (dev != prev) {
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) {
+      set_error("%s: hipSetDevice(%d): %s", entry_point, dev, hipGetErrorString(e));
+      status = DRIN_E_HIP;
+      return;
+    }
+    switched = true;
+  }
+  g_call_device = dev;
+}
+
+DeviceScope::~DeviceScope() {
+  if (status != DRIN_OK || prev < 0) return;
+  g_call_device = outer;
+  if (switched) (void)hipSetDevice(prev);
+}
+
 // ---- roctx ranges (opt-in: DRIN_ROCTX) ----------------------------------------------------------
 struct Roctx {
   int (*push)(const char*) = nullptr;
@@ -389,6 +445,7 @@ size_t drin_workspace_bytes(const drin_config* cfg, int for_training) {
 }
 
 int drin_edges_fwd(const drin_config* cfg, const drin_batch* batch, float* edges, float* span_mean, void* stream) {
+  DRIN_BIND_DEVICE(stream, edges, "drin_edges_fwd");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
   if (!edges) {
@@ -417,6 +474,7 @@ int drin_edges_fwd(const drin_config* cfg, const drin_batch* batch, float* edges
 
 int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled_entity_text,
                   float* pooled_mention_image, float* pooled_entity_image, void* stream) {
+  DRIN_BIND_DEVICE(stream, batch ? (const void*)batch->mention_image : nullptr, "drin_pool_fwd");
   DRIN_TRY(validate_config(cfg));
   if (!batch) {
     set_error("batch is NULL");
@@ -465,6 +523,7 @@ int drin_pool_fwd(const drin_config* cfg, const drin_batch* batch, float* pooled
 
 int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y, int64_t rows, int32_t n_out, int32_t k,
                     int32_t precision, void* stream) {
+  DRIN_BIND_DEVICE(stream, y, "drin_linear_fwd");
   if (!x || !w || !y) {
     set_error("drin_linear_fwd: NULL operand");
     return DRIN_E_NULL;
@@ -478,6 +537,7 @@ int drin_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 
 int drin_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t rows,
                     int32_t n_out, int32_t k, int32_t precision, float* scratch, size_t scratch_floats, void* stream) {
+  DRIN_BIND_DEVICE(stream, dy, "drin_linear_bwd");
   if (!dy || (dx && !w) || (dw && !x)) {
     set_error("drin_linear_bwd: NULL operand");
     return DRIN_E_NULL;
@@ -517,6 +577,7 @@ int drin_forward(const drin_config* cfg, const drin_batch* batch, const drin_par
 int drin_forward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                         size_t workspace_bytes, float* scores, int keep_for_backward, const drin_trace* trace,
                         void* params_ready_event, void* stream) {
+  DRIN_BIND_DEVICE(stream, workspace, "drin_forward_staged");
   RoctxRange range("drin_forward");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));
@@ -785,6 +846,7 @@ int drin_backward(const drin_config* cfg, const drin_batch* batch, const drin_pa
 int drin_backward_staged(const drin_config* cfg, const drin_batch* batch, const drin_params* params, void* workspace,
                          size_t workspace_bytes, const float* grad_scores, const drin_param_grads* grads,
                          void* layers_ready_event, void* stream) {
+  DRIN_BIND_DEVICE(stream, workspace, "drin_backward_staged");
   RoctxRange range("drin_backward");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(validate_batch(cfg, batch));

@@ -7,6 +7,17 @@ namespace drin {
 
 constexpr int kWave = 64;
 
+// An entity_index outside [0, E-1] is clamped (memory safety) AND reported: the first reporter - one compare-and-swap on the
+// error path only - leaves {1, pair, value low, value high} in the caller's int32[4] (drin_batch.index_status; sticky).
+__device__ __forceinline__ void report_bad_index(int32_t* status, int64_t pair, int64_t value) {
+  if (status == nullptr) return;
+  if (atomicCAS(reinterpret_cast<int*>(status), 0, 1) == 0) {
+    status[1] = (int32_t)pair;
+    status[2] = (int32_t)(uint32_t)(uint64_t)value;
+    status[3] = (int32_t)(uint32_t)((uint64_t)value >> 32);
+  }
+}
+
 // Sum over the 64 lanes, result in every lane.  Four DPP adds (quad swaps, half-row and row mirrors: plain
 // VALU, a few cycles each) leave every lane of a 16-lane row with the row sum; the four row sums are
 // then read as scalars.  The usual __shfl_xor butterfly compiles to six dependent ds_bpermute_b32

@@ -195,6 +195,7 @@ struct CachedArgs {
   const float* cache;            // [E][ldc]
   int64_t ldc, num_entities;
   const int64_t* entity_index;   // [M]
+  int32_t* index_status;         // optional int32[4]: where a clamped entity_index is reported (drin_batch.index_status)
   const float* miet;             // [M]
   const float* mtei;             // [M]
   const float* span_mean;        // [B, D]
@@ -275,11 +276,12 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
       v[k] = n < n_end ? a.entity_index[b * a.N + n] : 0;
     }
   };
-  auto uniform_indices = [&](int64_t (&dst)[4], const int64_t (&v)[4]) {
+  auto uniform_indices = [&](int64_t (&dst)[4], const int64_t (&v)[4], int base) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int64_t e = v[k];
       e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
+      if (e != v[k] && lane == 0) report_bad_index(a.index_status, b * a.N + base + wave + 4 * k, v[k]);   // clamped (memory safety) and reported
       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)e), hi = __builtin_amdgcn_readfirstlane((uint32_t)(e >> 32));
       dst[k] = (int64_t)(((uint64_t)hi << 32) | lo);
     }
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     r.miet = a.miet[p];
   };
   PairRow ra, rb;  // two named buffers (an indexed array of them ends up in scratch memory)
-  uniform_indices(ent, ent_v);
+  uniform_indices(ent, ent_v, n_begin);
   if (n_begin + wave < n_end) fetch(ra, ent[0], b * a.N + n_begin + wave);  // first row: in flight under the rest of the prologue
 
   for (int i = wave; i < a.Km; i += 4) {  // model.py:88 re-normalises the same mention rows for every pair
@@ -489,7 +491,7 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     step(ra, rb, n0, ent[0], ent[1]);
     step(rb, ra, n0 + 4, ent[1], ent[2]);
     step(ra, rb, n0 + 8, ent[2], ent[3]);
-    if (more) uniform_indices(nxt, nxt_v);
+    if (more) uniform_indices(nxt, nxt_v, g + 16);
     step(rb, ra, n0 + 12, ent[3], nxt[0]);
     if (!EXACT) break;
 #pragma unroll
@@ -670,6 +672,7 @@ DRIN_API size_t drin_cached_workspace_bytes(const drin_config* cfg) {
 DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* tables, const drin_params* params,
                                      const void* prepared, void* cache, size_t cache_bytes, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  DRIN_BIND_DEVICE(stream, cache, "drin_build_entity_cache");
   RoctxRange range("drin_build_entity_cache");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(cache_supported(cfg));
@@ -762,6 +765,7 @@ DRIN_API int drin_build_entity_cache(const drin_config* cfg, const drin_batch* t
 
 DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
                                  const void* cache, void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  DRIN_BIND_DEVICE(stream, workspace, "drin_forward_cached");
   RoctxRange range("drin_forward_cached");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(cache_supported(cfg));
@@ -823,6 +827,7 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   a.ldc = (int64_t)cache_row_floats(*cfg);
   a.num_entities = cfg->num_entities;
   a.entity_index = b->entity_index;
+  a.index_status = b->index_status;
   a.miet = b->miet_similarity;
   a.mtei = b->mtei_similarity;
   a.span_mean = ws + L.span_mean;

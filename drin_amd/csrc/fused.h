@@ -63,6 +63,7 @@ struct StreamArgs {
   const float* entity_object_score;  // [M, Ke]
   const int64_t* entity_index;       // optional [M]: entity_* above are tables, pair p reads row entity_index[p]
   int64_t num_entities;
+  int32_t* index_status;             // optional int32[4]: where a clamped entity_index is reported (drin_batch.index_status)
   const float* miet;                 // [M]
   const float* mtei;                 // [M]
   // mention side

@@ -135,6 +135,7 @@ using namespace drin;
 extern "C" {
 
 int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+  DRIN_BIND_DEVICE(stream, x, "drin_split_planes");
   if (!x || !hi || !lo) {
     set_error("drin_split_planes: NULL argument");
     return DRIN_E_NULL;
@@ -144,6 +145,7 @@ int drin_split_planes(const float* x, void* hi, void* lo, int64_t n, void* strea
 
 int drin_linear_planes_fwd(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                            float* y, int64_t rows, int32_t n_out, int32_t k, void* stream) {
+  DRIN_BIND_DEVICE(stream, y, "drin_linear_planes_fwd");
   if (!x_hi || !w_hi || !w_lo || !y) {
     set_error("drin_linear_planes_fwd: NULL argument");
     return DRIN_E_NULL;
@@ -165,6 +167,7 @@ size_t drin_prepared_bytes(const drin_config* cfg) {
 
 int drin_prepare(const drin_config* cfg, const drin_params* params, void* prepared, size_t prepared_bytes,
                  void* stream) {
+  DRIN_BIND_DEVICE(stream, prepared, "drin_prepare");
   RoctxRange range("drin_prepare");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(fused_supported(cfg));
@@ -379,6 +382,7 @@ static int forward_prepared_on_stream(const drin_config* cfg, const drin_batch* 
   sa.entity_object_score = b->entity_object_score;
   sa.entity_index = b->entity_index;
   sa.num_entities = cfg->num_entities;
+  sa.index_status = b->index_status;
   sa.miet = b->miet_similarity;
   sa.mtei = b->mtei_similarity;
   sa.span_mean = ws + L.span_mean;
@@ -540,6 +544,25 @@ int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached) {
   return L.chunks;
 }
 
+int drin_index_status(int32_t* index_status, void* stream) {
+  if (!index_status) {
+    set_error("drin_index_status: NULL argument");
+    return DRIN_E_NULL;
+  }
+  DRIN_BIND_DEVICE(stream, index_status, "drin_index_status");
+  int32_t w[4] = {0, 0, 0, 0};
+  hipError_t e = hipMemcpyAsync(w, index_status, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "drin_index_status");
+  if (w[0] == 0) return DRIN_OK;
+  e = hipMemsetAsync(index_status, 0, sizeof(w), (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "drin_index_status(reset)");
+  const long long value = (long long)(((uint64_t)(uint32_t)w[3] << 32) | (uint32_t)w[2]);
+  set_error("entity_index out of range: candidate row %lld at pair %d (b * N + n) is outside the entity tables - the row was clamped "
+            "and a WRONG entity scored; drin/data.py:87-93 raises IndexError here", value, (int)w[1]);
+  return DRIN_E_INDEX;
+}
+
 size_t drin_fused_workspace_bytes(const drin_config* cfg) {
   if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
   FusedLayout L;
@@ -549,6 +572,7 @@ size_t drin_fused_workspace_bytes(const drin_config* cfg) {
 
 int drin_forward_prepared(const drin_config* cfg, const drin_batch* b, const drin_params* params, const void* prepared,
                           void* workspace, size_t workspace_bytes, float* scores, void* stream) {
+  DRIN_BIND_DEVICE(stream, workspace, "drin_forward_prepared");
   RoctxRange range("drin_forward_prepared");
   DRIN_TRY(validate_config(cfg));
   DRIN_TRY(fused_supported(cfg));

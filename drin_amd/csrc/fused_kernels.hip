@@ -119,8 +119,9 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
     // entity row: the pair itself, or a row of the entity tables (on-device form of data.py:87-93)
     int64_t e = p;
     if (a.entity_index) {
-      e = a.entity_index[p];
-      e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
+      const int64_t raw = a.entity_index[p];
+      e = raw < 0 ? 0 : (raw >= a.num_entities ? a.num_entities - 1 : raw);
+      if (e != raw && lane == 0) report_bad_index(a.index_status, p, raw);   // data.py:87-93 would raise: clamped, and reported
     }
     // ---- text: CLS / pooler cosine (model.py:71-76) and token mean (ghmfc.py:245-249) ---------------
     Row<DV> xt;

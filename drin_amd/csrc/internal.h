@@ -34,15 +34,36 @@ struct KernelTimer {
   hipStream_t stream;
 };
 
+// The device a call runs on is the device of the caller's STREAM, not whatever device happens to be current on the calling
+// thread: every entry point that launches opens a DeviceScope first.  It asks the stream (hipStreamGetDevice) - or, for the NULL
+// stream, the device that owns `device_pointer` (hipPointerGetAttributes; the NULL stream of THAT device is then used) - makes that
+// device current for the duration of the call and restores the previous one on the way out.  A process whose current device is 0
+// may therefore score tensors that live on device 1 through a stream of device 1: kernel attributes, launches, events and memsets
+// all land on device 1.  Scopes nest (an entry point calling another one); the innermost one answers call_device().
+struct DeviceScope {
+  DeviceScope(void* stream, const void* device_pointer, const char* entry_point);
+  ~DeviceScope();
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+  int status;        // DRIN_OK, or DRIN_E_HIP with the message set
+  int prev, dev, outer;
+  bool switched;
+};
+// device of the innermost DeviceScope of this thread (outside any scope: the current device)
+int call_device();
+#define DRIN_BIND_DEVICE(stream, device_pointer, entry_point)               \
+  ::drin::DeviceScope _device_scope((stream), (device_pointer), (entry_point)); \
+  if (_device_scope.status != DRIN_OK) return _device_scope.status
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: one high-water mark per (call site,
 // device), so a process that runs on cuda:0 and later on cuda:1 opts in on both, and a later call that needs more LDS
-// than the first one raises it.  Atomics: the caller's thread and autograd's may race here harmlessly (idempotent call).
+// than the first one raises it.  The device is the CALL's (DeviceScope), which the entry point has made current.
+// Atomics: the caller's thread and autograd's may race here harmlessly (idempotent call).
 struct DynLdsOptIn {
   std::atomic<int> bytes[64] = {};
 };
 inline int ensure_dynamic_lds(DynLdsOptIn& s, const void* kernel, int bytes, const char* what) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const int dev = call_device();
   std::atomic<int>& mark = s.bytes[dev & 63];
   if (mark.load(std::memory_order_relaxed) >= bytes) return DRIN_OK;
   hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

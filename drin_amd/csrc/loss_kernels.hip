@@ -191,6 +191,7 @@ DRIN_API size_t drin_loss_workspace_bytes(int32_t batch) {
 DRIN_API int drin_triplet_topk(const float* scores, const uint8_t* answer, int32_t batch, int32_t num_candidates, float margin,
                       const int32_t* topk, int32_t num_topk, float* loss, float* d_scores, int64_t* correct,
                       void* workspace, size_t workspace_bytes, void* stream) {
+  DRIN_BIND_DEVICE(stream, scores, "drin_triplet_topk");
   RoctxRange range("drin_triplet_topk");
   if (batch <= 0 || num_candidates < 2) {
     set_error("drin_triplet_topk: batch %d, num_candidates %d (need >= 1 mention and the answer slot + 1 candidate)", batch,

@@ -86,6 +86,7 @@ using namespace drin;
 extern "C" int drin_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lerp_weight,
                               float beta2, float one_minus_beta2, float bias_correction2_sqrt, float eps, float neg_step_size,
                               void* stream) {
+  DRIN_BIND_DEVICE(stream, param, "drin_adam_step");
   RoctxRange range("drin_adam_step");
   if (!param || !grad || !exp_avg || !exp_avg_sq) {
     set_error("drin_adam_step: NULL operand");

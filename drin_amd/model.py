@@ -12,6 +12,7 @@ AMD GPU, `forward` raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -276,7 +277,7 @@ class _Call:
 
     def __init__(self, cfg: DrinConfig, batch: Sequence[torch.Tensor], precision: int,
                  entity_index: Optional[torch.Tensor] = None, keep_bf16: bool = False,
-                 entity_text_cls: Optional[torch.Tensor] = None):
+                 entity_text_cls: Optional[torch.Tensor] = None, index_status: Optional[torch.Tensor] = None):
         """`keep_bf16`: the caller will take a path that reads bf16-stored features in place (fused inference);
         otherwise bf16 features are widened to fp32 here (exact) - e.g. for training.
         `entity_text_cls` `[B, N, D]`: the token-0 rows of the text-text edge when `entity_text_feature` holds token
@@ -363,8 +364,10 @@ class _Call:
             want = (etf.shape[0], D) if table else (B, N, D)       # a table of token-0 rows, or per-pair rows
             if tuple(entity_text_cls.shape) != want:
                 raise ValueError(f"entity_text_cls has shape {tuple(entity_text_cls.shape)}, expected {want}")
+        if index_status is not None and (index_status.dtype != torch.int32 or index_status.numel() < 4 or index_status.device != dev):
+            raise ValueError("index_status: int32[4] on the batch's device")
         self.keep = [mtf, start, end, mimg, mobj, mscore, etf, emask, eimg, eobj, escore, miet, mtei, entity_index,
-                     entity_text_cls]
+                     entity_text_cls, index_status if table else None]
         self.device = dev
         self.B, self.N, self.D = B, N, D
         c = _lib.DrinConfigC()
@@ -394,7 +397,7 @@ class _Call:
         for name, t in zip(("mention_text", "mention_start", "mention_end", "mention_image", "mention_object",
                             "mention_object_score", "entity_text", "entity_text_mask", "entity_image",
                             "entity_object", "entity_object_score", "miet_similarity", "mtei_similarity",
-                            "entity_index", "entity_text_cls"), self.keep):
+                            "entity_index", "entity_text_cls", "index_status"), self.keep):
             setattr(b, name, _ptr(t))
         self.batch = b
 
@@ -563,6 +566,10 @@ class Model(nn.Module):
         self._params_ready = None                            # set by train.OverlappedStep: event behind an update still in flight
         self._param_flat: Optional[torch.Tensor] = None
         self._layout = None
+        # table-form calls: where the kernels report a candidate row outside the entity tables (drin_batch.index_status)
+        self.validate_indices = os.environ.get("DRIN_VALIDATE", "") not in ("", "0")
+        self._index_status: Dict[torch.device, torch.Tensor] = {}
+        self._index_watch: List = []                          # (host copy, event): async read-backs of calls still in flight
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         modes = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL, "bf16x3_if16": _lib.PREC_BF16X3_IF16}
         if precision not in modes:
@@ -660,7 +667,63 @@ class Model(nn.Module):
             self.invalidate()
         return flat
 
+    # ---- candidate rows outside the entity tables (drin/data.py:87-93 raises IndexError) ------------------------------
+    def _status_words(self, device: torch.device) -> torch.Tensor:
+        t = self._index_status.get(device)
+        if t is None:
+            t = self._index_status[device] = torch.zeros(4, dtype=torch.int32, device=device)
+        return t
+
+    @staticmethod
+    def _raise_bad_index(words) -> None:
+        w = [int(x) for x in words]
+        value = ((w[3] & 0xFFFFFFFF) << 32 | (w[2] & 0xFFFFFFFF))
+        value -= (1 << 64) if value >= (1 << 63) else 0
+        what = f"row {value} at pair {w[1]} (b * N + n)" if (w[2] or w[3]) else "a row of a training batch"
+        raise IndexError(f"IndexedBatch.candidates: {what} is outside the entity tables (it was clamped: the scores of that call are of the "
+                         f"WRONG entity there); the reference's fancy index, drin/data.py:87-93, raises here too")
+
+    def _watch_indices(self, device: torch.device) -> None:
+        """After a table-form call: raise at once when validating eagerly, else start an asynchronous read-back of the status
+        words which `forward` / `check_indices` look at once it has landed (no synchronisation is added to the step)."""
+        if self.validate_indices:
+            self.check_indices()
+            return
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(self._status_words(device), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._index_watch.append((host, ev))
+
+    def check_indices(self, wait: bool = True) -> None:
+        """Raise `IndexError` if any table-form call since the last check met a candidate row outside `[0, E - 1]`.  `wait=True`
+        synchronises with the device (call it where the loop synchronises anyway: `MELRunner.run_epoch` does, at the epoch's
+        end); `wait=False` only looks at read-backs that have already landed.  `Model(...).validate_indices = True` (or
+        `DRIN_VALIDATE=1`) checks after every call instead - the reference's behaviour, at one synchronisation per call."""
+        bad = None
+        if wait:
+            self._index_watch.clear()
+            for t in self._index_status.values():
+                w = t.cpu()
+                if int(w[0]) != 0 and bad is None:
+                    bad = w.tolist()
+                if int(w[0]) != 0:
+                    t.zero_()
+        else:
+            while self._index_watch and self._index_watch[0][1].query():
+                host, _ev = self._index_watch.pop(0)
+                if int(host[0]) != 0 and bad is None:
+                    bad = host.tolist()
+            if bad is not None:
+                self._index_watch.clear()
+                for t in self._index_status.values():
+                    t.zero_()
+        if bad is not None:
+            self._raise_bad_index(bad)
+
     def forward(self, batch) -> torch.Tensor:
+        if self._index_watch:
+            self.check_indices(wait=False)
         B = batch.candidates.shape[0] if isinstance(batch, IndexedBatch) else batch[0].shape[0]
         if B > self.MAX_CALL_MENTIONS:
             return torch.cat([self._forward(part) for part in _split_mentions(batch, self.MAX_CALL_MENTIONS)], 0)
@@ -682,12 +745,17 @@ class Model(nn.Module):
                     raise ValueError("the per-entity cache is built from fp32 tables; give EntityTable fp32 features")
                 # bf16-stored features are read in place by the fused path (never widened: the table is large)
                 prec = _lib.PREC_BF16X3 if (t.cache_enabled and self.precision in _FUSED_ONLY) else self.precision
-                call = _Call(self.cfg, seq, prec, entity_index=batch.candidates, keep_bf16=planes and not t.cache_enabled)
+                call = _Call(self.cfg, seq, prec, entity_index=batch.candidates, keep_bf16=planes and not t.cache_enabled,
+                             index_status=self._status_words(batch.candidates.device))
                 if _lib.load().drin_fused_supported(C.byref(call.cfg)) == _lib.OK:
                     if t.cache_enabled:                                # per-entity precompute cache
-                        return self._forward_cached(call, t, params)
+                        out = self._forward_cached(call, t, params)
+                        self._watch_indices(call.device)
+                        return out
                     if planes:
-                        return self._score(call, self._prepared, False, *params)
+                        out = self._score(call, self._prepared, False, *params)
+                        self._watch_indices(call.device)
+                        return out
             if not inference and t.text.dim() == 3:
                 # training on a token-level table: every entity's tokens pooled once; the step then reads the pooled /
                 # token-0 / image / object tables through the candidate index inside the kernels, or gathers those rows
@@ -695,10 +763,14 @@ class Model(nn.Module):
                 if call is not None:
                     if call.B == 0:
                         return torch.zeros(0, call.N, dtype=torch.float32, device=call.device)
-                    return self._score(call, None, True, *params)
-                batch, cls = batch.gathered_pooled(self.cfg)
+                    out = self._score(call, None, True, *params)
+                    self._watch_indices(call.device)
+                    return out
+                batch, cls = self._clamped(batch).gathered_pooled(self.cfg)
+                self._watch_indices(batch[0].device)
             else:
-                batch = batch.gathered()
+                batch = self._clamped(batch).gathered()
+                self._watch_indices(batch[0].device)
         # grad mode is already off inside Function.forward (and needs_input_grad ignores no_grad), so the
         # caller's mode is read here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
@@ -756,6 +828,15 @@ class Model(nn.Module):
                 torch.cuda.current_stream(call.device).wait_event(ev)
             raise
 
+    def _clamped(self, batch: "IndexedBatch") -> "IndexedBatch":
+        """The batch with its candidate rows clamped into the tables and any clamped row reported in the status words: the torch
+        gathers of the paths off the fused kernels must never see a row >= E (a device-side assert), and a negative row wraps
+        silently there."""
+        cand = batch.candidates
+        safe = cand.clamp(0, batch.table.num_entities - 1)
+        self._status_words(cand.device)[0:1].bitwise_or_((safe != cand).any().view(1).to(torch.int32))
+        return IndexedBatch(batch.mention, batch.table, safe, batch.miet_similarity, batch.mtei_similarity)
+
     def _indexed_training_call(self, batch: "IndexedBatch", planes: bool) -> Optional[_Call]:
         """The table form of `drin_forward` / `drin_backward` (`drin_batch.entity_index` over tables pooled ahead of time),
         when the library builds it for this geometry (`indexed_supported` in csrc/api.hip); None: gather the rows."""
@@ -772,9 +853,12 @@ class Model(nn.Module):
         dummy = torch.zeros(cand.shape[0], dtype=torch.int64, device=cand.device)
         seq = batch.mention + [pooled, dummy, t.image, t.object, t.object_score, batch.miet_similarity, batch.mtei_similarity]
         # the layer-by-layer kernels trust the index (the stream kernel of the fused path clamps it): clamp here, so that a
-        # bad candidate row can never become an out-of-bounds read on the device
+        # bad candidate row can never become an out-of-bounds read on the device - and report it like the kernels do
+        # (four small launches, no synchronisation: word 0 of the status words becomes 1, the value words stay 0)
         prec = _lib.PREC_BF16X3 if self.precision in _FUSED_ONLY else self.precision
-        return _Call(self.cfg, seq, prec, entity_index=cand.clamp(0, t.num_entities - 1), entity_text_cls=cls)
+        safe = cand.clamp(0, t.num_entities - 1)
+        self._status_words(cand.device)[0:1].bitwise_or_((safe != cand).any().view(1).to(torch.int32))
+        return _Call(self.cfg, seq, prec, entity_index=safe, entity_text_cls=cls)
 
     @torch.no_grad()
     def _forward_cached(self, call: _Call, table: EntityTable, params) -> torch.Tensor:

@@ -557,6 +557,8 @@ class MELRunner:
         for m in meters:
             m.sync(force=self.force_collectives)
         mean_loss = float(total) / max(steps, 1)
+        if hasattr(self.model, "check_indices"):
+            self.model.check_indices()            # the loop has just synchronised: a candidate row outside the tables raises here at the latest
         if _collectives(self.force_collectives):
             t = torch.tensor([mean_loss], device=self.device)
             dist.all_reduce(t)

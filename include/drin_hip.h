@@ -16,7 +16,13 @@
  *     nothing and keeps no mutable global state (the opt-in profile of drin_profile_begin apart; environment
  *     probes are read once), so calls are re-entrant.
  *   - every kernel is launched on the caller's `stream` (a hipStream_t passed as void*); the
- *     library never synchronises.
+ *     library never synchronises (drin_index_status apart, which exists to be the caller's synchronisation point).
+ *   - THE DEVICE OF A CALL IS THE DEVICE OF ITS STREAM, not the calling thread's current device: every launching entry
+ *     point asks the stream (hipStreamGetDevice), makes that device current for the duration of the call - kernel
+ *     attributes, launches, memsets and events all land there - and restores the caller's device before it returns.  With
+ *     the NULL stream the device is the one that owns the call's workspace / output pointer (hipPointerGetAttributes), and
+ *     THAT device's default stream is used.  A single process may therefore drive several GPUs from one thread without
+ *     hipSetDevice between calls; pointers of a call must all live on the stream's device.
  *   - tensors are dense row-major fp32 (`float`), index/mask tensors int64 exactly as
  *     `drin/data.py:110-126` collates them.
  */
@@ -30,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DRIN_ABI_VERSION 6
+#define DRIN_ABI_VERSION 7
 #define DRIN_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -40,7 +46,9 @@ typedef enum {
   DRIN_E_ALIGN = -3,     /* a pointer or leading dimension misses the 16-byte alignment contract */
   DRIN_E_WORKSPACE = -4, /* workspace smaller than drin_workspace_bytes()                        */
   DRIN_E_HIP = -5,       /* a HIP runtime call failed (launch error, bad stream, ...)            */
-  DRIN_E_UNSUPPORTED = -6 /* configuration not built (e.g. vector edge features)                */
+  DRIN_E_UNSUPPORTED = -6, /* configuration not built (e.g. vector edge features)               */
+  DRIN_E_INDEX = -7      /* drin_index_status: a candidate row index was outside [0, num_entities - 1]
+                            (the reference's fancy index, drin/data.py:87-93, raises IndexError)  */
 } drin_status;
 
 /* Arithmetic of the contractions.  All other arithmetic is fp32.  Every value here is INSIDE the 1e-4 bar of the path on freshly
@@ -130,8 +138,9 @@ typedef enum {
 } drin_cache_format;
 
 /* The reference resolves `getattr(torch.nn.functional, name)` (model.py:117-118) - any function name.  Built here: the
- * five below for the vertices; sigmoid, tanh and relu for the edges (their backward needs the derivative from the stored
- * OUTPUT; gelu / silu do not offer it).  Every entry point takes them: the layer-by-layer forward / backward and the folded
+ * five below, for the vertices AND for the edges (sigmoid, tanh and relu take their derivative from the stored output; gelu and
+ * silu edges keep the pre-activation for the backward pass - Layout::edge_z; goldens tiny_wd_gelu_edge,
+ * tiny_wm_silu_edge_vector).  Every entry point takes them: the layer-by-layer forward / backward and the folded
  * inference paths (whose default-activation kernels are separate instantiations, unchanged by the switch). */
 typedef enum {
   DRIN_ACT_DEFAULT = 0, /* gelu for vertex_activation, sigmoid for edge_activation (a zero-initialised config is the reference's) */
@@ -178,6 +187,14 @@ typedef struct {
    * every candidate every step.  NULL: the edge reads entity_text itself (the WikiDiverse layout).
    * drin_forward / drin_backward / drin_edges_fwd; the fused inference entry points return DRIN_E_UNSUPPORTED. */
   const float* entity_text_cls;       /* [B, N, D] or NULL                                       */
+  /* Optional, with entity_index: int32[4] in DEVICE memory where the kernels of drin_forward_prepared / drin_forward_cached
+   * REPORT an index outside [0, num_entities - 1].  Such an index is always clamped (no out-of-bounds read whatever the
+   * caller sends) - but the clamped row is another entity's, where the reference's fancy index (drin/data.py:87-93) raises.
+   * The first kernel to meet one sets word 0 to 1 and leaves the pair b * N + n in word 1 and the offending value in words
+   * 2 (low half) and 3 (high half); nothing else ever writes the words: STICKY - the caller zeroes them once and reads them
+   * wherever it synchronises anyway, or through drin_index_status.  NULL: clamp silently.  (The table form of drin_forward /
+   * drin_backward reads rows through the index without clamping: indices must be valid there, see entity_index.) */
+  int32_t* index_status;              /* [4] or NULL                                             */
 } drin_batch;
 
 /* One GCNLayer's parameters (drin/model.py:109-119); nn.Linear layout weight[out][in]. */
@@ -332,6 +349,12 @@ DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* bat
  * tests and benchmarks (which instantiation did this call take?); 0 when cfg is off the folded paths.  No reference
  * counterpart. */
 DRIN_API int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached);
+
+/* The caller-side check of drin_batch.index_status: waits for `stream` (the ONE entry point that synchronises: it exists to be
+ * the point where the caller would synchronise anyway), copies the four words to the host and returns DRIN_OK, or
+ * DRIN_E_INDEX with the pair and the value in drin_last_error() - what drin/data.py:87-93 reports as an IndexError - after
+ * zeroing the words again.  `index_status` is the device pointer given in drin_batch. */
+DRIN_API int drin_index_status(int32_t* index_status, void* stream);
 
 /* ---- per-entity precompute cache for table-form inference ---------------------- *
  * With frozen weights, what the first GCN layer takes from an entity (its rows of the entity_* tables,

@@ -11,8 +11,11 @@ fixed linear functional of the scores and of the triplet loss, and one Adam step
 
 `TripletLoss` lives in `common/utils.py`, whose module import fails on `torchmetrics`; the
 class itself is pure torch, so its source is taken from that file with `ast` and executed
-as is (no stand-in for torchmetrics is written; `TopkAccuracy` subclasses
-`torchmetrics.Metric` and is therefore pinned by hand-computed cases in the tests instead).
+as is (no stand-in for torchmetrics is written).  `TopkAccuracy` subclasses
+`torchmetrics.Metric`, so the CLASS cannot be built - but its `update` and `compute` bodies
+(`common/utils.py:60-69`) are pure torch on `self.top_k / self.correct / self.total`: the two
+function definitions are lifted with `ast` the same way and called, unmodified, on a plain
+namespace carrying those three attributes (`tests/golden/topk.npz`).
 
 usage:  python oracle/gen_golden.py            (writes tests/golden/)
 """
@@ -50,6 +53,20 @@ def _reference_triplet_loss():
 
 
 RefTripletLoss = _reference_triplet_loss()
+
+
+def _reference_topk_methods():
+    """`(update, compute)` of the reference's `TopkAccuracy` (`common/utils.py:60-69`) as plain functions of `self`."""
+    tree = ast.parse(open(os.path.join(REF, "common/utils.py")).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TopkAccuracy")
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("update", "compute")]
+    assert [f.name for f in fns] == ["update", "compute"], [f.name for f in fns]
+    ns = {"torch": torch, "Tensor": torch.Tensor}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "common/utils.py", "exec"), ns)
+    return ns["update"], ns["compute"]
+
+
+ref_topk_update, ref_topk_compute = _reference_topk_methods()
 
 
 def _patch(cfg: DrinConfig) -> None:
@@ -184,11 +201,55 @@ def triplet_cases():
     return out
 
 
+def topk_cases():
+    """The reference `TopkAccuracy.update` / `.compute` (executed from source on a namespace with `top_k`, `correct`, `total`) on
+    seeded `[B, N]` scores / `[B, N-1]` one-hot answers: plain rows, rows full of TIES (scores rounded to multiples of 0.25: the
+    `>=` rule counts every candidate equal to the k-th largest), all-zero answer rows (the gold entity is not among the
+    candidates: `answer == N - 1`), the last column dropped (`utils.py:61-62`), two updates accumulated, ks {1, 5, 10, 20, 50}."""
+    from types import SimpleNamespace
+    out = {}
+    g = np.random.Generator(np.random.Philox(key=[6, 6]))
+    shapes = [(2, 4), (7, 11), (64, 101), (33, 101)]
+    out["ks"] = np.array([1, 5, 10, 20, 50], dtype=np.int64)
+    for i, (B, N) in enumerate(shapes):
+        for ties in (0, 1):
+            yhat = g.random(size=(B, N), dtype=np.float32) * 2 - 1
+            if ties:
+                yhat = np.round(yhat * 4) / 4
+            ans = g.integers(0, N, size=B)
+            ans[0] = N - 1                                            # an all-zero answer row in every case
+            onehot = np.concatenate([np.eye(N - 1, dtype=np.uint8), np.zeros((1, N - 1), dtype=np.uint8)], 0)
+            y = onehot[ans]
+            tag = f"{i}_{ties}"
+            out[f"yhat{tag}"], out[f"y{tag}"] = yhat.astype(np.float32), y
+            for k in out["ks"]:
+                if k > N - 1:
+                    continue
+                m = SimpleNamespace(top_k=int(k), correct=torch.tensor(0), total=torch.tensor(0))
+                ref_topk_update(m, torch.from_numpy(yhat.astype(np.float32)), torch.from_numpy(y))
+                out[f"correct{tag}_k{k}"], out[f"total{tag}_k{k}"] = np.int64(int(m.correct)), np.int64(int(m.total))
+                # a second update on the first half of the rows accumulates; compute() = correct / total
+                ref_topk_update(m, torch.from_numpy(yhat[: (B + 1) // 2].astype(np.float32)), torch.from_numpy(y[: (B + 1) // 2]))
+                out[f"correct2{tag}_k{k}"], out[f"total2{tag}_k{k}"] = np.int64(int(m.correct)), np.int64(int(m.total))
+                out[f"acc2{tag}_k{k}"] = np.float64(float(ref_topk_compute(m)))
+    # y_pred already without the answer slot (shape[1] == y_true.shape[1]): nothing is dropped (utils.py:61)
+    yhat = g.random(size=(5, 10), dtype=np.float32)
+    y = np.eye(10, dtype=np.uint8)[g.integers(0, 10, size=5)]
+    m = SimpleNamespace(top_k=3, correct=torch.tensor(0), total=torch.tensor(0))
+    ref_topk_update(m, torch.from_numpy(yhat), torch.from_numpy(y))
+    out["yhat_same_width"], out["y_same_width"], out["correct_same_width_k3"] = yhat, y, np.int64(int(m.correct))
+    return out
+
+
 def main():
     dst = os.path.join(REPO, "tests", "golden")
     os.makedirs(dst, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if only == ["topk"]:
+        np.savez_compressed(os.path.join(dst, "topk.npz"), **topk_cases())
+        print("wrote topk")
+        return
     if only:  # regenerate just the named cases
         for name in only:
             np.savez_compressed(os.path.join(dst, f"{name}.npz"), **run_case(name))
@@ -200,6 +261,7 @@ def main():
     np.savez_compressed(os.path.join(dst, "tiny_wd_nan.npz"), **nan_case())
     np.savez_compressed(os.path.join(dst, "init_order.npz"), **init_order_case())
     np.savez_compressed(os.path.join(dst, "triplet.npz"), **triplet_cases())
+    np.savez_compressed(os.path.join(dst, "topk.npz"), **topk_cases())
     print("done")
 
 

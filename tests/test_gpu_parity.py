@@ -1089,7 +1089,7 @@ def test_entity_cache_scores_match_oracle_and_uncached(kw):
 
 
 def test_entity_cache_out_of_range_index_and_nan_entity():
-    """Out-of-range candidate indices clamp like the stream kernel's gather; an entity whose token slice is
+    """Out-of-range candidate indices clamp like the stream kernel's gather (and are reported: tests/test_gpu_round6.py); an entity whose token slice is
     empty (ntok <= 2, ghmfc.py:248) scores NaN for its pairs only."""
     from drin_amd.model import EntityTable, IndexedBatch
     cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=12, max_entity_attr_token_len=6, **TINY)
@@ -1109,6 +1109,8 @@ def test_entity_cache_out_of_range_index_and_nan_entity():
     model.load_state_dict(sd)
     with torch.no_grad():
         s = model(IndexedBatch(men[:7], table, cand.to(DEV), men[12], men[13])).cpu()
+        with pytest.raises(IndexError):                              # clamped for memory safety AND reported (round 6; data.py:87-93 raises)
+            model.check_indices()
         clamped = cand.clamp(0, E - 1)
         table.enable_cache(False)
         s2 = model(IndexedBatch(men[:7], table, clamped.to(DEV), men[12], men[13])).cpu()

@@ -1,0 +1,182 @@
+"""-m gpu, round 6 (VERDICT r5 "weak" 3-4, "next" 3-4):
+
+* a candidate row outside the entity tables is REPORTED (the kernels keep clamping it for memory safety): `IndexError` from
+  `Model.check_indices()` / eagerly with `validate_indices`, `DRIN_E_INDEX` from `drin_index_status` for C-ABI callers - what the
+  reference's fancy index (`drin/data.py:87-93`) does;
+* every launching entry point runs on the device of its STREAM, whatever the calling thread's current device is (`DeviceScope`,
+  `include/drin_hip.h`): fused, cached, training step, loss / metric and Adam with tensors on `cuda:1` while `cuda:0` is current
+  (needs two GPUs), and the NULL-stream form that takes the device from the call's pointers (any box).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from drin_amd import _lib, synth
+from drin_amd.config import DrinConfig, wikimel_config
+from drin_amd.metrics import DeviceLossMetric
+from drin_amd.model import EntityTable, IndexedBatch, Model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TINY = dict(bert_embed_dim=64, gcn_embed_dim=64, resnet_embed_dim=128, max_mention_sentence_len=12, resnet_num_region=3)
+
+
+def _to_dev(batch, dev=DEV):
+    return [t.to(dev) for t in batch]
+
+
+def _table_case(E=30, B=3, seed=5, cache=True, dev=DEV, **cfg_kw):
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=12, max_entity_attr_token_len=6, **{**TINY, **cfg_kw})
+    sd = synth.make_state_dict(cfg, 8)
+    tab = synth.make_batch(cfg.with_(num_candidates_data=E - 1), 1, seed)
+    table = EntityTable(tab[7][0], tab[8][0], tab[9][0], tab[10][0], tab[11][0]).to(dev)
+    if cache:
+        table.enable_cache()
+    men = _to_dev(synth.make_batch(cfg, B, seed + 1), dev)
+    cand = torch.randint(0, E, (B, cfg.num_candidates_model), generator=torch.Generator().manual_seed(1))
+    return cfg, sd, table, men, cand
+
+
+@pytest.mark.parametrize("cache", [True, False], ids=["k_cached_pairs", "k_entity_stream"])
+def test_out_of_range_candidate_rows_raise_like_the_reference_fancy_index(cache):
+    """-4 and E + 9 among the candidate rows: the kernels clamp them (no out-of-bounds read - the scores of those pairs are the
+    clamped entity's, as before) and report them; `check_indices()` raises IndexError naming the row, then the report is cleared;
+    with `validate_indices` the call itself raises; a valid batch never raises and scores the same bits as before the bad call."""
+    E = 30
+    cfg, sd, table, men, cand = _table_case(E=E, cache=cache)
+    model = Model(cfg, precision="bf16x3_all").to(DEV).eval()
+    model.load_state_dict(sd)
+    good = IndexedBatch(men[:7], table, cand.to(DEV), men[12], men[13])
+    bad_rows = cand.clone()
+    bad_rows[1, 0], bad_rows[2, 5] = -4, E + 9
+    bad = IndexedBatch(men[:7], table, bad_rows.to(DEV), men[12], men[13])
+    with torch.no_grad():
+        s_good = model(good)
+        model.check_indices()                                         # nothing to report
+        s_bad = model(bad)                                            # clamped: returns scores
+        with pytest.raises(IndexError, match=r"row (-4|39) at pair"):
+            model.check_indices()
+        model.check_indices()                                         # cleared by the raise
+        clamped = IndexedBatch(men[:7], table, bad_rows.clamp(0, E - 1).to(DEV), men[12], men[13])
+        assert torch.equal(model(clamped), s_bad)                     # memory-safe clamp: unchanged semantics
+        assert torch.equal(model(good), s_good)
+        model.check_indices()
+        # the lazy form: a later forward raises once the asynchronous read-back of the bad call has landed
+        model(bad)
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            model(good)
+        assert torch.equal(model(good), s_good)                       # and the report is gone again
+        # eager validation: the reference's behaviour, one synchronisation per call
+        model.validate_indices = True
+        with pytest.raises(IndexError):
+            model(bad)
+        assert torch.equal(model(good), s_good)
+
+
+def test_out_of_range_candidate_rows_in_a_training_step_raise():
+    """The table form of the training entry points reads rows through the index without clamping: `Model` clamps first and reports
+    what it clamped through the same status words."""
+    E = 40
+    cfg, sd, table, men, cand = _table_case(E=E, B=100, cache=False, bert_embed_dim=128, gcn_embed_dim=128)   # >= 1024 pairs: the indexed kernels
+    model = Model(cfg).to(DEV).train()
+    model.load_state_dict(sd)
+    bad_rows = cand.clone()
+    bad_rows[7, 3] = E
+    model(IndexedBatch(men[:7], table, cand.to(DEV), men[12], men[13])).sum().backward()
+    model.check_indices()
+    model(IndexedBatch(men[:7], table, bad_rows.to(DEV), men[12], men[13])).sum().backward()
+    with pytest.raises(IndexError, match="outside the entity tables"):
+        model.check_indices()
+
+
+def test_c_abi_index_status_and_null_stream_device_from_the_pointer():
+    """`drin_index_status` on device words: DRIN_OK when clean; DRIN_E_INDEX with row and pair in `drin_last_error()` after a report,
+    and the words are zeroed again.  Called with the NULL stream: the device comes from the pointer (DeviceScope)."""
+    lib = _lib.load()
+    words = torch.zeros(4, dtype=torch.int32, device=DEV)
+    assert lib.drin_index_status(words.data_ptr(), None) == _lib.OK
+    words.copy_(torch.tensor([1, 205, -4, -1], dtype=torch.int32))   # what report_bad_index leaves for row -4 at pair 205
+    st = lib.drin_index_status(words.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert st == _lib.E_INDEX
+    msg = lib.drin_last_error().decode()
+    assert "row -4" in msg and "pair 205" in msg, msg
+    assert words.cpu().tolist() == [0, 0, 0, 0] or int(words[0]) == 0
+    assert lib.drin_index_status(None, None) == _lib.E_NULL
+    # a launching entry point on the NULL stream: the split of a vector into bf16 planes, checked against torch
+    x = torch.randn(4096, device=DEV)
+    hi = torch.empty(4096, dtype=torch.bfloat16, device=DEV)
+    lo = torch.empty_like(hi)
+    torch.cuda.synchronize()
+    _lib.check(lib.drin_split_planes(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    assert (hi.float() + lo.float() - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_every_entry_point_runs_on_the_device_of_its_stream():
+    """Tensors, weights and streams on cuda:1 while cuda:0 is the thread's current device: the folded inference path, the
+    per-entity cache path (cache build included), a training step (forward, loss + metric, backward, library Adam) - all equal,
+    bit for bit, to the same work with cuda:0 current and resident; and the current device is what it was afterwards."""
+    from drin_amd.train import LibraryAdam
+    cfg = wikimel_config(max_entity_attr_token_len=8)
+    sd = synth.make_state_dict(cfg, 7)
+    outs = {}
+    for d in ("cuda:0", "cuda:1"):
+        torch.cuda.set_device(0)                                      # never the second device
+        res = []
+        m = Model(cfg).to(d).eval()
+        m.load_state_dict(sd)
+        batch = [t.to(d) for t in synth.make_batch(cfg, 300, 5)]
+        with torch.no_grad():
+            res.append(m(batch[:14]).cpu())                           # fused path (73 KB dynamic LDS: per-device opt-in)
+        tab = synth.make_batch(cfg.with_(num_candidates_data=199), 1, 9)
+        table = EntityTable(tab[7][0], tab[8][0], tab[9][0], tab[10][0], tab[11][0]).to(d).enable_cache()
+        cand = torch.randint(0, 200, (300, cfg.num_candidates_model), generator=torch.Generator().manual_seed(3)).to(d)
+        with torch.no_grad():
+            res.append(m(IndexedBatch(batch[:7], table, cand, batch[12], batch[13])).cpu())   # cache build + cached path
+        m.check_indices()
+        m.train()
+        opt = LibraryAdam(m, lr=1e-3)
+        meter = DeviceLossMetric(cfg.triplet_margin, [1, 5], d)
+        small = [t[:64] for t in batch]
+        for _ in range(2):
+            opt.zero_grad()
+            loss = meter(small[-1], m(small[:14]))
+            loss.backward()
+            opt.step()
+        res += [loss.detach().cpu(), meter.correct.cpu()] + [p.detach().cpu() for p in m.parameters()]
+        assert torch.cuda.current_device() == 0
+        outs[d] = res
+    for a, b in zip(outs["cuda:0"], outs["cuda:1"]):
+        assert torch.equal(a, b)
+
+
+def test_device_topk_counters_match_the_reference_source(golden_dir):
+    """`drin_triplet_topk`'s counters against `tests/golden/topk.npz` - counts the reference's own `TopkAccuracy.update` body
+    produced (`common/utils.py:60-66`, run from source by `oracle/gen_golden.py`): ties with the k-th largest score count, an
+    all-zero answer row never does, a second call accumulates."""
+    g = np.load(os.path.join(golden_dir, "topk.npz"))
+    all_ks = [int(k) for k in g["ks"]]
+    cases = 0
+    for name in g.files:
+        if not name.startswith("yhat") or name == "yhat_same_width":
+            continue
+        tag = name[4:]
+        yhat, y = torch.from_numpy(g[name]), torch.from_numpy(g["y" + tag])
+        B, N = yhat.shape
+        ks = [k for k in all_ks if k <= N - 1]
+        m = DeviceLossMetric(0.25, ks, DEV)
+        m(y.to(DEV), yhat.to(DEV))
+        assert m.correct.tolist() == [int(g[f"correct{tag}_k{k}"]) for k in ks] and m.total == B, tag
+        half = (B + 1) // 2
+        m(y[:half].to(DEV), yhat[:half].to(DEV))
+        assert m.correct.tolist() == [int(g[f"correct2{tag}_k{k}"]) for k in ks] and m.total == int(g[f"total2{tag}_k{ks[0]}"]), tag
+        for q, k in enumerate(ks):
+            assert abs(m.accuracies()[q] - float(g[f"acc2{tag}_k{k}"])) <= 1e-7
+        cases += 1
+    assert cases == 8

@@ -112,6 +112,42 @@ def test_topk_known_answer():
     assert O.topk_counts(yhat, y, 2) == (2, 3)
 
 
+def _topk_fixture_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "topk.npz"))
+    ks = [int(k) for k in g["ks"]]
+    for name in g.files:
+        if name.startswith("yhat") and name != "yhat_same_width":
+            tag = name[4:]
+            yield g, tag, torch.from_numpy(g[name]), torch.from_numpy(g["y" + tag]), ks
+
+
+def test_topk_accuracy_matches_the_reference_source(golden_dir):
+    """`tests/golden/topk.npz`: counts produced by the reference's own `TopkAccuracy.update` / `.compute` bodies
+    (`common/utils.py:60-69`, lifted with `ast` by `oracle/gen_golden.py` and run on a namespace with `top_k`, `correct`, `total`):
+    plain rows, tie-ridden rows, all-zero answer rows, two accumulated updates, ks {1, 5, 10, 20, 50}.  The oracle's
+    `topk_counts` and the product's host-side `metrics.TopkAccuracy` reproduce every count and the computed accuracy."""
+    from drin_amd.metrics import TopkAccuracy
+    seen = 0
+    for g, tag, yhat, y, ks in _topk_fixture_cases(golden_dir):
+        B = yhat.shape[0]
+        half = (B + 1) // 2
+        for k in ks:
+            if k > yhat.shape[1] - 1:
+                assert f"correct{tag}_k{k}" not in g.files
+                continue
+            assert O.topk_counts(yhat, y, k) == (int(g[f"correct{tag}_k{k}"]), int(g[f"total{tag}_k{k}"]))
+            m = TopkAccuracy(k)
+            m.update(yhat, y)
+            assert (int(m.correct), int(m.total)) == (int(g[f"correct{tag}_k{k}"]), B)
+            m.update(yhat[:half], y[:half])
+            assert (int(m.correct), int(m.total)) == (int(g[f"correct2{tag}_k{k}"]), int(g[f"total2{tag}_k{k}"]))
+            assert abs(float(m.compute()) - float(g[f"acc2{tag}_k{k}"])) <= 1e-7
+            seen += 1
+    assert seen == 28          # (2,4): k=1; (7,11): k in {1,5,10}; the two 101-wide shapes: all five - x2 (plain, ties)
+    g = np.load(os.path.join(golden_dir, "topk.npz"))            # scores already without the answer slot: nothing dropped
+    assert O.topk_counts(torch.from_numpy(g["yhat_same_width"]), torch.from_numpy(g["y_same_width"]), 3)[0] == int(g["correct_same_width_k3"])
+
+
 def test_cosine_semantics_pinned():
     """torch>=2 clamps each norm separately."""
     x = torch.tensor([[1e-9, 0.0]])

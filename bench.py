@@ -326,6 +326,8 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
                    else measured_traffic("k_entity_stream", "kernels", default_cfg))
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                # `traffic` is NOT measured in this run: PMC passes need their own rocprofv3 invocation
+                "traffic_replayed": bool(traffic), "traffic_file": (TRAFFIC_FILE if traffic else None),
                 "traffic_source": (f"{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration "
                                    "(tools/collect_pmc.py), replayed - not re-measured in this run") if traffic else None,
                 "launches": int(launches), "avg_launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": work}
@@ -358,13 +360,20 @@ def score_roofline(cfg, batch, B, prof, steps, precision, features, workload, ca
 
 
 def if16_taken(precision, cfg, workload, B, features="f32"):
-    """Whether a call takes the one-pass fp16 image contraction: the library's own gate (csrc/fused_forward.hip: N >= 64, the exact
-    widths, per-pair fp32-stored rows, at least 128 tiles of 256 x 256) - a `bf16x3_if16` line of any other shape ran split-bf16 and
-    says so."""
-    D, R, N = cfg.bert_embed_dim, cfg.resnet_embed_dim, cfg.num_candidates_model
-    tiles = -(-B * N // 256) * -(-D // 256)
-    return (precision == "bf16x3_if16" and N >= 64 and D == 768 and R == 2048 and workload != "table" and features == "f32"
-            and tiles >= 128)
+    """Whether a call takes the one-pass fp16 image contraction: asked of the LIBRARY (`drin_image_contraction_passes`, the gate
+    `csrc/fused_forward.hip` itself applies - N >= 64, the exact widths, per-pair fp32-stored rows, at least 128 tiles of
+    256 x 256): a `bf16x3_if16` line of any other shape ran split-bf16 and says so."""
+    if precision != "bf16x3_if16":
+        return False
+    import ctypes as C
+    from drin_amd import _lib
+    c = _lib.DrinConfigC()
+    _lib.check(_lib.load().drin_default_config(C.byref(c)))
+    c.batch, c.num_candidates, c.embed_dim, c.image_dim = B, cfg.num_candidates_model, cfg.bert_embed_dim, cfg.resnet_embed_dim
+    c.entity_tokens = cfg.max_entity_attr_token_len if cfg.token_level_entities else 0
+    c.precision = _lib.PREC_BF16X3_IF16
+    c.feature_dtype = _lib.FEAT_BF16 if features == "bf16" else _lib.FEAT_F32
+    return _lib.load().drin_image_contraction_passes(C.byref(c), 1 if workload == "table" else 0) == 1
 
 
 def whole_path_fractions(cfg, ab, flops_pair, rate_per_gpu, precision, workload="wikimel", B=1 << 20, features="f32"):
@@ -461,6 +470,7 @@ def cpu_baseline(cfg, sd, seconds=10.0):
             "reference_style_loops_value": it_r * B * N / el_r,
             "wikidiverse_b64_value": it_w * 64 * wd.num_candidates_model / el_w,
             "headline_shape_b64_value": b64,
+            "b64_value": b64,                      # SURVEY.md 8d's sample size (B = 64) beside `value` (B = 8: the CPU's better figure)
             "sample": f"{it} CPU-oracle forwards, {cfg.dataset_name}-shaped B={B} N={N} fp32, {torch.get_num_threads()} torch threads, {el:.1f} s",
             "other_samples": f"reference-style loops {it_r} forwards {el_r:.1f} s; wikidiverse-shaped B=64 N={wd.num_candidates_model}: "
                              f"{it_w} forwards {el_w:.1f} s"}
@@ -1045,7 +1055,7 @@ def quiet_stdout():
 LEGS_FILE = os.path.join(REPO, "bench_legs.json")
 LINE_LIMIT = 4096                 # bytes of the stdout line (the driver keeps an 8 KB tail; round 4's 32 KB line was not parsed)
 
-_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms",
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_replayed", "traffic_file", "launches", "avg_launch_ms",
               "algorithmic_bytes_per_launch", "executed_frac", "mfma_busy")
 _HEAD_KEYS = ("metric", "stub", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "rank_ms_per_step", "roofline", "cpu_baseline", "parity", "hbm_fraction_whole_path",
@@ -1101,7 +1111,7 @@ def headline_only(line, legs_file=None):
     if isinstance(head.get("roofline"), dict):
         head["roofline"] = _pick(head["roofline"], _ROOF_KEYS)
     if isinstance(head.get("cpu_baseline"), dict):
-        head["cpu_baseline"] = _pick(head["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+        head["cpu_baseline"] = _pick(head["cpu_baseline"], ("value", "b64_value", "unit", "cores", "kind", "sample"))
     if isinstance(head.get("parity"), dict):
         head["parity"] = _pick(head["parity"], ("max_abs_score_err", "top1_agreement", "mentions"))
     if isinstance(head.get("collective"), dict):
@@ -1147,7 +1157,20 @@ def emit(line, legs_file=""):
     sys.stderr.write(f"[bench.py] full record ({len(full)} bytes): {wrote or 'not written'}\n")
     sys.stderr.flush()
     text = json.dumps(headline_only(line, wrote), allow_nan=False)
-    assert len(text) <= LINE_LIMIT, len(text)
+    if len(text) > LINE_LIMIT:
+        # never no line at all: the contract fields alone, strings cut short (an `assert` here would end the run without a JSON
+        # line - an INCOMPLETE record - and vanishes under `python -O`)
+        short = {k: v for k, v in _strict(_pick(line, _HEAD_KEYS[:14])).items()}
+        for k, v in list(short.items()):
+            if isinstance(v, str):
+                short[k] = v[:120]
+            elif isinstance(v, dict):
+                short[k] = {a: (b[:80] if isinstance(b, str) else b) for a, b in v.items() if not isinstance(b, (dict, list))}
+        short["truncated"] = True
+        if wrote:
+            short["legs_file"] = os.path.relpath(wrote, REPO) if wrote.startswith(REPO) else wrote
+        text = json.dumps(short, allow_nan=False)
+        sys.stderr.write(f"[bench.py] headline line was {len(text)} bytes after truncation to the contract fields\n")
     out = _REAL_STDOUT or sys.stdout
     out.write(text + "\n")
     out.flush()

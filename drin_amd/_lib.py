@@ -97,6 +97,7 @@ EXPORTS = {
     "drin_fused_workspace_bytes": (C.c_size_t, [C.POINTER(DrinConfigC)]),
     "drin_workgroups_per_mention": (C.c_int32, [C.POINTER(DrinConfigC), C.c_int32]),
     "drin_index_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "drin_image_contraction_passes": (C.c_int32, [C.POINTER(DrinConfigC), C.c_int32]),
     "drin_prepare": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinParamsC), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drin_forward_prepared": (C.c_int, [C.POINTER(DrinConfigC), C.POINTER(DrinBatchC), C.POINTER(DrinParamsC), C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -195,7 +195,6 @@ struct CachedArgs {
   const float* cache;            // [E][ldc]
   int64_t ldc, num_entities;
   const int64_t* entity_index;   // [M]
-  int32_t* index_status;         // optional int32[4]: where a clamped entity_index is reported (drin_batch.index_status)
   const float* miet;             // [M]
   const float* mtei;             // [M]
   const float* span_mean;        // [B, D]
@@ -218,6 +217,17 @@ struct CachedArgs {
   float mask[4];
   float cos_eps, miei_eps, clip, ln_eps;
 };
+
+// k_cached_pairs clamps a candidate row outside the tables (memory safety) but has no register left to REPORT it (256 VGPRs:
+// the compare-and-report cost a spill): when the caller gave drin_batch.index_status, this pass over the M indices does -
+// 8 bytes per pair against the 16-23 KB of cache row the pair's scoring reads (a 4 096 x 1 001 chunk: ~10 us of 35 ms).
+__global__ void __launch_bounds__(256) k_check_entity_index(const int64_t* __restrict__ index, int64_t M, int64_t num_entities,
+                                                            int32_t* __restrict__ status) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < M; p += (int64_t)gridDim.x * 256) {
+    const int64_t e = index[p];
+    if (e < 0 || e >= num_entities) report_bad_index(status, p, e);
+  }
+}
 
 // grid (chunks, B), 256 threads; wave w takes candidates c0 + w, c0 + w + 4, ... of its chunk
 #ifndef DRIN_CACHED_PAIRS_WG_PER_CU
@@ -276,12 +286,11 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
       v[k] = n < n_end ? a.entity_index[b * a.N + n] : 0;
     }
   };
-  auto uniform_indices = [&](int64_t (&dst)[4], const int64_t (&v)[4], int base) {
+  auto uniform_indices = [&](int64_t (&dst)[4], const int64_t (&v)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int64_t e = v[k];
       e = e < 0 ? 0 : (e >= a.num_entities ? a.num_entities - 1 : e);
-      if (e != v[k] && lane == 0) report_bad_index(a.index_status, b * a.N + base + wave + 4 * k, v[k]);   // clamped (memory safety) and reported
       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)e), hi = __builtin_amdgcn_readfirstlane((uint32_t)(e >> 32));
       dst[k] = (int64_t)(((uint64_t)hi << 32) | lo);
     }
@@ -340,7 +349,7 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     r.miet = a.miet[p];
   };
   PairRow ra, rb;  // two named buffers (an indexed array of them ends up in scratch memory)
-  uniform_indices(ent, ent_v, n_begin);
+  uniform_indices(ent, ent_v);
   if (n_begin + wave < n_end) fetch(ra, ent[0], b * a.N + n_begin + wave);  // first row: in flight under the rest of the prologue
 
   for (int i = wave; i < a.Km; i += 4) {  // model.py:88 re-normalises the same mention rows for every pair
@@ -491,7 +500,7 @@ __global__ void __launch_bounds__(256, DRIN_CACHED_PAIRS_WG_PER_CU) k_cached_pai
     step(ra, rb, n0, ent[0], ent[1]);
     step(rb, ra, n0 + 4, ent[1], ent[2]);
     step(ra, rb, n0 + 8, ent[2], ent[3]);
-    if (more) uniform_indices(nxt, nxt_v, g + 16);
+    if (more) uniform_indices(nxt, nxt_v);
     step(rb, ra, n0 + 12, ent[3], nxt[0]);
     if (!EXACT) break;
 #pragma unroll
@@ -820,6 +829,14 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   float* hmfu = ws + L.hmfu;
   DRIN_TRY(launch_gemm_nt(vm0, D, pb + P.wcat1, D, pb + P.bcat1, hmfu, 2 * D, 2 * (int64_t)B, 2 * D, D, false, prec, st, sk, skf));
 
+  // candidate rows outside the tables: clamped by k_cached_pairs, reported here (drin_batch.index_status)
+  if (b->index_status) {
+    const int64_t pairs = (int64_t)B * cfg->num_candidates;
+    KernelTimer timer(DRIN_KC_EDGE, st);
+    hipLaunchKernelGGL(k_check_entity_index, dim3((unsigned)std::min<int64_t>(cdiv(pairs, 256), 2048)), dim3(256), 0, st, b->entity_index, pairs,
+                       (int64_t)cfg->num_entities, b->index_status);
+    DRIN_CHECK_LAUNCH("k_check_entity_index");
+  }
   // (2) one gathered pass over the cache rows: edges, layer-1 entity vertices, all cross-candidate sums
   CachedArgs a;
   memset(&a, 0, sizeof(a));
@@ -827,7 +844,6 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   a.ldc = (int64_t)cache_row_floats(*cfg);
   a.num_entities = cfg->num_entities;
   a.entity_index = b->entity_index;
-  a.index_status = b->index_status;
   a.miet = b->miet_similarity;
   a.mtei = b->mtei_similarity;
   a.span_mean = ws + L.span_mean;

@@ -81,7 +81,10 @@ struct FusedLayout {  // workspace offsets in floats
     mt2 = take(B * D);
     const bool planes = c.precision == DRIN_PREC_BF16X3 || c.precision == DRIN_PREC_BF16X3_ALL || c.precision == DRIN_PREC_BF16X3_IF16;
     p_xt = take(planes ? M * D : 0);   // hi plane (M*D bf16) then lo plane
-    p_xi = take(planes ? M * R : 0);   // the table form's (hi, lo) image planes; DRIN_PREC_BF16X3_IF16: the one fp16 plane (its first half)
+    // image planes, sized by use: the table form (cfg.num_entities > 0: entity_index gathers rows, so the stream kernel
+    // writes them as (hi, lo) bf16 planes) M R floats; DRIN_PREC_BF16X3_IF16 the one fp16 plane, M R / 2; gathered split-bf16
+    // batches read the image rows in place: nothing (3.4 GB less workspace at the headline batch)
+    p_xi = take(!planes ? 0 : c.num_entities > 0 ? M * R : c.precision == DRIN_PREC_BF16X3_IF16 ? M * R / 2 : 0);
     p_et1 = take(planes ? M * D : 0);
     xi_scale = take(c.precision == DRIN_PREC_BF16X3_IF16 ? M : 0);   // per-pair power-of-two scale of the image row
     // split-K partials of the mention-sized exact-fp32 products (small batches: the call is a chain of ~25 launches)
@@ -105,6 +108,16 @@ struct FusedLayout {  // workspace offsets in floats
     total = off;
   }
 };
+
+// The configuration part of the DRIN_PREC_BF16X3_IF16 gate (what is left - 16-byte alignment of workspace slots - holds by the
+// workspace contract): split-bf16 widths, per-pair fp32-stored rows, a list long enough to average the pass's rounding, the exact
+// widths the stream kernel's fp16 hand-over is instantiated for, at least half a round of 256 x 256 tiles.
+static bool if16_gate(const drin_config* c, bool indexed) {
+  const int64_t M = (int64_t)c->batch * c->num_candidates;
+  return c->precision == DRIN_PREC_BF16X3_IF16 && !indexed && c->feature_dtype == DRIN_FEAT_F32 &&
+         c->num_candidates >= kMixedMinCandidates && c->embed_dim == 768 && c->image_dim == 2048 &&
+         cdiv(M, 256) * cdiv(c->embed_dim, 256) >= 128;
+}
 
 int fused_supported(const drin_config* c) {
   if (c->num_layers != 2) {
@@ -276,10 +289,7 @@ static int forward_prepared_on_stream(const drin_config* cfg, const drin_batch* 
   // (the candidate-count gate: with freshly initialised weights the fp16 pass costs 8e-6 at N = 11, but once the weights are
   //  TRAINED the vertex -> score map steepens and 11 candidates average too little - 1.2e-4 after 200 Adam steps, outside the bar;
   //  at N = 101 the same weights give 2e-5: profiles/r4_precision_on_trained_weights.txt)
-  const bool if16 = cfg->precision == DRIN_PREC_BF16X3_IF16 && planes && !indexed && cfg->feature_dtype == DRIN_FEAT_F32 &&
-                    cfg->num_candidates >= kMixedMinCandidates &&
-                    D == 768 && R == 2048 &&   // (the stream kernel's fp16 hand-over is an instantiation of the exact widths)
-                    gemm_f16_planes_fits(ws + L.p_xi, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
+  const bool if16 = if16_gate(cfg, indexed) && gemm_f16_planes_fits(ws + L.p_xi, R, pb + P.p_cimg_f16, R, ws + L.h_image, D, M, D, R);
   if (b->entity_text_cls) {
     set_error("drin_forward_prepared: entity_text_cls (text pooled ahead of time) is a form of the training entry points");
     return DRIN_E_UNSUPPORTED;
@@ -542,6 +552,13 @@ int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached) {
   FusedLayout L;
   L.build(*cfg);
   return L.chunks;
+}
+
+int32_t drin_image_contraction_passes(const drin_config* cfg, int32_t indexed) {
+  if (validate_config(cfg) != DRIN_OK || fused_supported(cfg) != DRIN_OK) return 0;
+  if (cfg->precision == DRIN_PREC_F32) return 0;
+  if (if16_gate(cfg, indexed != 0)) return 1;
+  return cfg->feature_dtype == DRIN_FEAT_BF16 ? 2 : 3;
 }
 
 int drin_index_status(int32_t* index_status, void* stream) {

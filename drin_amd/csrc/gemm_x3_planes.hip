@@ -303,6 +303,12 @@ __global__ void __launch_bounds__(THREADS, 2)
 // instructions per unit per wave), which retires what phase g + 1 reads first; the delayed half waits one barrier later, and
 // the second barrier of the phase still lies between its wait and anybody's read.  A slot is re-filled two or more phases
 // after its last read, whose lgkmcnt(0) precedes the MFMAs of that phase.
+// The fp16 form's two scales (row, weight plane) are powers of two: their EXPONENTS are added and applied with one ldexp per
+// element, so that an extreme row scale (2^126) next to a weight scale other than 1 never overflows or flushes an intermediate
+// product `row_scale * b_scale` that the result itself does not need.
+__device__ __forceinline__ int pow2_exponent(float s) { return (int)((__builtin_bit_cast(uint32_t, s) >> 23) & 0xffu) - 127; }
+__device__ __forceinline__ float4 scale_pow2(float4 v, int e) { return make_float4(ldexpf(v.x, e), ldexpf(v.y, e), ldexpf(v.z, e), ldexpf(v.w, e)); }
+
 namespace p4 {
 
 #ifndef DRIN_P4_TERM_MAJOR
@@ -540,19 +546,19 @@ __global__ void __launch_bounds__(THREADS, 2)
       for (int i = 0; i < 4; ++i) {
         // (fp16 form: a slice carries its rows' scale like the part stored to C - powers of two, so the sum of scaled slices is the scaled sum)
         const int64_t row = m0 + a * 128 + wm * 64 + i * 16 + r;
-        const float rs = F16 ? row_scale[row < M ? row : M - 1] * *b_scale : 1.0f;
+        const int rs = F16 ? pow2_exponent(row_scale[row < M ? row : M - 1]) + pow2_exponent(*b_scale) : 0;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]);
-            if (F16) o = o * rs;
+            if (F16) o = scale_pow2(o, rs);
             st4(part + (a * 128 + wm * 64 + i * 16 + r) * BN + b * 128 + wn * 32 + j * 16 + c * 4, o);
           }
       }
     return;
   }
-  const float bs = F16 ? *b_scale : 1.0f;
+  const int bs = F16 ? pow2_exponent(*b_scale) : 0;
   float4 bv[2][2];   // the bias of this lane's four column groups, fetched once (a load per store would serialise the stores)
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -567,7 +573,7 @@ __global__ void __launch_bounds__(THREADS, 2)
     for (int i = 0; i < 4; ++i) {
       const int64_t row = m0 + a * 128 + wm * 64 + i * 16 + r;
       if (row >= M) continue;
-      const float rs = F16 ? row_scale[row] * bs : 1.0f;
+      const int rs = F16 ? pow2_exponent(row_scale[row]) + bs : 0;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -575,7 +581,7 @@ __global__ void __launch_bounds__(THREADS, 2)
           const int col = n0 + b * 128 + wn * 32 + j * 16 + c * 4;
           if (col >= N) continue;   // N % 4 == 0 (checked by the launcher)
           float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]);
-          if (F16) o = o * rs;
+          if (F16) o = scale_pow2(o, rs);
           st4(C + row * ldc + col, o + bv[b][j]);
         }
     }

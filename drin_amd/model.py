@@ -136,45 +136,75 @@ class EntityTable:
         self.text, self.mask, self.image, self.object, self.object_score = text, mask, image, object, object_score
         self.cache_enabled = False
         self.cache_format = "f32"
+        self.cache_format_forced = False
+        self.cache_format_used: Optional[str] = None          # row format of the cache that is built right now
+        self._scale_scan = None
+        self._fmt_key = None
         self._cache: Optional[torch.Tensor] = None
         self._cache_key = None
         self._pooled = None
 
-    def enable_cache(self, on: bool = True, format: str = "f32") -> "EntityTable":
+    # a row whose largest |x| exceeds this many times the median row's can dominate a mention's mean_n(ii ei): the mixed-f16
+    # format is then not used for the table (see enable_cache)
+    MIXED_F16_MAX_ROW_RATIO = 8.0
+
+    def enable_cache(self, on: bool = True, format: str = "f32", force: bool = False) -> "EntityTable":
         """Let inference calls score from a per-entity precompute cache (`drin_build_entity_cache`):
         23.5 KB per entity at D=768 / R=2048, rebuilt by the first inference call after any weight change.
         `format="mixed_f16"` (`DRIN_CACHE_MIXED_F16`): the operands of per-pair scalars - the two edge-update rows and the object
         row - are stored as fp16 under a power-of-two scale per row and field, the vertex contractions and the CLS row stay
-        fp32: 16.4 KB per entity, scores within ~2e-7 of the fp32 rows' (`oracle/precision_emulation.py`)."""
+        fp32: 16.4 KB per entity, scores within ~2e-7 of the fp32 rows' (`oracle/precision_emulation.py`).
+        The format holds a per-pair scalar (edge logit, image-image edge) to ~1e-5 and relies on the mention aggregates
+        `mean_n(edge x vertex)` (`model.py:143-144`) averaging that over the candidates.  ONE candidate whose image row is orders of
+        magnitude larger than the others' dominates the mean instead (measured: 1e-5 .. 7e-5 on the scores with rows x 1e6 - inside
+        the 1e-4 bar, outside the 1e-5 guard).  So the format is used only for tables it is safe for BY CONSTRUCTION: the cache
+        build scans the image table once per table version, and when any row's largest |x| exceeds `MIXED_F16_MAX_ROW_RATIO` (8) x
+        the median row's - a share of at most 8 / (8 + N - 1) of a mention's aggregate: <= 6e-6 at N = 101 - the table gets
+        fp32 rows, with a `UserWarning` saying so (`cache_format_used` tells which format a built cache has).
+        `force=True` keeps the fp16 fields whatever the scan finds (the emulation tests that pin the format's limit use it)."""
         if format not in _lib.CACHE_FORMATS:
             raise ValueError(f"cache format {format!r}: one of {sorted(_lib.CACHE_FORMATS)}")
         self.cache_enabled = on
-        if not on or format != self.cache_format:
+        if not on or format != self.cache_format or force != self.cache_format_forced:
             self._cache, self._cache_key = None, None
-        self.cache_format = format
+        self.cache_format, self.cache_format_forced = format, force
         return self
 
-    def _warn_if_rows_far_off_scale(self) -> None:
-        """The mixed-f16 row format holds a per-pair scalar (edge logit, image-image edge) to ~1e-5; the mention aggregates average
-        that over the candidates - unless ONE candidate's image vertex is orders of magnitude larger than the others' and dominates
-        the mean (`include/drin_hip.h`, drin_cache_format: measured 1e-5 .. 7e-5 on the scores with image rows x 1e6).  Checked once
-        per cache build (one pass over the image table, one host sync): rows whose largest |x| exceeds 1 000 x the median row's."""
+    def _rows_far_off_scale(self):
+        """`(far, rows)`: how many image rows have a largest |x| above MIXED_F16_MAX_ROW_RATIO x the median row's.  One pass over
+        the image table per table VERSION (no copy of it: max(amax, -amin); one host read-back), not per cache build."""
+        img = self.image
+        key = (img.data_ptr(), img._version, tuple(img.shape))
+        if self._scale_scan is None or self._scale_scan[0] != key:
+            flat = img.reshape(img.shape[0], -1)
+            m = torch.maximum(flat.amax(1), -flat.amin(1)).float()
+            finite = m[torch.isfinite(m) & (m > 0)]
+            far = int((finite > self.MIXED_F16_MAX_ROW_RATIO * finite.median()).sum()) if finite.numel() else 0
+            self._scale_scan = (key, far, int(m.numel()))
+        return self._scale_scan[1], self._scale_scan[2]
+
+    def _effective_cache_format(self) -> str:
+        if self.cache_format != "mixed_f16":
+            return self.cache_format
+        far, rows = self._rows_far_off_scale()
+        if far == 0:
+            return "mixed_f16"
         import warnings
-        m = self.image.reshape(self.image.shape[0], -1).abs().amax(1).float()
-        finite = m[torch.isfinite(m) & (m > 0)]
-        if finite.numel() == 0:
-            return
-        far = int((finite > 1e3 * finite.median()).sum())
-        if far:
-            warnings.warn(f"EntityTable cache format mixed_f16: {far} of {m.numel()} entity image rows are more than 1 000 x the median row's "
-                          f"magnitude; mentions that list such an entity may score up to ~1e-4 from the fp32 rows (inside the 1e-4 bar, outside "
-                          f"the 1e-5 guard) - use format='f32' for tables like this", UserWarning, stacklevel=3)
+        if self.cache_format_forced:
+            warnings.warn(f"EntityTable cache format mixed_f16 (forced): {far} of {rows} entity image rows are more than "
+                          f"{self.MIXED_F16_MAX_ROW_RATIO:g} x the median row's magnitude; mentions that list such an entity may score up to "
+                          f"~1e-4 from the fp32 rows", UserWarning, stacklevel=4)
+            return "mixed_f16"
+        warnings.warn(f"EntityTable cache format mixed_f16: {far} of {rows} entity image rows are more than {self.MIXED_F16_MAX_ROW_RATIO:g} x "
+                      f"the median row's magnitude - such a row can dominate a mention's aggregate and carry its one fp16 edge's rounding "
+                      f"(up to ~1e-4) into the scores; this table gets fp32 cache rows instead (format='f32')", UserWarning, stacklevel=4)
+        return "f32"
 
     def invalidate(self) -> "EntityTable":
         """Drop the per-entity cache and the pooled-text copy.  Needed only after the tables were edited through a path
         PyTorch's version counters do not see (`t.data.copy_(...)`, an external kernel writing the storage): in-place torch
         ops on the tensors and replaced tensors are detected by themselves."""
-        self._cache, self._cache_key, self._pooled = None, None, None
+        self._cache, self._cache_key, self._pooled, self._scale_scan = None, None, None, None
         return self
 
     def _table_key(self):
@@ -182,7 +212,11 @@ class EntityTable:
                      if t is not None)
 
     def _get_cache(self, call: "_Call", key, pc, prepared: torch.Tensor) -> torch.Tensor:
-        call.cfg.cache_format = _lib.CACHE_FORMATS[self.cache_format]
+        fmt = self.cache_format_used if (self._cache is not None and self._fmt_key == (self.cache_format, self.cache_format_forced, self._table_key())) \
+            else self._effective_cache_format()
+        self._fmt_key = (self.cache_format, self.cache_format_forced, self._table_key())
+        self.cache_format_used = fmt
+        call.cfg.cache_format = _lib.CACHE_FORMATS[fmt]
         key = (key, call.cfg.precision, call.cfg.num_entities, call.cfg.cache_format, self._table_key())
         if key != self._cache_key or self._cache is None:
             lib = _lib.load()
@@ -197,8 +231,6 @@ class EntityTable:
             _lib.check(lib.drin_build_entity_cache(C.byref(call.cfg), C.byref(call.batch), C.byref(pc), prepared.data_ptr(),
                                                    cache.data_ptr(), n, ws.data_ptr(), ws.numel(), stream))
             self._cache, self._cache_key = cache, key
-            if self.cache_format == "mixed_f16":
-                self._warn_if_rows_far_off_scale()
         return self._cache
 
     @property
@@ -222,7 +254,7 @@ class EntityTable:
     def to(self, device) -> "EntityTable":
         mv = lambda t: None if t is None else t.to(device)  # noqa: E731
         moved = EntityTable(mv(self.text), mv(self.mask), mv(self.image), mv(self.object), mv(self.object_score))
-        moved.cache_enabled, moved.cache_format = self.cache_enabled, self.cache_format
+        moved.cache_enabled, moved.cache_format, moved.cache_format_forced = self.cache_enabled, self.cache_format, self.cache_format_forced
         return moved
 
     def gather(self, index: torch.Tensor):

@@ -350,6 +350,12 @@ DRIN_API int drin_forward_prepared(const drin_config* cfg, const drin_batch* bat
  * counterpart. */
 DRIN_API int32_t drin_workgroups_per_mention(const drin_config* cfg, int32_t cached);
 
+/* How drin_forward_prepared evaluates the folded entity-image contraction x_i (W_h1 W_ei)^T - 57 % of the path's FLOPs - for this
+ * configuration (`indexed`: drin_batch.entity_index is set): 0 = the exact fp32 kernel (DRIN_PREC_F32), else the number of
+ * bf16 / fp16 MFMA passes: 3 (split-bf16), 2 (bf16-stored image rows are exact in their hi plane), 1 (DRIN_PREC_BF16X3_IF16 where its
+ * gate holds: see drin_precision).  The library's own gate, for callers that account executed FLOPs (bench.py). */
+DRIN_API int32_t drin_image_contraction_passes(const drin_config* cfg, int32_t indexed);
+
 /* The caller-side check of drin_batch.index_status: waits for `stream` (the ONE entry point that synchronises: it exists to be
  * the point where the caller would synchronise anyway), copies the four words to the host and returns DRIN_OK, or
  * DRIN_E_INDEX with the pair and the value in drin_last_error() - what drin/data.py:87-93 reports as an IndexError - after

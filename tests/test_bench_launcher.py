@@ -120,3 +120,66 @@ def test_latest_counter_file_is_found_by_round_number_not_a_hard_coded_list(tmp_
     existing = sorted(int(f.split("_")[0][1:]) for f in os.listdir(os.path.join(REPO, "profiles"))
                       if f.endswith("_hbm_traffic.json") and f[1:].split("_")[0].isdigit())
     assert n == existing[-1]
+
+
+def test_eight_ranks_rendezvous_and_report_on_the_stub_path():
+    """The first `bench.py --gpus 8` on an 8-GPU node must not also be the first 8-process rendezvous: eight stub ranks
+    (CPU + gloo, no GPU, no library) launched by bench.py itself - one JSON line from rank 0, eight per-rank times, the bracket the
+    MAX over ranks, whole-job value; train mode paces every rank to the slowest through the per-step all-reduce."""
+    r = _run("--gpus", "8", "--stub", "--steps", "3", "--warmup", "1", "--mode", "train")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert len(lines[0].encode()) < 4096
+    line = json.loads(lines[0], parse_constant=_reject_constant)
+    assert line["n_gpus"] == 8 and len(line["rank_ms_per_step"]) == 8 and line["stub"] is True
+    assert min(line["rank_ms_per_step"]) >= 7.9                        # rank 7 sleeps 8 ms per step: the all-reduce paces all eight
+    assert line["ms_per_step"] >= max(line["rank_ms_per_step"]) * 0.999
+    assert line["collectives_issued"] == 4
+    r = _run("--gpus", "8", "--stub", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(2 * 8 / (line["ms_per_step"] * 2e-3), rel=1e-6)
+
+
+def test_a_line_that_cannot_be_shrunk_still_comes_out_as_contract_fields(capsys, monkeypatch):
+    """`emit()` never ends a run without a JSON line (the former `assert` did, and vanished under `python -O`): a record
+    whose headline cannot be brought under the limit leaves the contract fields, strings cut short, marked `truncated`."""
+    sys.path.insert(0, REPO)
+    import bench
+    monkeypatch.setattr(bench, "_REAL_STDOUT", None)
+    rec = {"metric": "m" * 300, "value": 1.5, "unit": "pairs/s", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 3.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3", "data": "synthetic",
+           "config": {"workload": "w" * 9000}, "roofline": {"bound": "hbm", "kernel": "k" * 9000}, "parity": {"mentions": "x" * 9000}}
+    bench.emit(rec, legs_file=None)
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(out) == 1 and len(out[0]) <= bench.LINE_LIMIT
+    line = json.loads(out[0], parse_constant=_reject_constant)
+    assert line["truncated"] is True and line["value"] == 1.5 and line["unit"] == "pairs/s" and line["n_gpus"] == 1
+    assert len(line["config"]["workload"]) == 80
+
+
+def test_roofline_of_the_line_says_that_its_traffic_is_replayed():
+    sys.path.insert(0, REPO)
+    import bench
+    assert {"traffic_replayed", "traffic_file"} <= set(bench._ROOF_KEYS)
+    head = bench.headline_only({"metric": "m", "value": 1.0, "roofline": {"bound": "hbm", "traffic": 5e10, "traffic_replayed": True,
+                                                                         "traffic_file": "profiles/r6_hbm_traffic.json", "traffic_source": "long sentence"},
+                                "cpu_baseline": {"value": 4.5e4, "b64_value": 1.9e4, "unit": "pairs/s", "cores": 16, "kind": "port", "sample": "s", "host": {}}})
+    assert head["roofline"]["traffic_replayed"] is True and head["roofline"]["traffic_file"].endswith("hbm_traffic.json")
+    assert "traffic_source" not in head["roofline"] and head["cpu_baseline"]["b64_value"] == 1.9e4
+
+
+def test_the_fp16_pass_gate_bench_reports_is_the_librarys():
+    """`bench.if16_taken` asks `drin_image_contraction_passes` (it used to re-implement the gate)."""
+    sys.path.insert(0, REPO)
+    import bench
+    from drin_amd.config import wikidiverse_config, wikimel_config
+    wm, wd = wikimel_config(), wikidiverse_config()
+    assert bench.if16_taken("bf16x3_if16", wm, "wikimel", 4096) is True
+    assert bench.if16_taken("bf16x3_if16", wm, "wikimel", 64) is False          # fewer than 128 tiles of 256 x 256
+    assert bench.if16_taken("bf16x3_if16", wm, "wikimel", 4096, "bf16") is False
+    assert bench.if16_taken("bf16x3_if16", wm, "table", 4096) is False
+    assert bench.if16_taken("bf16x3_if16", wd, "wikidiverse", 16384) is False   # N = 11 < 64
+    assert bench.if16_taken("bf16x3", wm, "wikimel", 4096) is False

@@ -65,20 +65,41 @@ def _oracle_kwargs(cfg):
     return O.config_kwargs(cfg)
 
 
-class _relu_inputs:
-    """Records min |x| of every `F.relu` call made inside the block (the oracle resolves activations by name at call time,
-    `model.py:117-118`): how close a case's pre-activations come to relu's kink."""
+class _relu_spy:
+    """Wraps `F.relu` inside the block (the oracle resolves activations by name at call time, `model.py:117-118`).
+    Recording: `near` lists every relu INPUT ELEMENT closer to the kink than `thr` - as (call number, flat index, value) - EXACT
+    ZEROS EXCLUDED (a masked or zero-padded input is zero on every path, and relu'(0) = 0 is torch's convention the kernels must
+    follow: nothing to excuse there).  Replaying with `flip`: the listed elements keep their VALUE but take the derivative of the
+    other side of the kink (x > 0: derivative 0; x < 0: derivative 1) - the gradient the case has if the arithmetic of the path
+    under test put those pre-activations on the other side."""
+
+    def __init__(self, thr: float, flip=()):
+        self.thr, self.near, self.calls = thr, [], 0
+        self.flip = {}
+        for c, j in flip:
+            self.flip.setdefault(c, []).append(j)
 
     def __enter__(self):
         import torch.nn.functional as F
-        self._F, self._orig, self.mins = F, F.relu, []
+        self._F, self._orig = F, F.relu
 
         def spy(x, *a, **k):
-            if x.numel():
-                self.mins.append(float(x.detach().abs().min()))
-            return self._orig(x, *a, **k)
+            c, self.calls = self.calls, self.calls + 1
+            xd = x.detach()
+            close = (xd.abs() < self.thr) & (xd != 0)
+            if bool(close.any()):
+                flat = xd.reshape(-1)
+                self.near += [(c, int(j), float(flat[j])) for j in close.reshape(-1).nonzero().flatten().tolist()]
+            out = self._orig(x, *a, **k)
+            if c in self.flip:
+                sel = torch.zeros(x.numel(), dtype=torch.bool)
+                sel[torch.tensor(self.flip[c])] = True
+                sel = sel.view(x.shape)
+                out = torch.where(sel & (xd > 0), xd, out)               # value kept, derivative 0
+                out = torch.where(sel & (xd < 0), out + (x - xd), out)   # value 0, derivative 1
+            return out
         F.relu = spy
-        return self.mins
+        return self
 
     def __exit__(self, *exc):
         self._F.relu = self._orig
@@ -133,39 +154,63 @@ def test_random_configuration_every_path_against_the_oracle(i):
         # case (a sigmoid vertex activation squeezes all scores into a 2e-4 band: the fp32 oracle is then 7e-4 from the fp64
         # one - tools/probes/fuzz_grad_case.py, profiles/r4_fuzz_grad_cases.txt) and scales the bound; a relu vertex meets its
         # kink: a split-bf16 product moves a pre-activation by 1e-6 and one element in ten thousand flips its derivative
-        p64 = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
-        with _relu_inputs() as relu_in:
-            out64 = O.forward(p64, batch[:14], dtype=torch.float64, **_oracle_kwargs(cfg))
         # relu has no derivative at 0: a pre-activation closer to it than the arithmetic resolves (split-bf16 moves a mention-sized
         # pre-activation by up to ~5e-6, exact fp32 by ~1e-7) may sit on either side, and ONE flipped unit of a last-layer MENTION
         # vertex - which all N scores of its mention share - moved a LayerNorm bias gradient by 15 % (seed 349 of a 640-seed sweep:
-        # min |z| 4.6e-6, relu vertices 0.147, the same case with gelu 1.1e-5; tools/probes/fuzz_case_diff.py).  A gradient MISMATCH
-        # is therefore excused - said aloud, not silently - only when the fp64 oracle shows a relu input that close to the kink; a
-        # case that is near a kink and still agrees counts like any other.
-        near_kink = bool(relu_in) and min(relu_in) < (2e-5 if precision == "bf16x3_all" else 1e-6)
-        loss64 = ((out64 * w.double()).sum() if cfg.num_candidates_data == 0
-                  else O.triplet_loss(batch[14].double(), out64, cfg.triplet_margin))
-        g64 = torch.autograd.grad(loss64, list(p64.values()), allow_unused=True)
+        # min |z| 4.6e-6, relu vertices 0.147, the same case with gelu 1.1e-5; tools/probes/fuzz_case_diff.py).  What may be
+        # excused is BOUNDED: only relu input ELEMENTS within that resolution of the kink count (exact zeros - masked
+        # or padded inputs - never do), and a mismatching case passes only if ALL its gradients agree, to the same bound, with the
+        # fp64 oracle re-run with the derivative of some subset of exactly those elements flipped; anything else fails.
+        thr = 2e-5 if precision == "bf16x3_all" else 1e-6
+        w64 = w.double() if cfg.num_candidates_data == 0 else None
+
+        def grads64(flip=()):
+            p64 = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+            with _relu_spy(thr, flip) as spy:
+                out64 = O.forward(p64, batch[:14], dtype=torch.float64, **_oracle_kwargs(cfg))
+            loss64 = (out64 * w64).sum() if w64 is not None else O.triplet_loss(batch[14].double(), out64, cfg.triplet_margin)
+            return torch.autograd.grad(loss64, list(p64.values()), allow_unused=True), spy.near
+
+        g64, near = grads64()
         assert abs(loss.item() - ref_loss.item()) <= 2e-5
         base = 5e-4 if precision == "bf16x3_all" else 5e-5
         if cfg.gcn_vertex_activation == "relu" and precision == "bf16x3_all":
             base *= 4
-        mismatches = []
-        for (k, p), r, r64 in zip(model.named_parameters(), ref_g, g64):
+        named = list(model.named_parameters())
+        conds = {}
+        for (k, p), r, r64 in zip(named, ref_g, g64):
             assert k in ref_p
-            got = p.grad
-            assert (got is None) == (r is None), f"case {i}: grad of {k} is {'None' if got is None else 'set'}, reference {'None' if r is None else 'set'} ({cfg})"
+            assert (p.grad is None) == (r is None), f"case {i}: grad of {k} is {'None' if p.grad is None else 'set'}, reference {'None' if r is None else 'set'} ({cfg})"
             if r is not None and r64.norm().item() > 1e-10:
-                cond = (r.double() - r64).norm().item() / r64.norm().item()          # the fp32 oracle's own distance
-                rel = (got.cpu().double() - r64).norm().item() / r64.norm().item()
+                conds[k] = (r.double() - r64).norm().item() / r64.norm().item()          # the fp32 oracle's own distance
+
+        def mismatches_against(yardstick):
+            out_ = []
+            for (k, p), r64 in zip(named, yardstick):
+                if k not in conds or r64 is None or r64.norm().item() <= 1e-10:
+                    continue
+                rel = (p.grad.cpu().double() - r64).norm().item() / r64.norm().item()
                 # (5 x: the fp32 oracle's distance is ONE sample of the case's conditioning, the library's another; sigmoid vertices
                 #  squeeze all scores into a band of 4e-5 .. 2e-4, where a 1 400-seed sweep saw the two samples 3.5 x and 5.5 x apart:
                 #  profiles/r5_fuzz_deep_sweep.txt)
-                if rel > max(base, (10 if cfg.gcn_vertex_activation == "sigmoid" else 5) * cond):
-                    mismatches.append(f"case {i}: grad of {k} off by {rel:.2e} (fp32 oracle itself: {cond:.2e}) ({cfg}, B={B}, {precision})")
-        if mismatches and near_kink:
-            print(f"case {i}: {len(mismatches)} gradient(s) differ with a relu input {min(relu_in):.1e} from its kink (fp64 oracle): no gradient is "
-                  f"defined there at this precision - excused: {mismatches[0][:160]}")
+                if rel > max(base, (10 if cfg.gcn_vertex_activation == "sigmoid" else 5) * conds[k]):
+                    out_.append(f"case {i}: grad of {k} off by {rel:.2e} (fp32 oracle itself: {conds[k]:.2e}) ({cfg}, B={B}, {precision})")
+            return out_
+
+        mismatches = mismatches_against(g64)
+        if mismatches and near:
+            import itertools
+            units = [(c, j) for c, j, _v in near]
+            if len(units) <= 4:
+                subsets = [s_ for n_ in range(1, len(units) + 1) for s_ in itertools.combinations(units, n_)]
+            else:                                                      # many elements that close: each alone, then all of them
+                subsets = [(u,) for u in units[:15]] + [tuple(units)]
+            excused = next((s_ for s_ in subsets if not mismatches_against(grads64(s_)[0])), None)
+            assert excused is not None, (f"{mismatches[0]} - and no flip of the {len(units)} relu input(s) within {thr:g} of the kink "
+                                         f"({[f'{v:.1e}' for _c, _j, v in near][:6]}) explains it")
+            print(f"case {i}: {len(mismatches)} gradient(s) differ from the fp64 oracle's and ALL agree with the fp64 oracle whose relu derivative "
+                  f"is flipped at {len(excused)} of the {len(units)} input(s) within {thr:g} of the kink - no gradient is defined there at this "
+                  f"precision: {mismatches[0][:140]}")
         else:
             assert not mismatches, mismatches[0]
     # table form + per-entity cache (inference; the library says so when a geometry has no table form)

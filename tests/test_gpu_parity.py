@@ -578,7 +578,7 @@ def test_backward_vs_oracle_autograd_reference_batch():
             continue
         denom = r.norm().item() + 1e-12
         rel = (got - r).norm().item() / denom
-        assert rel <= 2e-3, (k, rel)
+        assert rel <= 2e-4, (k, rel)
 
 
 @pytest.mark.parametrize("maker,B,edge_type", [(DrinConfig, 16, "dynamic"), (wikimel_config, 3, "dynamic"), (DrinConfig, 5, "static")])
@@ -611,7 +611,7 @@ def test_vector_edges_vs_oracle(maker, B, edge_type):
         assert (got is None) == (r is None), k
         if r is not None:
             rel = (got - r).norm().item() / (r.norm().item() + 1e-12)
-            assert rel <= 2e-3, (k, rel)
+            assert rel <= 2e-4, (k, rel)
 
 
 def test_backward_bf16x3_vs_oracle_autograd():
@@ -842,7 +842,7 @@ def test_random_geometries_all_paths_vs_oracle(seed):
             assert (got is None) == (r is None), (seed, k)
             if r is not None and r.norm().item() > 1e-8:
                 rel = (got - r).norm().item() / r.norm().item()
-                assert rel <= 2e-3, (seed, k, rel)
+                assert rel <= 2e-4, (seed, k, rel)
 
 
 @pytest.mark.parametrize("seed", range(10))

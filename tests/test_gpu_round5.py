@@ -177,7 +177,9 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
          (`model.py:84-92`): the fp16 object row holds it to ~1e-5, and that edge multiplies the candidate's layer-1 image vertex in the
          mention aggregate mean_n(ii ei) (`model.py:143-144`) - a vertex 1e6 times the others' DOMINATES the mean, so the aggregate
          inherits the relative error of ONE edge instead of averaging 101 of them.  Measured: the fp32 rows stay within 1e-6 of the
-         fp64 oracle, the mixed rows are 1e-5 .. 7e-5 off on half of such mentions (inside the 1e-4 bar, outside the 1e-5 guard).
+         fp64 oracle, the mixed rows are 1e-5 .. 7e-5 off on half of such mentions (inside the 1e-4 bar, outside the 1e-5 guard) -
+         which is why `EntityTable` does not USE the format for such a table (round 6: the build scans the image rows and falls back
+         to fp32 rows; asserted here: <= 1e-5 from the fp64 oracle); the fp16 fields are then forced (`force=True`) and
          The test pins the cause by EMULATION: the fp64 oracle with exactly the three fp16 fields passed through the format's
          rounding (`oracle/precision_emulation.py`) reproduces the HIP scores of the mixed rows to 1e-5 - the deviation is the
          storage format's and nothing else's (`include/drin_hip.h`, drin_cache_format, states the limit);
@@ -212,9 +214,16 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
     with torch.no_grad():
         table.enable_cache(True)
         full = model(ib).cpu()
+        # round 6: the format meets the guard BY CONSTRUCTION - the build's scan of the image table finds the 50 rows x 1e6 and the 3e37
+        # row and gives this table fp32 rows (saying so); the fp16 fields below are FORCED, to keep the limit of the format pinned
         table.enable_cache(True, format="mixed_f16")
-        with pytest.warns(UserWarning, match="mixed_f16.*51 of 600 entity image rows"):      # the 50 rows x 1e6 and the 3e37 row: said at build time
+        with pytest.warns(UserWarning, match="mixed_f16: 51 of 600 entity image rows.*gets fp32 cache rows"):
+            fell_back = model(ib).cpu()
+        assert table.cache_format_used == "f32" and torch.equal(fell_back, full)
+        table.enable_cache(True, format="mixed_f16", force=True)
+        with pytest.warns(UserWarning, match=r"mixed_f16 \(forced\): 51 of 600 entity image rows"):
             mixed = model(ib).cpu()
+        assert table.cache_format_used == "mixed_f16"
     table.enable_cache(False)
     assert torch.isfinite(mixed).all() and torch.isfinite(full).all()
     _threads()
@@ -244,7 +253,8 @@ def test_mixed_f16_cache_rows_of_extreme_magnitude_against_the_fp64_oracle():
     assert own[b_rows].max().item() <= 1e-5 and e32[b_rows].max().item() <= 1e-5          # the fp32 rows are NOT noise there
     assert (mixed[b_rows].double() - emul).abs().max().item() <= 1e-5                      # the deviation IS the storage format's rounding
     assert (only_ohat - emul).abs().max().item() <= 1e-5                                   # ... of the object row (the static ii edge)
-    assert e16[b_rows].max().item() <= 2e-4
+    assert e16[b_rows].max().item() <= 1e-4                                                # the FORCED format: inside the bar (measured 6.7e-5)
+    assert (fell_back[ab].double() - ref64).abs().max().item() <= 1e-5                     # what a caller gets: the guard, by construction
     c = slice(2 * third, B)
     print(f"group C (a 3e37 row among the candidates): finite; formats apart max {d[c].max().item():.2e}, {(d[c] <= 1e-5).float().mean().item():.4f} within 1e-5")
     assert (d[c] <= 1e-5).float().mean().item() >= 0.95

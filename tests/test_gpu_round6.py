@@ -180,3 +180,77 @@ def test_device_topk_counters_match_the_reference_source(golden_dir):
             assert abs(m.accuracies()[q] - float(g[f"acc2{tag}_k{k}"])) <= 1e-7
         cases += 1
     assert cases == 8
+
+
+def test_mixed_f16_cache_rows_inside_the_scale_criterion_meet_the_guard():
+    """`EntityTable` uses the mixed-f16 row format only for tables whose image rows stay within `MIXED_F16_MAX_ROW_RATIO` (8) x the
+    median row's magnitude (the rows beyond it can dominate a mention's `mean_n(ii ei)` and carry ONE fp16 edge's rounding into the
+    scores: `tests/test_gpu_round5.py`).  Here 40 of 600 rows are x 6 - inside the criterion, so the fp16 fields ARE used, silently -
+    and every mention lists one of them: both row formats within 1e-5 of the fp64 oracle (bar 1e-4), the formats 1e-5 apart at most."""
+    import warnings
+    from oracle import drin_oracle as O
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    E, B, N = 600, 48, cfg.num_candidates_model
+    g = torch.Generator(device=DEV).manual_seed(4)
+    img = torch.randn(E, cfg.resnet_embed_dim, device=DEV, generator=g)
+    img[0:40] *= 6.0
+    table = EntityTable(torch.randn(E, 4, cfg.bert_embed_dim, device=DEV, generator=g), torch.ones(E, 4, dtype=torch.int64, device=DEV),
+                        img, torch.randn(E, 1, cfg.resnet_embed_dim, device=DEV, generator=g), torch.rand(E, 1, device=DEV, generator=g))
+    men = synth.make_device_batch(cfg.with_(num_candidates_data=0), B, 12, DEV)
+    cand = torch.randint(40, E, (B, N), device=DEV, generator=g)
+    cand[torch.arange(B), torch.randint(0, N - 1, (B,), generator=torch.Generator().manual_seed(5))] = torch.arange(B, device=DEV) % 40
+    sims = 20.0 + 5.0 * torch.randn(2, B, N, device=DEV, generator=g)
+    ib = IndexedBatch(men[:7], table, cand, sims[0], sims[1])
+    model = Model(cfg).to(DEV).eval()
+    model.load_state_dict(sd)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")                                 # no fallback, no warning: the table is inside the criterion
+        table.enable_cache(True)
+        full = model(ib).cpu()
+        table.enable_cache(True, format="mixed_f16")
+        mixed = model(ib).cpu()
+    assert table.cache_format_used == "mixed_f16"
+    table.enable_cache(False)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    host = [t.cpu() for t in ib.gathered()]
+    rows = slice(0, 24)
+    with torch.no_grad():
+        ref64 = O.forward({k: v.double() for k, v in sd.items()}, [t[rows] for t in host], dtype=torch.float64)
+    e32, e16 = (full[rows].double() - ref64).abs().max().item(), (mixed[rows].double() - ref64).abs().max().item()
+    apart = (mixed - full).abs().max().item()
+    print(f"image rows x 6 among the candidates (inside the x 8 criterion): fp32 rows {e32:.2e}, mixed-f16 rows {e16:.2e} from the fp64 oracle; formats apart {apart:.2e}")
+    assert e32 <= 1e-5 and e16 <= 1e-5 and apart <= 1e-5
+    assert (mixed[:, :-1].argmax(1) == full[:, :-1].argmax(1)).all()
+
+
+@pytest.mark.parametrize("factor", [1e-4, 1e4])
+def test_f16_image_contraction_extreme_row_next_to_a_scaled_weight(factor):
+    """the fp16 form's epilogue used to form `row_scale * weight_scale` first - with the row scale at its clamp (2^126, a
+    3e37 / 3e38 row; 2^-99 for a 1e-30 row) and a weight scale other than 1 that product overflowed or flushed although
+    acc * row_scale * weight_scale is representable.  The exponents are now added and applied by one ldexp.  Rows x 3e37, x 1e-30,
+    x 1e6 and an all-zero row in a batch scored with W_ei x 1e-4 / x 1e4: the same finite pattern as the exact-fp32 path, every score
+    both paths hold within 1e-5."""
+    cfg = wikimel_config(max_entity_attr_token_len=4)
+    sd = synth.make_state_dict(cfg, 7)
+    sd["vertex_encoder.entity_image_linear.weight"] = sd["vertex_encoder.entity_image_linear.weight"] * factor
+    B = 1024
+    batch = synth.make_device_batch(cfg, B, 57, DEV)[:14]
+    img = batch[9]                                                    # [B, N, 1, R]
+    img[0, 3] *= 3e37 / img[0, 3].abs().max()
+    img[1] *= 1e-30
+    img[2] *= 1e6
+    img[3, 5] = 0.0
+    models = []
+    for prec in ("f32", "bf16x3_if16"):
+        m = Model(cfg, precision=prec).to(DEV).eval()
+        m.load_state_dict(sd)
+        models.append(m)
+    with torch.no_grad():
+        ref, got = models[0](batch), models[1](batch)
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref)), "the fp16 pass changed which scores are finite"
+    both = torch.isfinite(got) & torch.isfinite(ref)
+    assert both[1:].all()                                             # only the 3e37 mention may leave fp32's range, in both paths alike
+    err = (got - ref)[both].abs().max().item()
+    print(f"W_ei x {factor:g} with rows x 3e37 / 1e-30 / 1e6 / 0: max |score - exact fp32| {err:.2e}; {int(both[0].sum())} of {both.shape[1]} scores of the 3e37 mention finite")
+    assert err <= 1e-5

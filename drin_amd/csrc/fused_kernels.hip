@@ -114,6 +114,10 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
   //  the top of a pair and worked off BEFORE the token walk, so that the walk starts with its count already there.  In-process A/B on
   //  one resident batch (tools/probes/inprocess_lib_ab.py): 7.96 against 7.97 ms, bit-identical scores - the other seven waves of the CU
   //  already cover a wave's round trips - for 256 instead of 230 VGPRs and spills in the bf16 and XSCALE instantiations.)
+  // (Measured in round 6 and dropped - profiles/r6_stream_prefetch_ab.txt: the NEXT pair's candidate row and mask word requested at the
+  //  top of the current pair, so that the chain row index -> mask words -> token count -> first token loads no longer starts cold.
+  //  In-process A/B on one resident batch: fp32 rows 8.31 against 8.31 ms, bf16-stored rows 4.75 against 4.78, WikiDiverse 1.16 / 1.17 -
+  //  bit-identical scores, four registers: the CU's other seven waves already cover a wave's cold start.)
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
     // entity row: the pair itself, or a row of the entity tables (on-device form of data.py:87-93)
@@ -551,17 +555,27 @@ __global__ void __launch_bounds__(256) k_pair_layer1(const PairArgs a) {
   Row<DV> S_t = zero_row<DV>(), S_i = zero_row<DV>();
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
+#ifdef DRIN_ABLATE_ROW_TRAFFIC   // timing ablation only (wrong results): the same arithmetic on four cache-resident rows, nothing stored
+    const int64_t p_ld = b * a.N + (n & 3);
+    const Row<DV> ht = load_row<DV>(a.h_text + p_ld * D, lane, D4);
+    const Row<DV> hi = load_row<DV>(a.h_image + p_ld * D, lane, D4);
+#else
     const Row<DV> ht = load_row_stream<DV>(a.h_text + p * D, lane, D4);  // read once: streaming cache policy
     const Row<DV> hi = load_row_stream<DV>(a.h_image + p * D, lane, D4);
+#endif
     const float e_tt = a.e0m[p], e_ti = a.e0m[M + p], e_it = a.e0m[2 * M + p], e_ii = a.e0m[3 * M + p];
     const Row<DV> et1 = ln_gelu_row_lds<DV, GENERIC_ACT>(combine_rows_lds<DV>(ht, e_tt, l_hm_t, e_it, l_hm_i, l_ct, lane, D4),
                                                          l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
+#ifdef DRIN_ABLATE_ROW_TRAFFIC
+    if (a.ln_eps < 0.f) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);   // never: keeps the values live
+#else
     if (a.et1) store_row<DV>(a.et1 + p * D, et1, lane, D4);
     if (a.et1_hi) store_row_planes<DV>(a.et1_hi, a.et1_lo, p * D, et1, lane, D4);
-    axpy_row<DV>(S_t, a.e1m[p], et1);
+#endif
+    axpy_row_pk<DV>(S_t, a.e1m[p], et1);
     const Row<DV> ei1 = ln_gelu_row_lds<DV, GENERIC_ACT>(combine_rows_lds<DV>(hi, e_ti, l_hm_t, e_ii, l_hm_i, l_ci, lane, D4),
                                                          l_gamma, l_beta, lane, D4, a.ln_eps, a.act_v);
-    axpy_row<DV>(S_i, a.e1m[M + p], ei1);
+    axpy_row_pk<DV>(S_i, a.e1m[M + p], ei1);
   }
   for (int w = 0; w < 4; ++w) {
     __syncthreads();
@@ -659,12 +673,16 @@ __global__ void __launch_bounds__(256) k_pair_final(const FinalArgs a) {
   const float xx = wave_sum(dot_rows<DV>(mt2, mt2));
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const int64_t p = b * a.N + n;
+#ifdef DRIN_ABLATE_ROW_TRAFFIC
+    const Row<DV> h = load_row<DV>(a.h2 + (b * a.N + (n & 3)) * D, lane, D4);
+#else
     const Row<DV> h = load_row_stream<DV>(a.h2 + p * D, lane, D4);
+#endif
     const Row<DV> et2 = ln_gelu_row_lds<DV, GENERIC_ACT>(
         combine_rows_lds<DV>(h, a.e1m[p], l_const, a.e1m[2 * M + p], l_const + LD, l_const + 2 * LD, lane, D4),
         l_const + 3 * LD, l_const + 4 * LD, lane, D4, a.ln_eps, a.act_v);
-    const float xy = wave_sum(dot_rows<DV>(mt2, et2));
-    const float yy = wave_sum(dot_rows<DV>(et2, et2));
+    const float xy = wave_sum(dot_rows_pk<DV>(mt2, et2));
+    const float yy = wave_sum(dot_rows_pk<DV>(et2, et2));
     if (lane == 0) a.scores[p] = cosine_from_sums(xy, xx, yy, a.cos_eps);
   }
 }

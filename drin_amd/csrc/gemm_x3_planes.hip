@@ -582,7 +582,11 @@ __global__ void __launch_bounds__(THREADS, 2)
           if (col >= N) continue;   // N % 4 == 0 (checked by the launcher)
           float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]);
           if (F16) o = scale_pow2(o, rs);
+#ifdef DRIN_ABLATE_GEMM_STORES   // timing ablation only: the product without its [M, N] fp32 result leaving the chip
+          if (ldc < 0) st4(C + row * ldc + col, o + bv[b][j]);
+#else
           st4(C + row * ldc + col, o + bv[b][j]);
+#endif
         }
     }
 }
@@ -917,6 +921,9 @@ __global__ void __launch_bounds__(THREADS, 2)
           float* dst = C + row * ldc + col;
           float4 o = make_float4(acc[a][b][i][j][0], acc[a][b][i][j][1], acc[a][b][i][j][2], acc[a][b][i][j][3]) + bv[b][j];
           if (accumulate) o = o + ld4(dst);
+#ifdef DRIN_ABLATE_GEMM_STORES
+          if (ldc < 0)
+#endif
           st4(dst, o);
         }
     }

@@ -10,6 +10,40 @@ struct Row {
   float4 v[V];
 };
 
+// ---- packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 per lane and issue slot) --------------------------------
+// The row kernels are VALU-ISSUE bound (round 6 SQ counters, profiles/r6_stream_sq.json: k_pair_final keeps the vector pipe busy
+// 100 % of its cycles, k_pair_layer1 78 %; ~33 vector instructions per element, none packed).  LayerNorm + GELU + the combine and the
+// dots on PAIRS of columns: every fma / mul / add serves two elements; the two transcendentals (v_rcp_f32, v_exp_f32) and |x| stay
+// per element.  Same operations on every element as the scalar form (the sums of a row are associated differently: a few ulps on
+// mean / variance).  -DDRIN_PK_ROWS=0 builds the scalar form (A/B: tools/variant_ab.sh).
+#ifndef DRIN_PK_ROWS
+#define DRIN_PK_ROWS 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk(float a, float b) { return f32x2{a, b}; }
+__device__ __forceinline__ f32x2 splat2(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 lo2(const float4& v) { return f32x2{v.x, v.y}; }
+__device__ __forceinline__ f32x2 hi2(const float4& v) { return f32x2{v.z, v.w}; }
+__device__ __forceinline__ float4 join2(f32x2 a, f32x2 b) { return make_float4(a.x, a.y, b.x, b.y); }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// gelu_fast on two values: erf by Abramowitz-Stegun 7.1.26 as there; 0.5 x (1 + sign(x) erf|z|) = 0.5 x + 0.5 |x| erf|z| saves the two
+// sign transfers
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 ax = pk(fabsf(x.x), fabsf(x.y));
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 den = pk_fma(z, splat2(0.3275911f), splat2(1.0f));
+  const f32x2 t = pk(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y));
+  f32x2 p = pk_fma(t, splat2(1.061405429f), splat2(-1.453152027f));
+  p = pk_fma(t, p, splat2(1.421413741f));
+  p = pk_fma(t, p, splat2(-0.284496736f));
+  p = pk_fma(t, p, splat2(0.254829592f));
+  p = t * p;
+  const f32x2 arg = (z * z) * (-1.44269504088896340736f);                      // exp(-z^2) = 2^(-z^2 log2 e)
+  const f32x2 ex = pk(__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y));
+  const f32x2 erf_abs = pk_fma(-p, ex, splat2(1.0f));                          // erf(|x| / sqrt 2)
+  return pk_fma(ax * 0.5f, erf_abs, x * 0.5f);
+}
+
 // Which float4 column of the row register slot jj of lane `lane` holds.  Default: lane, lane + 64, ... (one 16-byte fp32 load
 // per slot).  PAIR (rows stored as bf16): slots 2 q and 2 q + 1 are the two halves of EIGHT consecutive columns
 // 8 (lane + 64 q) .. + 7 - one 16-byte load of bf16 per pair of slots instead of two 8-byte ones (8-byte accesses move at
@@ -138,6 +172,32 @@ __device__ __forceinline__ void axpy_row(Row<V>& acc, float w, const Row<V>& x) 
 #pragma unroll
   for (int j = 0; j < V; ++j) acc.v[j] = fma4(w, x.v[j], acc.v[j]);
 }
+// the same two on the packed pipe (row kernels of the folded paths; a dot's terms are summed in another association)
+template <int V>
+__device__ __forceinline__ float dot_rows_pk(const Row<V>& a, const Row<V>& b) {
+#if DRIN_PK_ROWS
+  f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < V; ++j) s2 = pk_fma(hi2(a.v[j]), hi2(b.v[j]), pk_fma(lo2(a.v[j]), lo2(b.v[j]), s2));
+  return s2.x + s2.y;
+#else
+  return dot_rows<V>(a, b);
+#endif
+}
+template <int V>
+__device__ __forceinline__ void axpy_row_pk(Row<V>& acc, float w, const Row<V>& x) {
+#if DRIN_PK_ROWS
+  const f32x2 w2 = {w, w};
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const f32x2 l = pk_fma(w2, f32x2{x.v[j].x, x.v[j].y}, f32x2{acc.v[j].x, acc.v[j].y});
+    const f32x2 h = pk_fma(w2, f32x2{x.v[j].z, x.v[j].w}, f32x2{acc.v[j].z, acc.v[j].w});
+    acc.v[j] = make_float4(l.x, l.y, h.x, h.y);
+  }
+#else
+  axpy_row<V>(acc, w, x);
+#endif
+}
 template <int V>
 __device__ __forceinline__ Row<V> zero_row() {
   Row<V> r;
@@ -163,10 +223,44 @@ __device__ __forceinline__ float dot_row_lds(const Row<V>& a, const float* lds, 
 template <int DV, bool GENERIC_ACT = false>
 __device__ __forceinline__ Row<DV> ln_gelu_row_lds(const Row<DV>& h, const float* gamma, const float* beta, int lane,
                                                    int D4, float eps, int act = DRIN_ACT_GELU) {
+  const float inv_d = 1.0f / (float)(D4 * 4);
+#if DRIN_PK_ROWS
+  if constexpr (!GENERIC_ACT) {
+    f32x2 s2 = splat2(0.f);
+#pragma unroll
+    for (int j = 0; j < DV; ++j) s2 = (s2 + lo2(h.v[j])) + hi2(h.v[j]);   // (columns past D4 are zero in every caller's row)
+    const float mu_ = wave_sum(s2.x + s2.y) * inv_d;
+    const f32x2 mu2 = splat2(mu_);
+    f32x2 q2 = splat2(0.f);
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const int c4 = lane + 64 * j;
+      if (c4 < D4) {
+        const f32x2 dl = lo2(h.v[j]) - mu2, dh = hi2(h.v[j]) - mu2;
+        q2 = pk_fma(dl, dl, q2);
+        q2 = pk_fma(dh, dh, q2);
+      }
+    }
+    const f32x2 rstd2 = splat2(1.0f / sqrtf(wave_sum(q2.x + q2.y) * inv_d + eps));
+    Row<DV> y;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const int c4 = lane + 64 * j;
+      if (c4 < D4) {
+        const float4 g = ld4(gamma + c4 * 4), bt = ld4(beta + c4 * 4);
+        const f32x2 yl = gelu_fast2(pk_fma((lo2(h.v[j]) - mu2) * rstd2, lo2(g), lo2(bt)));
+        const f32x2 yh = gelu_fast2(pk_fma((hi2(h.v[j]) - mu2) * rstd2, hi2(g), hi2(bt)));
+        y.v[j] = join2(yl, yh);
+      } else {
+        y.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return y;
+  }
+#endif
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < DV; ++j) s += (h.v[j].x + h.v[j].y) + (h.v[j].z + h.v[j].w);
-  const float inv_d = 1.0f / (float)(D4 * 4);
   // (Measured in round 4 and dropped - profiles/r4_ln_stats_ab.txt: both moments in ONE round of wave reductions,
   //  var = E[x^2] - mu^2, so that the mean -> centred squares chain is one stage shorter.  Same box, alternating: the row
   //  kernels of the headline 1.12 -> 1.24 ms, of config 5 3.35 -> 3.48 ms - slower, although it is fewer instructions; the
@@ -207,9 +301,16 @@ __device__ __forceinline__ Row<DV> combine_rows_lds(const Row<DV>& base, float w
 #pragma unroll
   for (int j = 0; j < DV; ++j) {
     const int c4 = lane + 64 * j;
-    if (c4 < D4)
+    if (c4 < D4) {
+#if DRIN_PK_ROWS
+      const float4 a1 = ld4(u1 + c4 * 4), a2 = ld4(u2 + c4 * 4), cc = ld4(c + c4 * 4);
+      const f32x2 w1_ = splat2(w1), w2_ = splat2(w2);
+      r.v[j] = join2(pk_fma(w1_, lo2(a1), pk_fma(w2_, lo2(a2), lo2(base.v[j]) + lo2(cc))),
+                     pk_fma(w1_, hi2(a1), pk_fma(w2_, hi2(a2), hi2(base.v[j]) + hi2(cc))));
+#else
       r.v[j] = fma4(w1, ld4(u1 + c4 * 4), fma4(w2, ld4(u2 + c4 * 4), base.v[j] + ld4(c + c4 * 4)));
-    else
+#endif
+    } else
       r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   return r;

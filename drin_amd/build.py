@@ -22,7 +22,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdrin_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "stream_kernels.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_x3_planes.hip", "gemm_rows.hip", "gemm_tn_bf16x3.hip", "gcn_kernels.hip", "backward_kernels.hip", "fused_kernels.hip", "fused_forward.hip", "vector_kernels.hip", "loss_kernels.hip", "entity_cache.hip", "optim_kernels.hip"]
+SOURCES = ["api.hip", "stream_kernels.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_x3_planes.hip", "gemm_tn_bf16x3.hip", "gcn_kernels.hip", "backward_kernels.hip", "fused_kernels.hip", "fused_forward.hip", "vector_kernels.hip", "loss_kernels.hip", "entity_cache.hip", "optim_kernels.hip"]
 
 
 def _hipcc() -> str:

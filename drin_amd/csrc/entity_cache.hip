@@ -918,12 +918,8 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
                                  vertex_act(cfg)));
   // (5) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h2;
-  const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
-  // (round 6) contraction + LayerNorm + GELU + cosine in one launch on full-row tiles (gemm_rows.hip): h2 never stored
-  const bool rows_final = planes && vertex_act(cfg) == DRIN_ACT_GELU &&
-                          rows_final_fits(M, N, D, D, D, D, e1_hi, e1_hi + MD, w2, w2 + (size_t)D * D);
-  if (rows_final) {
-  } else if (planes) {
+  if (planes) {
+    const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
     DRIN_TRY(launch_gemm_x3_planes(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, nullptr, h2, D, M, D, D, st));
   } else {
     DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
@@ -950,7 +946,6 @@ DRIN_API int drin_forward_cached(const drin_config* cfg, const drin_batch* b, co
   fa.ln_eps = cfg->layer_norm_eps;
   fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;
-  if (rows_final) return launch_rows_final(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, fa, D, st);
   return launch_pair_final(fa, st);
 }
 

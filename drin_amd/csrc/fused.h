@@ -138,12 +138,4 @@ int launch_pair_layer1(const PairArgs& a, hipStream_t st);
 int launch_mention_input2(const float* part, const float* mt1, float* out, int B, int D, int N, int chunks,
                           hipStream_t st);
 int launch_pair_final(const FinalArgs& a, hipStream_t st);
-// The layer-2 entity-text contraction et' W_h2^T AND k_pair_final's arithmetic in one launch on 128-row x 768-column tiles
-// (gemm_rows.hip): the [M, 768] fp32 product never leaves the chip.  `a.h2` is not used.  rows_final_fits: whether a call may take it
-// (D = 768, split-bf16 planes, candidate lists of >= 64, >= 32 768 pairs; DRIN_ROWS_FINAL=0 in the environment turns it off).
-bool rows_final_fits(int64_t M, int N_candidates, int D, int K, int64_t lda, int64_t ldb, const void* a_hi, const void* a_lo, const void* b_hi,
-                     const void* b_lo);
-int launch_rows_final(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb, const FinalArgs& a,
-                      int K, hipStream_t st);
-
 }  // namespace drin

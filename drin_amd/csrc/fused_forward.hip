@@ -516,12 +516,12 @@ static int forward_prepared_on_stream(const drin_config* cfg, const drin_batch* 
                                  vertex_act(cfg)));
   // (8) layer-2 entity-text contraction, vertex and score
   float* h2 = ws + L.h_text;
-  const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
-  // (round 6) contraction + LayerNorm + GELU + cosine in ONE launch on full-row tiles where the call is large enough: h2 never stored
-  const bool rows_final = planes && vertex_act(cfg) == DRIN_ACT_GELU &&
-                          rows_final_fits(M, N, D, D, D, D, e1_hi, e1_hi + MD, w2, w2 + (size_t)D * D);
-  if (rows_final) {
-  } else if (planes) {
+  // (Round 6, built and dropped - profiles/r6_full_row_ab.txt, tools/probes/r6_full_row/, commit 8a5bc6b: this contraction and k_pair_final's
+  //  arithmetic in ONE launch on 96-row x 768-column tiles, so that h2 never goes to HBM.  Correct, and slower: a full-row tile needs all
+  //  768 weight rows per K-step for 96 activation rows - 1.56 x the LDS-DMA instructions per MFMA of the 256 x 256 tile - and its K-loop
+  //  alone took what the 256 x 256 kernel takes including its store (1.20 against 1.15 ms); the epilogue's vector work came on top.)
+  if (planes) {
+    const __bf16* w2 = reinterpret_cast<const __bf16*>(pb + P.p_wh2);
     DRIN_TRY(launch_gemm_x3_planes(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, nullptr, h2, D, M, D, D, st, psk, pskf));
   } else {
     DRIN_TRY(launch_gemm_nt(ws + L.et1, D, L2.w_h, D, nullptr, h2, D, M, D, D, false, prec, st));
@@ -543,7 +543,6 @@ static int forward_prepared_on_stream(const drin_config* cfg, const drin_batch* 
   fa.ln_eps = cfg->layer_norm_eps;
   fa.act_v = vertex_act(cfg);
   fa.cos_eps = cfg->cosine_eps;
-  if (rows_final) return launch_rows_final(e1_hi, e1_hi + MD, D, w2, w2 + (size_t)D * D, D, fa, D, st);
   return launch_pair_final(fa, st);
 }
 

@@ -373,3 +373,90 @@ def test_design_md_quotes_what_its_tracked_files_say():
             with open(doc, "w") as f:
                 f.write(text)
             assert len(mod.check(doc)[1]) == bad, (text, mod.check(doc))
+
+
+# ---- round 6: host logic of the index report, the cache-format criterion, the exported contraction gate --------------------------
+def _cpu_table(rows=50, scale_row=None, factor=1.0):
+    from drin_amd.model import EntityTable
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(rows, 1, 64, generator=g)
+    if scale_row is not None:
+        img[scale_row] *= factor
+    return EntityTable(torch.randn(rows, 4, 16, generator=g), torch.ones(rows, 4, dtype=torch.int64), img,
+                       torch.randn(rows, 1, 64, generator=g), torch.rand(rows, 1, generator=g)), img
+
+
+def test_mixed_f16_cache_format_is_used_only_inside_its_scale_criterion():
+    """`EntityTable.enable_cache(format="mixed_f16")`: one scan of the image table per table VERSION; a row more than
+    MIXED_F16_MAX_ROW_RATIO (8) x the median row's magnitude makes the table fall back to fp32 rows, with a warning saying so;
+    `force=True` keeps the fp16 fields (and still says what it found); a table inside the criterion is silent."""
+    import warnings
+    t, img = _cpu_table()
+    t.enable_cache(True, format="mixed_f16")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert t._effective_cache_format() == "mixed_f16"
+    img[7] *= 20.0                                                   # in place: the version counter moves, the next build rescans
+    with pytest.warns(UserWarning, match="1 of 50 entity image rows.*gets fp32 cache rows"):
+        assert t._effective_cache_format() == "f32"
+    scans = []
+    orig = torch.Tensor.amax
+    try:
+        torch.Tensor.amax = lambda self, *a, **k: (scans.append(1), orig(self, *a, **k))[1]
+        with pytest.warns(UserWarning):
+            t._effective_cache_format()                              # same table version: no second pass over the table
+    finally:
+        torch.Tensor.amax = orig
+    assert not scans
+    t.enable_cache(True, format="mixed_f16", force=True)
+    with pytest.warns(UserWarning, match=r"mixed_f16 \(forced\): 1 of 50"):
+        assert t._effective_cache_format() == "mixed_f16"
+    img[7] /= 20.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert t._effective_cache_format() == "mixed_f16"
+    t.enable_cache(True, format="f32")
+    assert t._effective_cache_format() == "f32"
+    with pytest.raises(ValueError):
+        t.enable_cache(True, format="fp8")
+
+
+def test_index_report_words_become_an_index_error():
+    """`Model.check_indices`: the four status words the kernels leave (`drin_batch.index_status`: flag, pair, value low / high) raise
+    IndexError naming row and pair - a negative row too - and are cleared; clean words raise nothing."""
+    m = Model(TINY_WD)
+    dev = torch.device("cpu")
+    words = m._status_words(dev)
+    assert words.dtype == torch.int32 and words.tolist() == [0, 0, 0, 0]
+    m.check_indices()
+    words.copy_(torch.tensor([1, 205, -4, -1], dtype=torch.int32))                # row -4 at pair 205
+    with pytest.raises(IndexError, match=r"row -4 at pair 205 .*drin/data.py:87-93"):
+        m.check_indices()
+    assert words.tolist() == [0, 0, 0, 0]
+    words.copy_(torch.tensor([1, 7, 1001, 0], dtype=torch.int32))
+    with pytest.raises(IndexError, match="row 1001 at pair 7"):
+        m.check_indices()
+    words[0] = 1                                                                  # the training paths report the flag alone
+    with pytest.raises(IndexError, match="a row of a training batch"):
+        m.check_indices()
+    m.check_indices()
+
+
+def test_library_reports_how_it_runs_the_image_contraction():
+    """`drin_image_contraction_passes`: the library's own gate for the one-pass fp16 contraction (host-side, no launch)."""
+    import ctypes as C
+    from drin_amd import _lib
+    lib = _lib.load()
+    c = _lib.DrinConfigC()
+    _lib.check(lib.drin_default_config(C.byref(c)))
+    c.batch, c.num_candidates, c.embed_dim, c.image_dim, c.entity_tokens = 4096, 101, 768, 2048, 64
+    for prec, feat, indexed, want in ((_lib.PREC_F32, _lib.FEAT_F32, 0, 0), (_lib.PREC_BF16X3, _lib.FEAT_F32, 0, 3),
+                                      (_lib.PREC_BF16X3, _lib.FEAT_BF16, 0, 2), (_lib.PREC_BF16X3_IF16, _lib.FEAT_F32, 0, 1),
+                                      (_lib.PREC_BF16X3_IF16, _lib.FEAT_F32, 1, 3), (_lib.PREC_BF16X3_IF16, _lib.FEAT_BF16, 0, 2)):
+        c.precision, c.feature_dtype = prec, feat
+        assert lib.drin_image_contraction_passes(C.byref(c), indexed) == want, (prec, feat, indexed)
+    c.precision, c.feature_dtype, c.num_candidates = _lib.PREC_BF16X3_IF16, _lib.FEAT_F32, 11          # short lists: split-bf16
+    assert lib.drin_image_contraction_passes(C.byref(c), 0) == 3
+    c.num_candidates, c.batch = 101, 64                                                                 # fewer than 128 tiles
+    assert lib.drin_image_contraction_passes(C.byref(c), 0) == 3
+    assert lib.drin_index_status(None, None) == _lib.E_NULL

@@ -17,7 +17,19 @@ cp $O/train64_bench_under_rocprof.json $P/${R}_train_b64_bench_under_rocprof.jso
 cp $O/train512_bench_under_rocprof.json $P/${R}_train_b512_bench_under_rocprof.json
 cp $O/train64_rccl_world1_bench_under_rocprof.json $P/${R}_train_b64_rccl_world1_bench_under_rocprof.json
 cp $O/config5_1M_stream.json $P/${R}_config5_1M_mentions_streamed.json
-cp $O/hbm_traffic.json $P/${R}_hbm_traffic.json
+# (a round profiled in two gpurun calls leaves the per-entity-cache sections in hbm_traffic_part2.json: joined here)
+python3 - $O/hbm_traffic.json $O/hbm_traffic_part2.json $P/${R}_hbm_traffic.json <<'PY'
+import json, os, sys
+a = json.load(open(sys.argv[1]))
+if os.path.exists(sys.argv[2]):
+    b = json.load(open(sys.argv[2]))
+    for k, v in b.items():
+        if isinstance(v, dict) and isinstance(a.get(k), dict):
+            a[k].update(v)
+        elif k not in a:
+            a[k] = v
+json.dump(a, open(sys.argv[3], "w"), indent=1)
+PY
 cp gpurun_out/pmc_mfma/${R}_mfma_pmc.json $P/${R}_mfma_pmc.json
 cp "$(stats bf16f)" $P/${R}_wikimel_b4096_bf16_features_kernel_stats.csv
 cp $O/bf16f_bench_under_rocprof.json $P/${R}_wikimel_b4096_bf16_features_bench_under_rocprof.json

@@ -35,17 +35,21 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/if16 -- python3 bench
 echo "[profile_round] wikidiverse / fp16 contraction done"
 fi
 if [ "$PART" = "1" ]; then ls $O; exit 0; fi
+# (gpurun_out/ does not travel to the GPU box: part 2 starts from an empty directory there, and what it writes is merged over the
+#  local copy afterwards - so its traffic sections go to their own file; tools/copy_profiles.sh joins the two)
+HT=$O/hbm_traffic.json
+if [ "$PART" = "2" ]; then HT=$O/hbm_traffic_part2.json; fi
 TAB="--workload table --batch 4096 --entity-cache"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tab -- python3 bench.py $TAB --steps 5 --warmup 2 $HEAD --legs-file $O/table_cache_bench_under_rocprof.json > /dev/null 2> $O/tab.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tab -- python3 bench.py $TAB --steps 2 --warmup 1 $HEAD > $O/pmc_fetch_tab.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_tab -- python3 bench.py $TAB --steps 2 --warmup 1 $HEAD > $O/pmc_write_tab.log 2>&1
-python3 tools/collect_pmc.py $O/pmc_fetch_tab $O/pmc_write_tab $O/hbm_traffic.json kernels_table_cache "python3 bench.py $TAB --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
+python3 tools/collect_pmc.py $O/pmc_fetch_tab $O/pmc_write_tab $HT kernels_table_cache "python3 bench.py $TAB --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
 # the same chunk from DRIN_CACHE_MIXED_F16 rows: kernel stats + its own PMC passes (section kernels_table_cache_mixed_f16)
 TABM="$TAB --cache-format mixed_f16"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tabm -- python3 bench.py $TABM --steps 5 --warmup 2 $HEAD --legs-file $O/table_cache_mixed_f16_bench_under_rocprof.json > /dev/null 2> $O/tabm.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tabm -- python3 bench.py $TABM --steps 2 --warmup 1 $HEAD > $O/pmc_fetch_tabm.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_tabm -- python3 bench.py $TABM --steps 2 --warmup 1 $HEAD > $O/pmc_write_tabm.log 2>&1
-python3 tools/collect_pmc.py $O/pmc_fetch_tabm $O/pmc_write_tabm $O/hbm_traffic.json kernels_table_cache_mixed_f16 "python3 bench.py $TABM --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
+python3 tools/collect_pmc.py $O/pmc_fetch_tabm $O/pmc_write_tabm $HT kernels_table_cache_mixed_f16 "python3 bench.py $TABM --steps 2 --warmup 1 $HEAD" >> $O/hbm_traffic.txt
 echo "[profile_round] table cache done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 bench.py --mode train --batch 64 --steps 20 --warmup 30 --legs-file $O/train64_bench_under_rocprof.json > /dev/null 2> $O/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train512 -- python3 bench.py --mode train --batch 512 --steps 20 --warmup 30 --legs-file $O/train512_bench_under_rocprof.json > /dev/null 2> $O/train512.err

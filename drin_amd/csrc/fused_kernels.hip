@@ -219,6 +219,8 @@ __global__ void __launch_bounds__(256, 2) k_entity_stream(const StreamArgs a) {
             for (int j = 0; j < DV; ++j) acc.v[j] = acc.v[j] + r[u].v[j];
         }
       }
+      // (round 6, measured and dropped: SIX fp32 token rows in flight per wave - 256 VGPRs, same bits - 8.61 = 8.62 ms and 8.41 = 8.41 ms in
+      //  two processes: profiles/r6_stream_prefetch_ab.txt; eight rows spill)
       for (; t + 4 <= stop; t += 4) {  // 4 token rows (12 KB at D = 768) in flight per wave
         const Row<DV> r0 = load_row_stream<DV>(base + (int64_t)t * D, lane, D4);
         const Row<DV> r1 = load_row_stream<DV>(base + (int64_t)(t + 1) * D, lane, D4);

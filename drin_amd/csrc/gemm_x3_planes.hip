@@ -323,6 +323,14 @@ constexpr int kDmaPlace = DRIN_P4_DMA_PLACE;
 #define DRIN_P4_REBALANCE 1
 #endif
 constexpr bool kRebalance = DRIN_P4_REBALANCE != 0 && kDmaPlace == 0;   // the fp32-A kernel's phase schedule (see there)
+// fp32-A kernel, rebalanced schedule: the split of a landed activation unit (24 vector instructions + 4 LDS writes per thread) runs
+// INSIDE the MFMA half of its phase - one vector instruction per MFMA gap (an MFMA holds the SIMD's vector issue for 8 of its 16
+// cycles: MI355X_MICROARCH.md) - instead of between the counted wait and the phase's first barrier, where its ~250 cycles
+// delayed all eight waves twice per K-block.
+#ifndef DRIN_P4_SPLIT_IN_MMA
+#define DRIN_P4_SPLIT_IN_MMA 1
+#endif
+constexpr bool kSplitInMma = DRIN_P4_SPLIT_IN_MMA != 0 && kRebalance;
 // the counted wait before a phase's first barrier (two DMA / load instructions per unit per wave)
 __device__ __forceinline__ void wait_units() {
   if (kDmaPlace == 0) {
@@ -656,17 +664,24 @@ __global__ void __launch_bounds__(THREADS, 2)
         src.ptr[u][i] = bp + g * ldb * 2;
       }
     src.ptr[0][0] = src.ptr[0][1] = src.ptr[1][0] = src.ptr[1][1] = nullptr;
-    const int c4 = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const int c4 = threadIdx.x & 7;
+    // which two rows of a 128-row unit this thread loads and splits.  kSplitInMma: a wave GROUP splits exactly the 64 rows its own
+    // waves read (group g: rows 64 g .. 64 g + 63), so that the split may run inside the group's MFMA half - nobody of the other
+    // group, which runs one barrier apart, ever reads what this group has not yet written.  Otherwise rows t / 8 and t / 8 + 64.
+    int urow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      urow[i] = p4::kSplitInMma ? (int)(threadIdx.x >> 8) * 64 + (int)((threadIdx.x & 255) >> 3) + 32 * i : (int)(threadIdx.x >> 3) + 64 * i;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        int64_t g = m0 + h * 128 + row + 64 * i;
+        int64_t g = m0 + h * 128 + urow[i];
         g = g < M ? g : M - 1;
         arow[h][i] = A + g * lda + c4 * 4;
       }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a_off[i] = swz16(row + 64 * i, c4 >> 1) + ((c4 & 1) << 3);
+    for (int i = 0; i < 2; ++i) a_off[i] = swz16(urow[i], c4 >> 1) + ((c4 & 1) << 3);
   }
 
   f32x4 acc[2][2][4][2];
@@ -794,6 +809,26 @@ __global__ void __launch_bounds__(THREADS, 2)
         for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], ah[i], cc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
+    // the same MFMAs with the split of one activation unit between the three groups of eight (kSplitInMma)
+    auto mma_split = [&](f32x4 (&cc)[4][2], const bf16x8 (&fh)[2], const bf16x8 (&fl)[2], char* dst_buf, int half, f32x4v v0, f32x4v v1) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], al[i], cc[i][j], 0, 0, 0);
+      split_store(v0, dst_buf + half * p4::UNIT_BYTES, a_off[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[j], ah[i], cc[i][j], 0, 0, 0);
+      split_store(v1, dst_buf + half * p4::UNIT_BYTES, a_off[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[j], ah[i], cc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the planes are in LDS before the barrier that publishes them to this group
+    };
     for (int kb = 0; kb < nkb; ++kb) {
       char* buf = smem + (kb & 1) * p4::BUF;
       char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
@@ -816,9 +851,14 @@ __global__ void __launch_bounds__(THREADS, 2)
       load_a(0, kn, a0v0, a0v1);
       wait4();
       landed(a1v0, a1v1);
-      store_a(buf, 1, a1v0, a1v1);
-      barrier();
-      mma_b(acc[0][1], bh, bl);
+      if (p4::kSplitInMma) {
+        barrier();
+        mma_split(acc[0][1], bh, bl, buf, 1, a1v0, a1v1);
+      } else {
+        store_a(buf, 1, a1v0, a1v1);
+        barrier();
+        mma_b(acc[0][1], bh, bl);
+      }
       barrier();
       // phase 2: quadrant 11
       read_a(buf, 1);
@@ -831,9 +871,14 @@ __global__ void __launch_bounds__(THREADS, 2)
       load_a(1, kn, a1v0, a1v1);
       wait4();
       landed(a0v0, a0v1);
-      store_a(nbuf, 0, a0v0, a0v1);
-      barrier();
-      mma_b(acc[1][0], b0h, b0l);
+      if (p4::kSplitInMma) {
+        barrier();
+        mma_split(acc[1][0], b0h, b0l, nbuf, 0, a0v0, a0v1);
+      } else {
+        store_a(nbuf, 0, a0v0, a0v1);
+        barrier();
+        mma_b(acc[1][0], b0h, b0l);
+      }
       barrier();
     }
   } else

@@ -602,6 +602,7 @@ class Model(nn.Module):
         self.validate_indices = os.environ.get("DRIN_VALIDATE", "") not in ("", "0")
         self._index_status: Dict[torch.device, torch.Tensor] = {}
         self._index_watch: List = []                          # (host copy, event): async read-backs of calls still in flight
+        self._index_pool: List = []                           # landed (pinned host words, event) pairs, re-used
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         modes = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16x3_all": _lib.PREC_BF16X3_ALL, "bf16x3_if16": _lib.PREC_BF16X3_IF16}
         if precision not in modes:
@@ -718,12 +719,13 @@ class Model(nn.Module):
     def _watch_indices(self, device: torch.device) -> None:
         """After a table-form call: raise at once when validating eagerly, else start an asynchronous read-back of the status
         words which `forward` / `check_indices` look at once it has landed (no synchronisation is added to the step)."""
+        if torch.cuda.is_current_stream_capturing():          # inside a graph capture: no read-back, no event (the status words are still
+            return                                            # written by the replayed kernels: check_indices() after a replay sees them)
         if self.validate_indices:
             self.check_indices()
             return
-        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host, ev = self._index_pool.pop() if self._index_pool else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
         host.copy_(self._status_words(device), non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         self._index_watch.append((host, ev))
 
@@ -743,9 +745,10 @@ class Model(nn.Module):
                     t.zero_()
         else:
             while self._index_watch and self._index_watch[0][1].query():
-                host, _ev = self._index_watch.pop(0)
+                host, ev = self._index_watch.pop(0)
                 if int(host[0]) != 0 and bad is None:
                     bad = host.tolist()
+                self._index_pool.append((host, ev))               # pinned words and event are re-used by the next call
             if bad is not None:
                 self._index_watch.clear()
                 for t in self._index_status.values():
@@ -754,7 +757,7 @@ class Model(nn.Module):
             self._raise_bad_index(bad)
 
     def forward(self, batch) -> torch.Tensor:
-        if self._index_watch:
+        if self._index_watch and not torch.cuda.is_current_stream_capturing():
             self.check_indices(wait=False)
         B = batch.candidates.shape[0] if isinstance(batch, IndexedBatch) else batch[0].shape[0]
         if B > self.MAX_CALL_MENTIONS:

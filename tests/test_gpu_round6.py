@@ -254,3 +254,27 @@ def test_f16_image_contraction_extreme_row_next_to_a_scaled_weight(factor):
     err = (got - ref)[both].abs().max().item()
     print(f"W_ei x {factor:g} with rows x 3e37 / 1e-30 / 1e6 / 0: max |score - exact fp32| {err:.2e}; {int(both[0].sum())} of {both.shape[1]} scores of the 3e37 mention finite")
     assert err <= 1e-5
+
+
+def test_an_epoch_over_a_split_with_a_bad_candidate_row_raises(tmp_path):
+    """End to end: `.npy` tables -> device-resident split -> `MELRunner`.  One candidate row of the validation split is corrupted on
+    the device (E + 3: past the tables): the epoch - whose kernels clamp it, so nothing faults - ends in `IndexError` where
+    `run_epoch` synchronises anyway (the reference's `drin/data.py:87-93` raises when it gathers); the intact splits run through."""
+    from drin_amd.data import create_device_splits, load_entity_table, write_synthetic_dataset
+    from drin_amd.train import MELRunner, seed_everything
+    cfg = DrinConfig(dataset_name="wikimel", num_candidates_data=6, max_entity_attr_token_len=6, batch_size=4, num_epoch=1,
+                     test_epoch_interval=1, shuffle_train_data=False, metrics_topk=(1, 3), acc_correction=(0.0, 0.0, 0.0), **TINY)
+    write_synthetic_dataset(cfg, str(tmp_path), sizes=(12, 4, 4), seed=4, num_entities=30)
+    seed_everything(cfg.seed)
+    model = Model(cfg, precision="f32").to(DEV)
+    table = load_entity_table(cfg, str(tmp_path), DEV)
+    train, valid, test = create_device_splits(cfg, str(tmp_path), DEV)
+    runner = MELRunner(cfg, model, DEV, entity_table=table)
+    ok = runner.run_epoch(test, 2, None)                                  # an intact split: no report
+    assert ok.loss == ok.loss
+    valid.tensors[7][1, 2] = table.num_entities + 3                        # candidate rows live in slot 7 of the split's tensors
+    with pytest.raises(IndexError, match="outside the entity tables"):
+        runner.run_epoch(valid, 1, None)
+    again = runner.run_epoch(test, 2, None)                               # the report was cleared by the raise
+    assert again.loss == pytest.approx(ok.loss, rel=1e-6)
+    runner.close()

@@ -700,6 +700,13 @@ class Model(nn.Module):
             self.invalidate()
         return flat
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle of the Module: the index watch holds HIP events and pinned buffers of calls in flight - per-process
+        # bookkeeping, not state (a copy starts with none; its first table-form call makes its own status words)
+        state = self.__dict__.copy()
+        state["_index_watch"], state["_index_pool"], state["_index_status"] = [], [], {}
+        return state
+
     # ---- candidate rows outside the entity tables (drin/data.py:87-93 raises IndexError) ------------------------------
     def _status_words(self, device: torch.device) -> torch.Tensor:
         t = self._index_status.get(device)

@@ -441,7 +441,9 @@ typedef enum {
  * autograd's thread - is bracketed by hipEvents on its stream.  drin_profile_end synchronises those
  * events, returns per-class GPU milliseconds and launch counts (arrays of DRIN_KC_COUNT) and closes the
  * profile.  One profile per process at a time; this is the library's only process-wide state and it is
- * inert unless a profile is open.  The loss kernels (drin_triplet_topk) count under DRIN_KC_EDGE. */
+ * inert unless a profile is open.  The loss kernels (drin_triplet_topk) count under DRIN_KC_EDGE.  The events belong to the
+ * device that is current when drin_profile_begin runs: a profile times the calls whose streams live on THAT device (launches on
+ * another device run untimed - their results are unaffected). */
 DRIN_API int drin_profile_begin(int max_launches);
 DRIN_API int drin_profile_end(double* ms_by_class, int64_t* launches_by_class);
 DRIN_API const char* drin_kernel_class_name(int kernel_class);

@@ -49,6 +49,7 @@ def test_out_of_range_candidate_rows_raise_like_the_reference_fancy_index(cache)
     cfg, sd, table, men, cand = _table_case(E=E, cache=cache)
     model = Model(cfg, precision="bf16x3_all").to(DEV).eval()
     model.load_state_dict(sd)
+    model.validate_indices = False                                    # the lazy forms first, whatever DRIN_VALIDATE says
     good = IndexedBatch(men[:7], table, cand.to(DEV), men[12], men[13])
     bad_rows = cand.clone()
     bad_rows[1, 0], bad_rows[2, 5] = -4, E + 9
@@ -84,6 +85,7 @@ def test_out_of_range_candidate_rows_in_a_training_step_raise():
     cfg, sd, table, men, cand = _table_case(E=E, B=100, cache=False, bert_embed_dim=128, gcn_embed_dim=128)   # >= 1024 pairs: the indexed kernels
     model = Model(cfg).to(DEV).train()
     model.load_state_dict(sd)
+    model.validate_indices = False
     bad_rows = cand.clone()
     bad_rows[7, 3] = E
     model(IndexedBatch(men[:7], table, cand.to(DEV), men[12], men[13])).sum().backward()
@@ -267,6 +269,7 @@ def test_an_epoch_over_a_split_with_a_bad_candidate_row_raises(tmp_path):
     write_synthetic_dataset(cfg, str(tmp_path), sizes=(12, 4, 4), seed=4, num_entities=30)
     seed_everything(cfg.seed)
     model = Model(cfg, precision="f32").to(DEV)
+    model.validate_indices = False                                        # the epoch-end check is what this test is about
     table = load_entity_table(cfg, str(tmp_path), DEV)
     train, valid, test = create_device_splits(cfg, str(tmp_path), DEV)
     runner = MELRunner(cfg, model, DEV, entity_table=table)

@@ -369,6 +369,17 @@ __device__ __forceinline__ void issue_unit(const Src& s, char* buf, int kb) {
 // 16 x 16 tile takes two MFMAs per K-block (sub-block 0, sub-block 1: the k order of 32-wide blocks), 16 per phase, for half
 // the K-blocks.  Row m of A was divided by row_scale[m] and B by *b_scale when their planes were written (powers of two: exact;
 // fp16's range never matters): the epilogue multiplies output row m by row_scale[m] * *b_scale.
+// -DDRIN_P4_STAMPS (tools/probes/p4_stamps_probe.py): cycle stamps of one workgroup (block 121 of a launch of more than 100 000 rows) of
+// the two four-phase kernels - per K-block and phase: phase start, after the first barrier (MFMAs may start), after the MFMAs - for one
+// wave of each wave group.  Stamps sit only where the wave has no LDS read in flight anyway (s_memtime counts in lgkmcnt).
+#ifdef DRIN_P4_STAMPS
+__device__ unsigned long long g_p4_stamps[2 * 2 * 32 * 4 * 3];   // [kernel: 0 planes, 1 fp32-A][wave group][K-block][phase][point]
+#define DRIN_P4_STAMP(KERNEL, KB, PHASE, POINT)                                                                               \
+  if (stamp_on && (KB) < 32)                                                                                                  \
+    g_p4_stamps[((((KERNEL) * 2 + (int)(threadIdx.x >> 8)) * 32 + (KB)) * 4 + (PHASE)) * 3 + (POINT)] = __builtin_readcyclecounter()
+#else
+#define DRIN_P4_STAMP(KERNEL, KB, PHASE, POINT)
+#endif
 template <bool A_LO = true, bool F16 = false>
 __global__ void __launch_bounds__(THREADS, 2)
     k_gemm_x3_planes_p4(const __bf16* __restrict__ a_hi, const __bf16* __restrict__ a_lo, int64_t lda,
@@ -520,27 +531,33 @@ __global__ void __launch_bounds__(THREADS, 2)
   // second third of the MFMAs.  The unit a phase's wait must retire was issued two phases earlier: with the phase's own issue
   // in front of the wait (0) two newer units are outstanding - vmcnt(4) - with it behind the barrier (1, 2) one - vmcnt(2).
   auto none = [] {};
-#define DRIN_P4_PHASE(READS, UNIT, ACC)                                  \
+#ifdef DRIN_P4_STAMPS
+  const bool stamp_on = blockIdx.x == 121 && M > 100000 && (threadIdx.x & 255) == 0 && !F16;
+#endif
+#define DRIN_P4_PHASE(READS, UNIT, ACC, PH)                              \
   {                                                                      \
+    DRIN_P4_STAMP(0, kb, PH, 0);                                         \
     READS;                                                               \
     if (p4::kDmaPlace == 0) p4::issue_unit<UNIT, KB_BYTES>(src, nbuf, kn);         \
     p4::wait_units();                                                    \
     barrier();                                                           \
+    DRIN_P4_STAMP(0, kb, PH, 1);                                         \
     if (p4::kDmaPlace == 1) p4::issue_unit<UNIT, KB_BYTES>(src, nbuf, kn);         \
     if (p4::kDmaPlace == 2)                                              \
       mma(ACC, [&] { p4::issue_unit<UNIT, KB_BYTES>(src, nbuf, kn); });            \
     else                                                                 \
       mma(ACC, none);                                                    \
+    DRIN_P4_STAMP(0, kb, PH, 2);                                         \
     barrier();                                                           \
   }
   for (int kb = 0; kb < nkb; ++kb) {
     const char* buf = smem + (kb & 1) * p4::BUF;
     char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
     const int kn = kb + 1 < nkb ? kb + 1 : kb;
-    DRIN_P4_PHASE((read_a(buf, 0), read_b(buf, 0)), 0, acc[0][0])   // quadrant 00
-    DRIN_P4_PHASE(read_b(buf, 1), 2, acc[0][1])                      // quadrant 01 (A0 fragments stay)
-    DRIN_P4_PHASE(read_a(buf, 1), 3, acc[1][1])                      // quadrant 11 (B1 fragments stay)
-    DRIN_P4_PHASE(read_b(buf, 0), 1, acc[1][0])                      // quadrant 10 (A1 fragments stay)
+    DRIN_P4_PHASE((read_a(buf, 0), read_b(buf, 0)), 0, acc[0][0], 0)   // quadrant 00
+    DRIN_P4_PHASE(read_b(buf, 1), 2, acc[0][1], 1)                      // quadrant 01 (A0 fragments stay)
+    DRIN_P4_PHASE(read_a(buf, 1), 3, acc[1][1], 2)                      // quadrant 11 (B1 fragments stay)
+    DRIN_P4_PHASE(read_b(buf, 0), 1, acc[1][0], 3)                      // quadrant 10 (A1 fragments stay)
   }
 #undef DRIN_P4_PHASE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant units of the last block
@@ -829,11 +846,15 @@ __global__ void __launch_bounds__(THREADS, 2)
       __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the planes are in LDS before the barrier that publishes them to this group
     };
+#ifdef DRIN_P4_STAMPS
+    const bool stamp_on = blockIdx.x == 121 && M > 100000 && (threadIdx.x & 255) == 0;
+#endif
     for (int kb = 0; kb < nkb; ++kb) {
       char* buf = smem + (kb & 1) * p4::BUF;
       char* nbuf = smem + ((kb + 1) & 1) * p4::BUF;
       const int kn = kb + 1 < nkb ? kb + 1 : kb;
       // phase 0: quadrant 00
+      DRIN_P4_STAMP(1, kb, 0, 0);
       read_a(buf, 0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -844,41 +865,54 @@ __global__ void __launch_bounds__(THREADS, 2)
       p4::issue_unit<2>(src, nbuf, kn);
       wait4();
       barrier();
+      DRIN_P4_STAMP(1, kb, 0, 1);
       mma_b(acc[0][0], b0h, b0l);
+      DRIN_P4_STAMP(1, kb, 0, 2);
       barrier();
       // phase 1: quadrant 01
+      DRIN_P4_STAMP(1, kb, 1, 0);
       read_b(buf, 1);
       load_a(0, kn, a0v0, a0v1);
       wait4();
       landed(a1v0, a1v1);
       if (p4::kSplitInMma) {
         barrier();
+        DRIN_P4_STAMP(1, kb, 1, 1);
         mma_split(acc[0][1], bh, bl, buf, 1, a1v0, a1v1);
       } else {
         store_a(buf, 1, a1v0, a1v1);
         barrier();
+        DRIN_P4_STAMP(1, kb, 1, 1);
         mma_b(acc[0][1], bh, bl);
       }
+      DRIN_P4_STAMP(1, kb, 1, 2);
       barrier();
       // phase 2: quadrant 11
+      DRIN_P4_STAMP(1, kb, 2, 0);
       read_a(buf, 1);
       p4::issue_unit<3>(src, nbuf, kn);
       wait4();
       barrier();
+      DRIN_P4_STAMP(1, kb, 2, 1);
       mma_b(acc[1][1], bh, bl);
+      DRIN_P4_STAMP(1, kb, 2, 2);
       barrier();
       // phase 3: quadrant 10
+      DRIN_P4_STAMP(1, kb, 3, 0);
       load_a(1, kn, a1v0, a1v1);
       wait4();
       landed(a0v0, a0v1);
       if (p4::kSplitInMma) {
         barrier();
+        DRIN_P4_STAMP(1, kb, 3, 1);
         mma_split(acc[1][0], b0h, b0l, nbuf, 0, a0v0, a0v1);
       } else {
         store_a(nbuf, 0, a0v0, a0v1);
         barrier();
+        DRIN_P4_STAMP(1, kb, 3, 1);
         mma_b(acc[1][0], b0h, b0l);
       }
+      DRIN_P4_STAMP(1, kb, 3, 2);
       barrier();
     }
   } else
@@ -1029,6 +1063,11 @@ __global__ void __launch_bounds__(256) k_transpose_split_batch(const SplitBatch 
 
 }  // namespace x3p
 
+#ifdef DRIN_P4_STAMPS
+extern "C" __attribute__((visibility("default"))) int drin_debug_p4_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(drin::x3p::g_p4_stamps), sizeof(unsigned long long) * 2 * 2 * 32 * 4 * 3);
+}
+#endif
 #ifdef DRIN_STAMPS
 extern "C" __attribute__((visibility("default"))) int drin_debug_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(x3p::g_stamps), sizeof(unsigned long long) * (8 * 64 * 4 + 64));
